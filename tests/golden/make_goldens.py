@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the IMPORTED reference (/root/reference) in this container.
+
+Run once here (the reference cannot travel to the GPU box):
+    python tests/golden/make_goldens.py
+Writes tests/golden/*.npz (+ meta.json).  Inputs/weights are NOT stored: they are regenerated from
+`videocad_amd.synth` (integer hash) by seed.  The script also checks the oracle restatement
+(oracle/restatement.py) against the reference on every case and records the deviations in meta.json.
+
+Import recipe: transformers first, then stubs for timm/cv2/torchvision and the
+restated vit_pytorch (tests/golden/stubs), then /root/reference on sys.path; CWD = scratch dir holding a
+copy of class_weights.json (the reference trainer reads it CWD-relative and writes logs/ there).
+"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+
+import numpy as np
+import torch
+import transformers  # noqa: F401  (must precede the stubs)
+from transformers import GPT2Model  # noqa: F401
+
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+
+from videocad_amd import synth  # noqa: E402
+from oracle import restatement as O  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+SLICE_TENSORS = [
+    "state_embedding_model.to_patch_embedding.1.weight",
+    "state_embedding_model.to_patch_embedding.2.weight",
+    "state_embedding_model.pos_embedding",
+    "state_embedding_model.cls_token",
+    "state_embedding_model.transformer.layers.0.0.to_qkv.weight",
+    "state_embedding_model.transformer.layers.5.1.net.4.weight",
+    "state_embedding_model.transformer.norm.weight",
+    "cad_embedding_model.transformer.layers.3.0.to_out.0.weight",
+    "embed_state.weight", "embed_image.bias", "image_projection.weight", "embed_action.weight",
+    "timestep_embedding.weight",
+    "transformer_decoder.layers.0.self_attn.in_proj_weight",
+    "transformer_decoder.layers.0.multihead_attn.in_proj_bias",
+    "transformer_decoder.layers.7.linear1.weight",
+    "transformer_decoder.layers.7.norm3.weight",
+    "predict_action_class_0_4.weight", "predict_action_class_0_999.bias",
+]
+
+
+def sl(t, n=64):
+    """64 evenly spaced elements of the flattened tensor (deterministic slice)."""
+    f = t.detach().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return f[idx].numpy().copy()
+
+
+def build_reference(cfg_name, weights, scratch):
+    from model.model_factory import ModelFactory
+    from trainer import create_trainer
+    cfg = json.load(open(os.path.join(HERE, "model_configs.json")))[cfg_name]
+    sd = {k: torch.tensor(v) for k, v in weights.items()}
+    model, mtype = ModelFactory().create_model(cfg["model_name"], dict(cfg), "cpu", state_dict=sd)
+    missing = [k for k in sd if k not in model.state_dict()]
+    assert not missing, f"generated keys absent from the reference state_dict: {missing[:5]}"
+    for k, v in sd.items():                       # strict=False load really took every live tensor
+        assert torch.equal(model.state_dict()[k], v), k
+    pk = {"loader": [], "sampler": None}
+    def mk(use_mse):
+        return create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": use_mse, "experiment_name": "golden"},
+                              "cpu", mtype, rank=0)
+    return model, mk, cfg
+
+
+def tbatch(b):
+    return {k: (torch.tensor(v) if v is not None else None) for k, v in b.items()}
+
+
+def rel(a, b):
+    a = a.double(); b = b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def main():
+    scratch = tempfile.mkdtemp(prefix="vcad_golden_")
+    shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
+    os.chdir(scratch)
+    meta = {"generator": "tests/golden/make_goldens.py", "torch": torch.__version__,
+            "vit_source": "restated vit-pytorch>=1.2 (tests/golden/stubs/vit_pytorch) — UNPINNED upstream",
+            "cases": {}}
+    shapes = O.param_shapes()
+    weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
+    print("generated", sum(v.size for v in weights.values()), "live parameters")
+
+    # ------------------------------------------------------------------ case c1_full (+ c1_ragged)
+    model, mk, cfg = build_reference("cad_past_10_actions_and_states_timestep_embedding", weights, scratch)
+    live_names = set(weights)
+    for case, B, T, seed, lengths in [("c1_full", 2, 8, 1, None), ("c1_ragged", 2, 8, 2, [9, 6])]:
+        # fresh weights for every case (the previous case's Adam step mutated the model)
+        model.load_state_dict({k: torch.tensor(v) for k, v in weights.items()}, strict=False)
+        tr = mk(True)
+        batch_np = synth.make_batch(B, T, seed, lengths)
+        batch = tbatch(batch_np)
+        model.eval()
+        with torch.no_grad():
+            bd = tr.prepare_batch(batch)
+            cmds, params = model(tr._prepare_model_inputs(bd, False))
+            loss_f, metrics = tr.compute_loss((cmds, params), bd["actions"][:, 1:])
+            tr_nomse = mk(False)
+            loss_nomse, metrics_nomse = tr_nomse.compute_loss((cmds, params), bd["actions"][:, 1:])
+        # full step (eval mode => dropout off => deterministic): grads captured via hook before the clip
+        grads = {}
+        orig_clip = torch.nn.utils.clip_grad_norm_
+        def spy(parameters, max_norm, *a, **k):
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    grads[n] = p.grad.detach().clone()
+            out = orig_clip(model.parameters(), max_norm, *a, **k)
+            grads["__total_norm__"] = out.detach().clone()
+            return out
+        torch.nn.utils.clip_grad_norm_ = spy
+        loss_s, _ = tr._process_batch(batch)
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+        assert set(k for k in grads if k != "__total_norm__") == live_names, "live-parameter set differs from Appendix B"
+        post = {k: v.detach().clone() for k, v in model.state_dict().items() if k in live_names}
+
+        # oracle on the same case
+        ot = O.OracleTrainer(weights)
+        taps = {}
+        with torch.no_grad():
+            ocmds, oparams, _ = ot.forward(batch_np, taps)
+        oloss, ometrics, ototal, _, _ = ot.step(batch_np)
+        dev = {
+            "cmds_rel": rel(ocmds, cmds), "params_rel": rel(oparams, params),
+            "loss_abs": abs(float(oloss) - float(loss_s)),
+            "argmax_equal": bool((oparams.argmax(-1) == params.argmax(-1)).all() and (ocmds.argmax(-1) == cmds.argmax(-1)).all()),
+            "total_norm_rel": abs(ototal - float(grads["__total_norm__"])) / float(grads["__total_norm__"]),
+            "grad_rel_max": max(rel(ot.P[k].grad, grads[k]) for k in live_names if grads[k].norm() > 0),
+            "post_adam_maxabs": max(float((ot.P[k].detach() - post[k]).abs().max()) for k in live_names),
+            "metrics_equal": ometrics == metrics,
+        }
+        print(case, json.dumps(dev))
+        assert dev["cmds_rel"] < 1e-5 and dev["params_rel"] < 1e-5 and dev["argmax_equal"] and dev["metrics_equal"]
+        assert dev["grad_rel_max"] < 1e-3 and dev["post_adam_maxabs"] < 2e-6, dev
+        top2 = params.topk(2, dim=-1).values
+        gap = float((top2[..., 0] - top2[..., 1]).min())
+        out = {
+            "cmds": cmds.numpy(), "params": params.numpy() if case == "c1_full" else params[:, :, :, ::8].numpy().copy(),
+            "params_argmax": params.argmax(-1).numpy(), "cmds_argmax": cmds.argmax(-1).numpy(),
+            "loss": np.float32(loss_s.item()), "loss_fwd": np.float32(loss_f.item()),
+            "loss_use_mse_false": np.float32(loss_nomse.item()),
+            "total_grad_norm": np.float32(grads["__total_norm__"].item()),
+            "grad_names": np.array(sorted(live_names)),
+            "grad_norms": np.array([float(grads[k].double().norm()) for k in sorted(live_names)], dtype=np.float64),
+            "metrics_json": np.array(json.dumps(metrics)),
+        }
+        for k in SLICE_TENSORS:
+            out["gslice:" + k] = sl(grads[k]); out["pslice:" + k] = sl(post[k])
+        for k, v in taps.items():                    # oracle-derived stage checkpoints (oracle validated above)
+            out["tap_sum:" + k] = np.float64(v.double().sum().item())
+            out["tap_abs:" + k] = np.float64(v.double().abs().sum().item())
+            out["tap_slice:" + k] = sl(v)
+        np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)
+        meta["cases"][case] = {"config": "cad_past_10_actions_and_states_timestep_embedding", "B": B, "T": T, "seed": seed,
+                               "lengths": lengths, "min_top2_gap_params": gap, "oracle_vs_reference": dev,
+                               "taps": "oracle-derived (oracle validated end-to-end against the reference on this case)"}
+
+    # ------------------------------------------------------------------ window_size = 1 variant (forward + loss only)
+    model1, mk1, cfg1 = build_reference("cad_3_actions_and_states", weights, scratch)
+    tr1 = mk1(True)
+    batch_np = synth.make_batch(2, 8, 3)
+    model1.eval()
+    with torch.no_grad():
+        bd = tr1.prepare_batch(tbatch(batch_np))
+        cmds, params = model1(tr1._prepare_model_inputs(bd, False))
+        loss1, metrics1 = tr1.compute_loss((cmds, params), bd["actions"][:, 1:])
+    cfgw = dict(O.CANONICAL_CONFIG); cfgw["window_size"] = 1
+    ot = O.OracleTrainer(weights, cfgw)
+    with torch.no_grad():
+        ocmds, oparams, otgt = ot.forward(batch_np)
+        oloss, _ = O.compute_loss(ocmds, oparams, otgt)
+    dev = {"cmds_rel": rel(ocmds, cmds), "params_rel": rel(oparams, params), "loss_abs": abs(float(oloss) - float(loss1))}
+    print("win1", dev)
+    assert dev["cmds_rel"] < 1e-5 and dev["params_rel"] < 1e-5
+    np.savez_compressed(os.path.join(HERE, "win1.npz"), cmds=cmds.numpy(), params=params[:, :, :, ::8].numpy().copy(),
+                        params_argmax=params.argmax(-1).numpy(), loss=np.float32(loss1.item()),
+                        metrics_json=np.array(json.dumps(metrics1)))
+    meta["cases"]["win1"] = {"config": "cad_3_actions_and_states", "B": 2, "T": 8, "seed": 3, "oracle_vs_reference": dev}
+
+    # ------------------------------------------------------------------ loss-only cases on synthetic logits
+    tr = mk(True); trn = mk(False)
+    loss_cases = {}
+    M_B, M_T = 4, 40                                  # T > 30 so the [:, :30] "topk" slice matters
+    def synth_logits(seed, peak=None, tgt=None):
+        c = synth.hash_uniform(1000 + seed, M_B * M_T * 5).reshape(M_B, M_T, 5) * 3
+        p = synth.hash_uniform(2000 + seed, M_B * M_T * 6000).reshape(M_B, M_T, 6, 1000) * 3
+        return torch.tensor(c), torch.tensor(p)
+    for name, seed, mode in [("random", 11, "plain"), ("all_inside", 12, "inside"), ("empty_param", 13, "empty"),
+                             ("clamped_edge", 14, "edge")]:
+        acts = torch.tensor(synth.make_actions(M_B, M_T + 1, seed, lengths=[41, 41, 30, 12]))[:, 1:]
+        c, p = synth_logits(seed)
+        if mode == "inside":                          # peak every param head inside its window -> constant-0 branch
+            t = acts[..., 1:].long().clamp(min=0)
+            p.scatter_(-1, t.unsqueeze(-1), 50.0)
+        if mode == "empty":                           # no valid targets at all for params 4,5
+            acts[..., 5:] = -1
+        if mode == "edge":                            # targets at 998/999 exercise the clamp/unique window
+            m = acts[..., 1:] >= 0
+            acts[..., 1:][m] = torch.where(acts[..., 1:][m] > 500, torch.tensor(999.0), torch.tensor(998.0))
+        l1, m1 = tr.compute_loss((c, p), acts)
+        l0, m0 = trn.compute_loss((c, p), acts)
+        ol1, om1 = O.compute_loss(c, p, acts, True)
+        ol0, om0 = O.compute_loss(c, p, acts, False, json.load(open(os.path.join(HERE, "class_weights.json"))))
+        d = {"mse_abs": abs(float(l1) - float(ol1)), "nomse_abs": abs(float(l0) - float(ol0)),
+             "metrics_equal": m1 == om1 and m0 == om0}
+        print("loss case", name, float(l1), float(l0), d)
+        assert d["mse_abs"] < 2e-6 and d["nomse_abs"] < 2e-5 and d["metrics_equal"], d
+        loss_cases[name] = {"seed": seed, "mode": mode, "loss_use_mse": float(l1), "loss_no_mse": float(l0),
+                            "metrics_use_mse": m1, "metrics_no_mse": m0, "oracle_vs_reference": d}
+    json.dump({"B": M_B, "T": M_T, "lengths": [41, 41, 30, 12], "cases": loss_cases},
+              open(os.path.join(HERE, "loss_cases.json"), "w"), indent=1)
+    json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
+    shutil.rmtree(scratch, ignore_errors=True)
+    print("goldens written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
