@@ -1,0 +1,111 @@
+/* vcad.h — C ABI of libvcad_hip.so: the MI355X-native hot path of VideoCAD's behaviour-cloning train step.
+ *
+ * The reference (ghadinehme/VideoCAD) has NO FFI/plugin layer: its boundary is the Python protocol
+ *   ModelFactory.create_model(...)                      reference model/model_factory.py:15-36
+ *   AutoRegressiveTransformer.forward(inputs)           reference model/autoregressive_transformer.py:121-220
+ *   BaseTrainer._process_batch / compute_loss           reference trainer.py:480-496, 935-1063
+ * so this header defines the binding a maintainer adds underneath those classes (see INTEGRATION.md for the
+ * ctypes stub).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host"; the caller (PyTorch caching allocator) owns
+ *     every buffer including the workspace; the library keeps no device state of its own
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); nothing here synchronises the device
+ *   - return value 0 = ok; non-zero = error, text via vcad_last_error() (thread-local)
+ *   - dtype: VCAD_F32 = exact-fp32 parity mode (f32 MFMA), VCAD_BF16 = bf16 MFMA with fp32 accumulate,
+ *     fp32 residual stream, fp32 master weights + bf16 weight shadow
+ */
+#ifndef VCAD_H
+#define VCAD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VCAD_F32 = 0, VCAD_BF16 = 1 };
+
+typedef struct vcad_config {
+    /* AutoRegressiveTransformer.__init__ kwargs (reference model/autoregressive_transformer.py:11-35) */
+    int hidden_size, nhead, num_decoder_layers, dim_feedforward, window_size, act_dim;
+    int num_classes, num_params, num_params_values, max_ep_len;
+    /* vit_pytorch.ViT(...) constructor call at reference model/trajectory_model.py:54-65 */
+    int vit_dim, vit_depth, vit_heads, vit_dim_head, vit_mlp, image_size, patch_size;
+    int dtype;                     /* VCAD_F32 | VCAD_BF16 */
+} vcad_config;
+
+typedef struct vcad_engine vcad_engine;
+
+const char* vcad_last_error(void);
+const char* vcad_version(void);
+
+/* ---- engine lifetime (host-only bookkeeping; replaces AutoRegressiveTransformer.__init__ parameter creation) */
+int vcad_engine_create(const vcad_config* cfg, vcad_engine** out);
+void vcad_engine_destroy(vcad_engine* e);
+
+/* ---- flat parameter layout (state_dict keys of SURVEY Appendix B, live parameters only, reverse-execution order) */
+int64_t vcad_param_total(const vcad_engine* e);                   /* floats in the flat buffer (incl. alignment pads) */
+int vcad_param_count(const vcad_engine* e);                       /* number of named tensors */
+/* name -> host char buffer; shape[4] padded with 0; offset/numel in floats */
+int vcad_param_info(const vcad_engine* e, int index, char* name, size_t name_cap, int64_t* offset, int64_t* numel,
+                    int64_t shape[4], int* ndim);
+/* number of DDP buckets and the [begin,end) float range of bucket i; bucket i's gradients are final when
+ * vcad_backward_stage(i) has been enqueued (heads+decoder+stem first, ViT patch-embed last) */
+int vcad_bucket_count(const vcad_engine* e);
+int vcad_bucket_range(const vcad_engine* e, int bucket, int64_t* begin, int64_t* end);
+
+/* params/grads/m/v: fp32 [vcad_param_total]; shadow: bf16 [vcad_param_total] (VCAD_BF16 only, else NULL) */
+int vcad_bind(vcad_engine* e, float* params, float* grads, float* adam_m, float* adam_v, void* shadow_bf16);
+/* refresh the bf16 weight shadow from the fp32 master weights (after load_state_dict / external optimiser) */
+int vcad_sync_shadow(vcad_engine* e, void* stream);
+
+size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T);
+int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
+
+/* ---- AutoRegressiveTransformer.forward (reference model/autoregressive_transformer.py:121-220)
+ * frames: fp32, frame (b,t) at frames + b*frame_bstride + t*S*S  (so batch['frames'][:, :-1] needs no copy)
+ * actions_norm: fp32 [B,T,7] already normalised (reference trainer.py:800-804); cad: fp32 [B,1,S,S]
+ * cmds_out fp32 [B,T,num_classes], params_out fp32 [B,T,num_params*num_params_values] */
+int vcad_forward(vcad_engine* e, const float* frames, int64_t frame_bstride, const float* actions_norm, const float* cad,
+                 int B, int T, float* cmds_out, float* params_out, void* stream);
+
+/* ---- MultiClassesTrainer.compute_loss (reference trainer.py:935-1063, flexible_cross_entropy :853-917)
+ * targets: fp32 [B*T,7] = raw batch['actions'][:, 1:]; class_weights: fp32 [6][1000] (use_mse = 0) or NULL
+ * loss_out: fp32 [8] = total, cmd, param0..5;  metrics_out: int32 [32] (slots in loss.h)
+ * also leaves d(loss)/d(logits) in the workspace for vcad_backward(NULL, NULL) */
+int vcad_loss(vcad_engine* e, const float* cmds, const float* params, const float* targets, int B, int T, int use_mse,
+              const float* class_weights, float* loss_out, int32_t* metrics_out, void* stream);
+
+/* ---- autograd backward of forward (+ what `loss.backward()` does at reference trainer.py:492)
+ * dcmds/dparams: fp32 gradients of the two outputs, or both NULL to use the ones vcad_loss left in the workspace.
+ * Gradients are WRITTEN (not accumulated) into the bound flat grad buffer. */
+int vcad_backward(vcad_engine* e, const float* dcmds, const float* dparams, void* stream);
+/* the same, one DDP bucket at a time (stage 0 .. vcad_bucket_count-1, in order) so the caller can overlap RCCL */
+int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
+
+/* ---- clip_grad_norm_(max_norm) + Adam.step (reference trainer.py:493-494); step = 1-based Adam step count;
+ * grad_scale multiplies gradients first (1/world_size after an all-reduce SUM); norm_out: fp32 [2] = |g|, clip coef */
+int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, float eps, float max_norm, int step,
+                        float grad_scale, float* norm_out, void* stream);
+
+/* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
+int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
+                 int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
+                 const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, void* stream);
+int vcad_op_layernorm_fwd(int tx, int ty, int C, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                          float* y32, void* yt, float* stats, int64_t rows, float eps, void* stream);
+int vcad_op_layernorm_bwd(int td, int ty, int C, const void* dy, const float* x, int64_t ldx, const float* stats,
+                          const float* gamma, const float* add_in, float* dx32, void* dxt, float* dgamma, float* dbeta,
+                          int64_t rows, float* scratch, size_t scratch_bytes, void* stream);
+int vcad_op_attention_fwd(int t, int D, const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,
+                          int64_t ldv, int64_t ldo, float* lse, int B, int H, int Tq, int Tk, int window, int causal,
+                          float scale, void* stream);
+int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void* v, const void* dout, int64_t ldq,
+                          int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
+                          void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
+                          int causal, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

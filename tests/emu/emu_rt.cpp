@@ -1,0 +1,183 @@
+// emu_rt.cpp — TEST INFRASTRUCTURE ONLY (never linked into the product library).
+// A small fiber-per-lane CPU emulator of the HIP execution model used by vc_rt.h under -DVC_EMU:
+// blocks run one after another; the threads of a block are ucontext fibers scheduled round-robin and
+// switch only at __syncthreads / wave shuffles / MFMA, so wave64 collectives and LDS semantics are
+// reproduced deterministically.  MFMA follows the gfx950 operand maps quoted in vc_rt.h.
+#include <ucontext.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <stdint.h>
+
+#define VC_EMU 1
+#include "vc_rt.h"
+
+namespace vcemu {
+
+struct Fiber {
+    ucontext_t uc;
+    Ctx ctx;
+    bool done = false;
+    char* stack = nullptr;
+};
+
+struct WaveState {
+    int arrived = 0, gen = 0, alive = 0;
+    float fslot[64];
+    int islot[64];
+    short a[64][8], b[64][8];
+    float fa[64], fb[64];
+};
+
+struct BlockState {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    ucontext_t sched;
+    int cur = -1;
+    int alive = 0;
+    int bar_arrived = 0, bar_gen = 0;
+    void (*tramp)(void*) = nullptr;
+    void* args = nullptr;
+    std::vector<unsigned char> dyn;
+};
+
+static thread_local BlockState* g_bs = nullptr;
+static const size_t kStack = 256 * 1024;
+
+Ctx* cur() { return &g_bs->fibers[g_bs->cur].ctx; }
+void* dyn_shared() { return g_bs->dyn.data(); }
+
+static void yield_() {
+    BlockState* bs = g_bs;
+    swapcontext(&bs->fibers[bs->cur].uc, &bs->sched);
+}
+
+static void fiber_main() {
+    BlockState* bs = g_bs;
+    bs->tramp(bs->args);
+    Fiber& f = bs->fibers[bs->cur];
+    f.done = true;
+    bs->alive--;
+    bs->waves[bs->cur / 64].alive--;
+    swapcontext(&f.uc, &bs->sched);
+}
+
+void sync_block() {
+    BlockState* bs = g_bs;
+    int my = bs->bar_gen;
+    bs->bar_arrived++;
+    while (bs->bar_gen == my) {
+        if (bs->bar_arrived >= bs->alive) { bs->bar_arrived = 0; bs->bar_gen++; break; }
+        yield_();
+    }
+}
+
+static void wave_sync() {
+    BlockState* bs = g_bs;
+    WaveState& w = bs->waves[bs->cur / 64];
+    int my = w.gen;
+    w.arrived++;
+    while (w.gen == my) {
+        if (w.arrived >= w.alive) { w.arrived = 0; w.gen++; break; }
+        yield_();
+    }
+}
+
+void sync_wave() { wave_sync(); }
+
+float shfl_f(float v, int src) {
+    BlockState* bs = g_bs;
+    WaveState& w = bs->waves[bs->cur / 64];
+    w.fslot[bs->cur & 63] = v;
+    wave_sync();
+    float r = w.fslot[src & 63];
+    wave_sync();
+    return r;
+}
+int shfl_i(int v, int src) {
+    BlockState* bs = g_bs;
+    WaveState& w = bs->waves[bs->cur / 64];
+    w.islot[bs->cur & 63] = v;
+    wave_sync();
+    int r = w.islot[src & 63];
+    wave_sync();
+    return r;
+}
+
+void mfma_32x32x16_bf16(const short* a8, const short* b8, float* c16) {
+    BlockState* bs = g_bs;
+    WaveState& w = bs->waves[bs->cur / 64];
+    int l = bs->cur & 63;
+    memcpy(w.a[l], a8, 16);
+    memcpy(w.b[l], b8, 16);
+    wave_sync();
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c16[r];
+        for (int k = 0; k < 16; ++k) {
+            vc_bf16 av{(uint16_t)w.a[row + 32 * (k / 8)][k % 8]}, bv{(uint16_t)w.b[col + 32 * (k / 8)][k % 8]};
+            acc += vc_bf16_to_f32(av) * vc_bf16_to_f32(bv);
+        }
+        c16[r] = acc;
+    }
+    wave_sync();
+}
+
+void mfma_32x32x2_f32(float a, float b, float* c16) {
+    BlockState* bs = g_bs;
+    WaveState& w = bs->waves[bs->cur / 64];
+    int l = bs->cur & 63;
+    w.fa[l] = a; w.fb[l] = b;
+    wave_sync();
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c16[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(w.fa[row + 32 * k], w.fb[col + 32 * k], acc);
+        c16[r] = acc;
+    }
+    wave_sync();
+}
+
+void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem) {
+    int nthreads = block.x * block.y * block.z;
+    if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size %d not a multiple of 64\n", nthreads); abort(); }
+    BlockState bs;
+    bs.tramp = trampoline; bs.args = args;
+    bs.fibers.resize(nthreads);
+    bs.waves.resize(nthreads / 64);
+    bs.dyn.resize(shmem + 64);
+    for (auto& f : bs.fibers) f.stack = (char*)malloc(kStack);
+    g_bs = &bs;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        bs.alive = nthreads; bs.bar_arrived = 0; bs.bar_gen = 0;
+        for (auto& w : bs.waves) { w.arrived = 0; w.gen = 0; w.alive = 64; }
+        for (int t = 0; t < nthreads; ++t) {
+            Fiber& f = bs.fibers[t];
+            f.done = false;
+            f.ctx.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            f.ctx.bid = dim3(bx, by, bz);
+            f.ctx.bdim = block; f.ctx.gdim = grid;
+            getcontext(&f.uc);
+            f.uc.uc_stack.ss_sp = f.stack; f.uc.uc_stack.ss_size = kStack; f.uc.uc_link = nullptr;
+            makecontext(&f.uc, (void (*)())fiber_main, 0);
+        }
+        int idle_rounds = 0;
+        while (bs.alive > 0) {
+            int before = bs.alive;
+            for (int t = 0; t < nthreads; ++t) {
+                if (bs.fibers[t].done) continue;
+                bs.cur = t;
+                swapcontext(&bs.sched, &bs.fibers[t].uc);
+            }
+            (void)before;
+            if (++idle_rounds > 100000000) { fprintf(stderr, "emu: deadlock?\n"); abort(); }
+        }
+    }
+    for (auto& f : bs.fibers) free(f.stack);
+    g_bs = nullptr;
+}
+
+}  // namespace vcemu

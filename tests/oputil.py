@@ -1,0 +1,163 @@
+"""Shared op-level parity checks: the same functions drive the CPU emulator build (tests/emu/libvcad_emu.so,
+host pointers) and the real HIP library (device pointers), comparing each kernel with plain PyTorch fp32 math."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import torch
+
+from videocad_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_PATH = os.path.join(ROOT, "tests", "emu", "libvcad_emu.so")
+TD = {torch.float32: L.VCAD_F32, torch.bfloat16: L.VCAD_BF16}
+
+
+def load_emu():
+    if not os.path.exists(EMU_PATH) or os.path.getmtime(EMU_PATH) < max(
+            os.path.getmtime(os.path.join(ROOT, "videocad_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "videocad_amd", "csrc"))
+            if f.endswith((".h", ".hip"))):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "videocad_amd", "csrc"), "emu"])
+    return L.declare(C.CDLL(EMU_PATH))
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream_of(device):
+    if torch.device(device).type == "cuda":
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+def rnd(shape, device, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(device)
+
+
+def relerr(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, tra=0, trb=0, bias=False, act=0, residual=False, seed=0,
+               pad=0, tol=None, splitk=True):
+    """C = act(opA @ opB^T + bias) + residual ; operands stored with `pad` extra leading-dimension elements."""
+    sa = ct if sa is None else sa
+    to = ct if to is None else to
+    sb = ct
+    A_log = rnd((M, K), "cpu", seed=seed + 1)
+    B_log = rnd((N, K), "cpu", seed=seed + 2)
+    A_q = A_log.to(sa).float() if ct == torch.float32 else A_log.to(torch.bfloat16).float()
+    B_q = B_log.to(sb).float()
+
+    def store(x_log, tr, dt):
+        x = x_log.t().contiguous() if tr else x_log.contiguous()
+        buf = torch.zeros(x.shape[0], x.shape[1] + pad, dtype=dt)
+        buf[:, : x.shape[1]] = x.to(dt)
+        return buf.to(device), x.shape[1] + pad
+
+    A, lda = store(A_log, tra, sa)
+    Bm, ldb = store(B_log, trb, sb)
+    bias_t = rnd((N,), device, seed=seed + 3) if bias else None
+    res_t = rnd((M, N), device, seed=seed + 4) if residual else None
+    Cbuf = torch.full((M, N + pad), 7.0, dtype=to, device=device)
+    scratch = torch.empty(8 << 20, dtype=torch.float32, device=device) if splitk else None
+    rc = lib.vcad_op_gemm(TD[ct], TD[sa], TD[sb], TD[to], tra, trb, ptr(A), ptr(Bm), ptr(Cbuf), M, N, K, lda, ldb, N + pad,
+                          ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, stream_of(device))
+    L.check(lib, rc, "gemm")
+    ref = A_q.double() @ B_q.double().t()
+    if bias:
+        ref = ref + bias_t.double().cpu()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    elif act == 3:
+        ref = torch.tanh(ref)
+    if residual:
+        ref = ref + res_t.double().cpu()
+    out = Cbuf[:, :N].float().cpu()
+    err = relerr(out, ref)
+    if tol is None:
+        tol = 2e-6 if (ct == torch.float32) else (6e-3 if to == torch.bfloat16 else 2e-5)
+        if ct == torch.bfloat16 and to == torch.float32:
+            tol = 1e-5
+    assert err < tol, f"gemm M{M} N{N} K{K} ct={ct} sa={sa} to={to} tra={tra} trb={trb}: rel err {err:.3e} > {tol}"
+    if pad:
+        assert bool((Cbuf[:, N:].float() == 7.0).all()), "gemm wrote outside the N columns"
+    return err
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+def check_layernorm(lib, device, rows, C_, dt, seed=0):
+    x = rnd((rows, C_), device, seed=seed, scale=2.0) + 0.5
+    g = rnd((C_,), device, seed=seed + 1, scale=0.2) + 1.0
+    b = rnd((C_,), device, seed=seed + 2, scale=0.1)
+    y32 = torch.empty(rows, C_, device=device)
+    yt = torch.empty(rows, C_, dtype=dt, device=device)
+    stats = torch.empty(rows, 2, device=device)
+    rc = lib.vcad_op_layernorm_fwd(L.VCAD_F32, TD[dt], C_, ptr(x), C_, ptr(g), ptr(b), ptr(y32), ptr(yt), ptr(stats), rows, 1e-5, stream_of(device))
+    L.check(lib, rc, "ln_fwd")
+    xr = x.double().cpu().requires_grad_(True); gr = g.double().cpu().requires_grad_(True); br = b.double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (C_,), gr, br, 1e-5)
+    assert relerr(y32, ref) < 2e-6, relerr(y32, ref)
+    assert relerr(yt, ref) < (2e-6 if dt == torch.float32 else 4e-3)
+    dy = rnd((rows, C_), device, seed=seed + 3)
+    dyt = dy.to(dt)
+    add = rnd((rows, C_), device, seed=seed + 4)
+    dx = torch.empty(rows, C_, device=device); dg = torch.empty(C_, device=device); db = torch.empty(C_, device=device)
+    scratch = torch.empty(4 << 20, dtype=torch.float32, device=device)
+    rc = lib.vcad_op_layernorm_bwd(TD[dt], TD[dt], C_, ptr(dyt), ptr(x), C_, ptr(stats), ptr(g), ptr(add), ptr(dx), None, ptr(dg), ptr(db),
+                                   rows, ptr(scratch), scratch.numel() * 4, stream_of(device))
+    L.check(lib, rc, "ln_bwd")
+    ref.backward(dyt.double().cpu())
+    tol = 5e-6 if dt == torch.float32 else 1e-5
+    assert relerr(dx, xr.grad + add.double().cpu()) < tol, relerr(dx, xr.grad + add.double().cpu())
+    assert relerr(dg, gr.grad) < tol and relerr(db, br.grad) < tol, (relerr(dg, gr.grad), relerr(db, br.grad))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, window, causal, scale):
+    """q,k,v: [B,T,H,D] double. mask rule of csrc/attn.h."""
+    Tq, Tk = q.shape[1], k.shape[1]
+    i = torch.arange(Tq)[:, None]; j = torch.arange(Tk)[None, :]
+    ok = (j >= i - window + 1) & ((j <= i) if causal else torch.ones_like(j, dtype=torch.bool))
+    s = torch.einsum("bihd,bjhd->bhij", q, k) * scale
+    s = s.masked_fill(~ok, float("-inf"))
+    p = s.softmax(-1)
+    return torch.einsum("bhij,bjhd->bihd", p, v), torch.logsumexp(s, -1)
+
+
+def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=True):
+    scale = 1.0 / math.sqrt(D)
+    qkv = rnd((B, T, 3, H, D), device, dt, seed=seed)                      # packed projection [B*T, 3*H*D]
+    ld = 3 * H * D
+    es = qkv.element_size()
+    base = qkv.data_ptr()
+    o = torch.empty(B, T, H, D, dtype=dt, device=device)
+    lse = torch.empty(B, H, T, device=device)
+    st = stream_of(device)
+    rc = lib.vcad_op_attention_fwd(TD[dt], D, C.c_void_p(base), C.c_void_p(base + H * D * es), C.c_void_p(base + 2 * H * D * es), ptr(o),
+                                   ld, ld, ld, H * D, ptr(lse), B, H, T, T, window, causal, scale, st)
+    L.check(lib, rc, "attn_fwd")
+    qr, kr, vr = (qkv[:, :, i].double().cpu().requires_grad_(True) for i in range(3))
+    ref, lse_ref = attn_ref(qr, kr, vr, window, causal, scale)
+    tol = 3e-6 if dt == torch.float32 else 6e-3
+    assert relerr(o, ref) < tol, ("attn fwd", relerr(o, ref))
+    assert relerr(lse, lse_ref) < 1e-5
+    do = rnd((B, T, H, D), device, dt, seed=seed + 1)
+    dqkv = torch.zeros(B, T, 3, H, D, dtype=dt, device=device)
+    delta = torch.empty(B, H, T, device=device)
+    db_ = dqkv.data_ptr()
+    rc = lib.vcad_op_attention_bwd(TD[dt], D, C.c_void_p(base), C.c_void_p(base + H * D * es), C.c_void_p(base + 2 * H * D * es), ptr(do),
+                                   ld, ld, ld, H * D, ptr(lse), ptr(delta), C.c_void_p(db_), C.c_void_p(db_ + H * D * es),
+                                   C.c_void_p(db_ + 2 * H * D * es), ld, ld, ld, B, H, T, T, window, causal, scale, st)
+    L.check(lib, rc, "attn_bwd")
+    ref.backward(do.double().cpu())
+    tolb = 1e-5 if dt == torch.float32 else 1.5e-2
+    for i, g in enumerate((qr.grad, kr.grad, vr.grad)):
+        assert relerr(dqkv[:, :, i], g) < tolb, ("attn bwd", i, relerr(dqkv[:, :, i], g))

@@ -1,0 +1,59 @@
+"""CPU checks of the HIP kernels' indexing logic: the SAME kernel sources compiled with -DVC_EMU run under the
+fiber emulator (tests/emu/emu_rt.cpp, test infrastructure only) and are compared with PyTorch fp32 math.
+Sizes are tiny — the emulator executes every lane as a fiber."""
+import pytest
+import torch
+
+import oputil as U
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return U.load_emu()
+
+
+@pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_f32_layouts(emu, tra, trb):
+    U.check_gemm(emu, "cpu", 70, 40, 50, F32, tra=tra, trb=trb, pad=3, bias=True, residual=True, splitk=False)
+
+
+def test_gemm_f32_multi_tile_and_act(emu):
+    U.check_gemm(emu, "cpu", 130, 136, 37, F32, act=1, bias=True, pad=4)
+    U.check_gemm(emu, "cpu", 16, 5, 64, F32, act=3, bias=True, pad=0)
+
+
+def test_gemm_f32_splitk(emu):
+    U.check_gemm(emu, "cpu", 24, 20, 640, F32, tra=1, trb=1, bias=True, residual=True)
+
+
+@pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("sa,to", [(BF16, BF16), (F32, F32)])
+def test_gemm_bf16(emu, tra, trb, sa, to):
+    if tra == 1 and to == BF16:
+        pytest.skip("wgrad always writes fp32")
+    U.check_gemm(emu, "cpu", 72, 48, 136, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=8, bias=True, act=2, splitk=False)
+
+
+def test_gemm_bf16_unaligned_tail(emu):
+    U.check_gemm(emu, "cpu", 33, 7, 100, BF16, sa=F32, to=F32, tra=1, trb=1, pad=1, splitk=False)
+
+
+@pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16)])
+def test_layernorm(emu, C_, dt):
+    U.check_layernorm(emu, "cpu", 11, C_, dt)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_vit_shape(emu, dt):
+    U.check_attention(emu, "cpu", 2, 2, 50, 64, window=50, causal=0, dt=dt)
+
+
+def test_attention_causal_d256(emu):
+    U.check_attention(emu, "cpu", 1, 2, 70, 256, window=70, causal=1, dt=F32)     # > 64 keys: NPASS = 3 path
+
+
+def test_attention_band(emu):
+    U.check_attention(emu, "cpu", 2, 1, 23, 256, window=10, causal=1, dt=F32)
+    U.check_attention(emu, "cpu", 1, 1, 9, 256, window=1, causal=1, dt=F32)

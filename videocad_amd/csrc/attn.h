@@ -1,0 +1,209 @@
+// attn.h — windowed softmax attention, forward and backward, one wave64 per (batch, head, row).
+//
+// Covers every attention on the hot path with one mask rule: key j is visible to query i iff
+//     lo(i) <= j <= hi(i),   lo = max(0, i - window + 1),   hi = causal ? i : Tk - 1
+//   * ViT self-attention (50 tokens, 16 x 64):   window >= Tk, causal = 0
+//   * decoder self-attention (4 x 256, causal):  window >= T,  causal = 1   (generate_square_subsequent_mask,
+//                                                 reference model/autoregressive_transformer.py:180)
+//   * decoder cross-attention band:              window = 10,  causal = 1   (reference :182-188) — only the <= 10
+//                                                 visible keys are touched; the reference materialises T x T.
+// Element (b, t, h, d) of q/k/v/o lives at base + (b*T + t)*ld + h*D + d, so the packed projections
+// ([rows, 3*inner]) are consumed in place with pointer offsets — no head-split copies.
+//
+// Scores: lane = key (each lane walks one K row, q broadcast from a wave-private LDS row);
+// softmax: wave-shuffle max / sum;  PV: lane = DPL consecutive output dims, p broadcast lane->wave.
+// Backward is the usual two-kernel split (no atomics, deterministic):
+//   attn_bwd_q : per query  -> D_i = sum_j P_ij dP_ij, dq_i
+//   attn_bwd_kv: per key    -> dk_j, dv_j  (recomputes P from the saved log-sum-exp)
+// (The host clamps `window` to max(Tq, Tk) so i + window never overflows.)
+#pragma once
+#include "vc_rt.h"
+
+struct AttnParams {
+    const void* q; const void* k; const void* v; void* o;        // type T
+    long ldq, ldk, ldv, ldo;
+    float* lse;                                                  // [B][H][Tq]
+    int B, H, Tq, Tk, window, causal;
+    float scale;
+    // backward
+    const void* dout; long lddo;                                 // type T
+    void* dq; void* dk; void* dv; long lddq, lddk, lddv;         // type T
+    float* delta;                                                // [B][H][Tq]  D_i
+};
+
+template <typename T, int D>
+VC_DEV float attn_dot_row(const T* row, const float* bc) {      // sum_d row[d] * bc[d]; bc: LDS, same address for all lanes
+    float s = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < D; d += 4)
+        s += vc_ld(row + d) * bc[d] + vc_ld(row + d + 1) * bc[d + 1] + vc_ld(row + d + 2) * bc[d + 2] + vc_ld(row + d + 3) * bc[d + 3];
+    return s;
+}
+
+// NPASS = ceil(max visible keys / 64)
+template <typename T, int DPL, int NPASS>
+VC_KERNEL __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    constexpr int D = 64 * DPL;
+    VC_SHARED float qs[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const long total = (long)p.B * p.H * p.Tq;
+    if (wid >= total) return;
+    const int i = (int)(wid % p.Tq); const int h = (int)((wid / p.Tq) % p.H); const int b = (int)(wid / ((long)p.Tq * p.H));
+    const int lo = (i - p.window + 1 > 0) ? (i - p.window + 1) : 0;
+    const int hi = p.causal ? (i < p.Tk - 1 ? i : p.Tk - 1) : (p.Tk - 1);
+    const int nk = hi - lo + 1;
+    const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) qs[wave][lane * DPL + j] = vc_ld(qrow + lane * DPL + j);
+    vc_wave_barrier();   // wave-private LDS row: in-order per wave, no workgroup barrier needed
+    float s[NPASS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int jj = ps * 64 + lane;
+        s[ps] = -INFINITY;
+        if (jj < nk) {
+            const T* krow = (const T*)p.k + ((long)b * p.Tk + lo + jj) * p.ldk + h * D;
+            s[ps] = attn_dot_row<T, D>(krow, qs[wave]) * p.scale;
+        }
+        m = fmaxf(m, s[ps]);
+    }
+    m = vc_wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) { s[ps] = (ps * 64 + lane < nk) ? expf(s[ps] - m) : 0.f; l += s[ps]; }
+    l = vc_wave_sum(l);
+    float acc[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        int cnt = nk - ps * 64; cnt = cnt > 64 ? 64 : cnt;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float pj = vc_shfl(s[ps], jj);
+            const T* vrow = (const T*)p.v + ((long)b * p.Tk + lo + ps * 64 + jj) * p.ldv + h * D + lane * DPL;
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) acc[j] += pj * vc_ld(vrow + j);
+        }
+    }
+    const float inv = 1.0f / l;
+    T* orow = (T*)p.o + ((long)b * p.Tq + i) * p.ldo + h * D + lane * DPL;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) vc_st(orow + j, acc[j] * inv);
+    if (p.lse && lane == 0) p.lse[wid] = m + logf(l);
+}
+
+template <typename T, int DPL, int NPASS>
+VC_KERNEL __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
+    constexpr int D = 64 * DPL;
+    VC_SHARED float qs[4][D];
+    VC_SHARED float dos[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const long total = (long)p.B * p.H * p.Tq;
+    if (wid >= total) return;
+    const int i = (int)(wid % p.Tq); const int h = (int)((wid / p.Tq) % p.H); const int b = (int)(wid / ((long)p.Tq * p.H));
+    const int lo = (i - p.window + 1 > 0) ? (i - p.window + 1) : 0;
+    const int hi = p.causal ? (i < p.Tk - 1 ? i : p.Tk - 1) : (p.Tk - 1);
+    const int nk = hi - lo + 1;
+    const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D;
+    const T* dorow = (const T*)p.dout + ((long)b * p.Tq + i) * p.lddo + h * D;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        qs[wave][lane * DPL + j] = vc_ld(qrow + lane * DPL + j);
+        dos[wave][lane * DPL + j] = vc_ld(dorow + lane * DPL + j);
+    }
+    vc_wave_barrier();
+    const float lse = p.lse[wid];
+    float pr[NPASS], dp[NPASS];
+    float dsum = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int jj = ps * 64 + lane;
+        pr[ps] = 0.f; dp[ps] = 0.f;
+        if (jj < nk) {
+            const T* krow = (const T*)p.k + ((long)b * p.Tk + lo + jj) * p.ldk + h * D;
+            const T* vrow = (const T*)p.v + ((long)b * p.Tk + lo + jj) * p.ldv + h * D;
+            pr[ps] = expf(attn_dot_row<T, D>(krow, qs[wave]) * p.scale - lse);
+            dp[ps] = attn_dot_row<T, D>(vrow, dos[wave]);
+        }
+        dsum += pr[ps] * dp[ps];
+    }
+    dsum = vc_wave_sum(dsum);
+    float acc[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const float ds_mine = pr[ps] * (dp[ps] - dsum);
+        int cnt = nk - ps * 64; cnt = cnt > 64 ? 64 : cnt;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float ds = vc_shfl(ds_mine, jj);
+            const T* krow = (const T*)p.k + ((long)b * p.Tk + lo + ps * 64 + jj) * p.ldk + h * D + lane * DPL;
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) acc[j] += ds * vc_ld(krow + j);
+        }
+    }
+    T* dqrow = (T*)p.dq + ((long)b * p.Tq + i) * p.lddq + h * D + lane * DPL;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) vc_st(dqrow + j, acc[j] * p.scale);
+    if (lane == 0) p.delta[wid] = dsum;
+}
+
+// NPASS = ceil(max queries that can see one key / 64)
+template <typename T, int DPL, int NPASS>
+VC_KERNEL __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
+    constexpr int D = 64 * DPL;
+    VC_SHARED float ks[4][D];
+    VC_SHARED float vs[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    const long total = (long)p.B * p.H * p.Tk;
+    if (wid >= total) return;
+    const int jk = (int)(wid % p.Tk); const int h = (int)((wid / p.Tk) % p.H); const int b = (int)(wid / ((long)p.Tk * p.H));
+    const int i0 = p.causal ? jk : 0;
+    int i1 = jk + p.window - 1; if (i1 > p.Tq - 1) i1 = p.Tq - 1;
+    const int nq = i1 - i0 + 1;                                  // may be <= 0 (key seen by nobody)
+    const T* krow = (const T*)p.k + ((long)b * p.Tk + jk) * p.ldk + h * D;
+    const T* vrow = (const T*)p.v + ((long)b * p.Tk + jk) * p.ldv + h * D;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        ks[wave][lane * DPL + j] = vc_ld(krow + lane * DPL + j);
+        vs[wave][lane * DPL + j] = vc_ld(vrow + lane * DPL + j);
+    }
+    vc_wave_barrier();
+    float pr[NPASS], ds[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int ii = ps * 64 + lane;
+        pr[ps] = 0.f; ds[ps] = 0.f;
+        if (ii < nq) {
+            const int i = i0 + ii;
+            const long sidx = ((long)b * p.H + h) * p.Tq + i;
+            const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D;
+            const T* dorow = (const T*)p.dout + ((long)b * p.Tq + i) * p.lddo + h * D;
+            pr[ps] = expf(attn_dot_row<T, D>(qrow, ks[wave]) * p.scale - p.lse[sidx]);
+            ds[ps] = pr[ps] * (attn_dot_row<T, D>(dorow, vs[wave]) - p.delta[sidx]);
+        }
+    }
+    float dk[DPL], dv[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) { dk[j] = 0.f; dv[j] = 0.f; }
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        int cnt = nq - ps * 64; cnt = cnt > 64 ? 64 : cnt;
+        for (int ii = 0; ii < cnt; ++ii) {
+            const float pi = vc_shfl(pr[ps], ii), dsi = vc_shfl(ds[ps], ii);
+            const int i = i0 + ps * 64 + ii;
+            const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D + lane * DPL;
+            const T* dorow = (const T*)p.dout + ((long)b * p.Tq + i) * p.lddo + h * D + lane * DPL;
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) { dv[j] += pi * vc_ld(dorow + j); dk[j] += dsi * vc_ld(qrow + j); }
+        }
+    }
+    T* dkrow = (T*)p.dk + ((long)b * p.Tk + jk) * p.lddk + h * D + lane * DPL;
+    T* dvrow = (T*)p.dv + ((long)b * p.Tk + jk) * p.lddv + h * D + lane * DPL;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) { vc_st(dkrow + j, dk[j] * p.scale); vc_st(dvrow + j, dv[j]); }
+}

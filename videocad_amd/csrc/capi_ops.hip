@@ -1,0 +1,62 @@
+// capi_ops.hip — single-op C entry points (include/vcad.h "vcad_op_*"): thin wrappers over the same launchers
+// the engine uses, so the parity tests exercise exactly the shipped kernels.
+#include "ops.h"
+#include "../../include/vcad.h"
+#include <string.h>
+
+extern "C" {
+
+int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
+                 int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
+                 const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, void* stream) {
+    GemmCall c; memset(&c, 0, sizeof(c));
+    c.ct = ct; c.sa = sa; c.sb = sb; c.to = to; c.tra = tra; c.trb = trb;
+    c.p.A = A; c.p.B = B; c.p.C = C; c.p.M = M; c.p.N = N; c.p.K = K; c.p.lda = lda; c.p.ldb = ldb; c.p.ldc = ldc;
+    c.p.bias = bias; c.p.act = act; c.p.residual = residual; c.p.ldr = ldr; c.p.alpha = alpha; c.p.rowadd_div = 1;
+    int rc = vc_gemm(c, scratch, scratch_bytes, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_gemm: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
+
+int vcad_op_layernorm_fwd(int tx, int ty, int C, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                          float* y32, void* yt, float* stats, int64_t rows, float eps, void* stream) {
+    LnFwdParams p; memset(&p, 0, sizeof(p));
+    p.x = x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.y32 = y32; p.ldy32 = C; p.yt = yt; p.ldyt = C; p.stats = stats;
+    p.rows = rows; p.eps = eps;
+    return vc_ln_fwd(tx, ty, C, 0, p, (vc_stream_t)stream);
+}
+
+int vcad_op_layernorm_bwd(int td, int ty, int C, const void* dy, const float* x, int64_t ldx, const float* stats,
+                          const float* gamma, const float* add_in, float* dx32, void* dxt, float* dgamma, float* dbeta,
+                          int64_t rows, float* scratch, size_t scratch_bytes, void* stream) {
+    const size_t part = (size_t)vc_ln_bwd_blocks(rows) * 2 * C * 4;
+    const size_t cs = (size_t)vc_colsum_chunks(vc_ln_bwd_blocks(rows)) * C * 4;
+    if (part + cs + 512 > scratch_bytes) { vc_set_error("layernorm_bwd: scratch %zu < %zu", scratch_bytes, part + cs + 512); return VC_ERR_WORKSPACE; }
+    LnBwdParams p; memset(&p, 0, sizeof(p));
+    p.dy = dy; p.lddy = C; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.add_in = add_in; p.ldadd = C;
+    p.dx32 = dx32; p.lddx32 = C; p.dxt = dxt; p.lddxt = C; p.rows = rows;
+    float* colws = (float*)((char*)scratch + ((part + 255) & ~(size_t)255));
+    return vc_ln_bwd(td, VC_F32, ty, C, 0, p, scratch, dgamma, dbeta, colws, (vc_stream_t)stream);
+}
+
+int vcad_op_attention_fwd(int t, int D, const void* q, const void* k, const void* v, void* o, int64_t ldq, int64_t ldk,
+                          int64_t ldv, int64_t ldo, float* lse, int B, int H, int Tq, int Tk, int window, int causal,
+                          float scale, void* stream) {
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.o = o; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lse = lse;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.window = window; p.causal = causal; p.scale = scale;
+    return vc_attn_fwd(t, D, p, (vc_stream_t)stream);
+}
+
+int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void* v, const void* dout, int64_t ldq,
+                          int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
+                          void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
+                          int causal, float scale, void* stream) {
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.lse = (float*)lse; p.delta = delta;
+    p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.window = window; p.causal = causal; p.scale = scale;
+    return vc_attn_bwd(t, D, p, (vc_stream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,657 @@
+// engine.hip — host-side orchestration of the train step: forward, fused loss, backward (staged by DDP
+// bucket), clip + Adam.  Pure launch logic: every arithmetic op is one of the HIP kernels in this directory.
+//
+// Restates (reference file:line)
+//   AutoRegressiveTransformer.forward .......... model/autoregressive_transformer.py:121-220
+//   ViT encoder (vit-pytorch, ctor call) ....... model/trajectory_model.py:54-67, 90-100
+//   nn.TransformerDecoder (post-norm, ReLU) .... model/autoregressive_transformer.py:54-62, 191-197
+//   compute_loss / backward / clip / Adam ...... trainer.py:935-1063, 492-494
+//
+// HBM layout
+//   * ONE flat fp32 parameter buffer (+ grads, Adam m, v of the same shape; + bf16 shadow in bf16 mode), tensors in
+//     reverse-execution order so that each DDP bucket is a contiguous range that becomes final at the end of one
+//     backward stage (bucket 0 = heads+decoder+stem is ~75 % of the bytes and is ready before the ViT backward starts).
+//   * activations live in a caller-owned workspace, bump-allocated per (B, T); the fp32 residual stream and every
+//     GEMM input needed by wgrad are kept (no recompute: 288 GB HBM), softmax probabilities are NOT kept (LSE only).
+#include "ops.h"
+#include "../../include/vcad.h"
+#include <map>
+#include <string>
+#include <vector>
+#include <string.h>
+#include <stdio.h>
+
+namespace {
+
+struct PInfo { std::string name; long off, numel; long shape[4]; int ndim; };
+struct Mat { const void* p; int dt; long ld; };
+struct Epi {
+    const float* bias = nullptr; int act = 0;
+    const float* residual = nullptr; long ldr = 0;
+    const float* rowadd = nullptr; int rdiv = 1, rmod = 0; long ldrow = 0;
+    void* aux = nullptr; long ldaux = 0;
+    const void* dact = nullptr; long lddact = 0; int dkind = 0;
+};
+
+struct VitW {       // float offsets into the flat buffer
+    long pos, cls, ln1w, ln1b, pew, peb, ln2w, ln2b, normw, normb;
+    struct L { long anw, anb, qkv, ow, ob, fnw, fnb, w1, b1, w4, b4; };
+    std::vector<L> l;
+};
+struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w2, b2, n1w, n1b, n2w, n2b, n3w, n3b; };
+
+struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo; };
+struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e; };
+struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* st1; float* x1; void* q_c; void* kv_c; float* lse_c; void* ao_c;
+                      float* s2; float* st2; float* x2; void* f1; float* s3; float* st3; float* x3; };
+
+}  // namespace
+
+struct vcad_engine {
+    vcad_config c;
+    int dt;                       // activation / compute dtype
+    size_t esz;
+    std::vector<PInfo> plist; std::map<std::string, int> pindex; long ptotal = 0;
+    std::vector<std::pair<long, long>> buckets;
+    VitW wv[2]; std::vector<DecW> wd;      // [0] = state_embedding_model, [1] = cad_embedding_model
+    long o_es_w, o_es_b, o_ei_w, o_ei_b, o_ip_w, o_ip_b, o_ea_w, o_ea_b, o_ts, o_h5_w, o_h5_b, o_h6_w, o_h6_b;
+    float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr; vc_bf16* S = nullptr;
+    char* ws = nullptr; size_t ws_bytes = 0;
+    // ---- per-(B,T) plan
+    int B = 0, T = 0; bool fwd_valid = false;
+    const float* in_frames = nullptr; long in_fbstride = 0; const float* in_actions = nullptr; const float* in_cad = nullptr;
+    VitActs va[2]; std::vector<DecLayerActs> da;
+    float *ui, *cadterm, *mem, *act; void* cadE;
+    float *xfinal;                // = da.back().x3
+    // backward temporaries
+    float *t_dx, *t_dpe, *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
+    void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_df1, *t_dq, *t_dkv, *t_dao_d, *t_dqkv_d;
+    float *t_delta;
+    // scratch
+    float *scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
+    float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
+    const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
+};
+
+namespace {
+
+const int NB_BUCKETS = 4;
+
+long add_param(vcad_engine* e, const std::string& name, std::initializer_list<long> shape) {
+    PInfo p; p.name = name; p.ndim = (int)shape.size(); p.numel = 1;
+    int i = 0; for (long s : shape) { p.shape[i++] = s; p.numel *= s; }
+    for (; i < 4; ++i) p.shape[i] = 0;
+    p.off = e->ptotal;
+    e->ptotal += (p.numel + 63) / 64 * 64;            // 256-byte alignment (fp32), 128-byte for the bf16 shadow
+    e->pindex[name] = (int)e->plist.size();
+    e->plist.push_back(p);
+    return p.off;
+}
+
+void add_vit_layer(vcad_engine* e, int v, const std::string& pre, int L) {
+    const vcad_config& c = e->c;
+    const long D = c.vit_dim, inner = (long)c.vit_heads * c.vit_dim_head;
+    VitW::L& l = e->wv[v].l[L];
+    std::string a = pre + "transformer.layers." + std::to_string(L) + ".0.";
+    std::string f = pre + "transformer.layers." + std::to_string(L) + ".1.net.";
+    l.w4 = add_param(e, f + "4.weight", {D, c.vit_mlp}); l.b4 = add_param(e, f + "4.bias", {D});
+    l.w1 = add_param(e, f + "1.weight", {c.vit_mlp, D}); l.b1 = add_param(e, f + "1.bias", {(long)c.vit_mlp});
+    l.fnw = add_param(e, f + "0.weight", {D}); l.fnb = add_param(e, f + "0.bias", {D});
+    l.ow = add_param(e, a + "to_out.0.weight", {D, inner}); l.ob = add_param(e, a + "to_out.0.bias", {D});
+    l.qkv = add_param(e, a + "to_qkv.weight", {3 * inner, D});
+    l.anw = add_param(e, a + "norm.weight", {D}); l.anb = add_param(e, a + "norm.bias", {D});
+}
+void add_vit_embed(vcad_engine* e, int v, const std::string& pre) {
+    const vcad_config& c = e->c;
+    const long D = c.vit_dim, pd = (long)c.patch_size * c.patch_size;
+    const long ntok = (long)(c.image_size / c.patch_size) * (c.image_size / c.patch_size) + 1;
+    VitW& w = e->wv[v];
+    w.ln2w = add_param(e, pre + "to_patch_embedding.3.weight", {D}); w.ln2b = add_param(e, pre + "to_patch_embedding.3.bias", {D});
+    w.pew = add_param(e, pre + "to_patch_embedding.2.weight", {D, pd}); w.peb = add_param(e, pre + "to_patch_embedding.2.bias", {D});
+    w.ln1w = add_param(e, pre + "to_patch_embedding.1.weight", {pd}); w.ln1b = add_param(e, pre + "to_patch_embedding.1.bias", {pd});
+    w.pos = add_param(e, pre + "pos_embedding", {1, ntok, D});
+    w.cls = add_param(e, pre + "cls_token", {1, 1, D});
+}
+
+void build_params(vcad_engine* e) {
+    const vcad_config& c = e->c;
+    const long H = c.hidden_size, ff = c.dim_feedforward;
+    // ---- bucket 0: heads, decoder L-1..0, stem
+    long b0 = e->ptotal;
+    e->o_h6_w = add_param(e, "predict_action_class_0_999.weight", {(long)c.num_params * c.num_params_values, H});
+    e->o_h6_b = add_param(e, "predict_action_class_0_999.bias", {(long)c.num_params * c.num_params_values});
+    e->o_h5_w = add_param(e, "predict_action_class_0_4.weight", {(long)c.num_classes, H});
+    e->o_h5_b = add_param(e, "predict_action_class_0_4.bias", {(long)c.num_classes});
+    e->wd.resize(c.num_decoder_layers);
+    for (int L = c.num_decoder_layers - 1; L >= 0; --L) {
+        std::string p = "transformer_decoder.layers." + std::to_string(L) + ".";
+        DecW& w = e->wd[L];
+        w.n3w = add_param(e, p + "norm3.weight", {H}); w.n3b = add_param(e, p + "norm3.bias", {H});
+        w.w2 = add_param(e, p + "linear2.weight", {H, ff}); w.b2 = add_param(e, p + "linear2.bias", {H});
+        w.w1 = add_param(e, p + "linear1.weight", {ff, H}); w.b1 = add_param(e, p + "linear1.bias", {ff});
+        w.n2w = add_param(e, p + "norm2.weight", {H}); w.n2b = add_param(e, p + "norm2.bias", {H});
+        w.ca_ow = add_param(e, p + "multihead_attn.out_proj.weight", {H, H}); w.ca_ob = add_param(e, p + "multihead_attn.out_proj.bias", {H});
+        w.ca_w = add_param(e, p + "multihead_attn.in_proj_weight", {3 * H, H}); w.ca_b = add_param(e, p + "multihead_attn.in_proj_bias", {3 * H});
+        w.n1w = add_param(e, p + "norm1.weight", {H}); w.n1b = add_param(e, p + "norm1.bias", {H});
+        w.sa_ow = add_param(e, p + "self_attn.out_proj.weight", {H, H}); w.sa_ob = add_param(e, p + "self_attn.out_proj.bias", {H});
+        w.sa_w = add_param(e, p + "self_attn.in_proj_weight", {3 * H, H}); w.sa_b = add_param(e, p + "self_attn.in_proj_bias", {3 * H});
+    }
+    e->o_ea_w = add_param(e, "embed_action.weight", {H, (long)c.act_dim}); e->o_ea_b = add_param(e, "embed_action.bias", {H});
+    e->o_ts = add_param(e, "timestep_embedding.weight", {(long)c.max_ep_len, H});
+    e->o_ip_w = add_param(e, "image_projection.weight", {H, 2 * H}); e->o_ip_b = add_param(e, "image_projection.bias", {H});
+    e->o_ei_w = add_param(e, "embed_image.weight", {H, (long)c.vit_dim}); e->o_ei_b = add_param(e, "embed_image.bias", {H});
+    e->o_es_w = add_param(e, "embed_state.weight", {H, (long)c.vit_dim}); e->o_es_b = add_param(e, "embed_state.bias", {H});
+    e->buckets.push_back({b0, e->ptotal});
+    // ---- bucket 1: CAD ViT;  buckets 2,3: state ViT (upper / lower half)
+    for (int v = 1; v >= 0; --v) {
+        std::string pre = v == 0 ? "state_embedding_model." : "cad_embedding_model.";
+        e->wv[v].l.resize(c.vit_depth);
+        long bb = e->ptotal;
+        e->wv[v].normw = add_param(e, pre + "transformer.norm.weight", {(long)c.vit_dim});
+        e->wv[v].normb = add_param(e, pre + "transformer.norm.bias", {(long)c.vit_dim});
+        const int split = c.vit_depth / 2;
+        for (int L = c.vit_depth - 1; L >= 0; --L) {
+            if (v == 0 && L == split - 1) { e->buckets.push_back({bb, e->ptotal}); bb = e->ptotal; }
+            add_vit_layer(e, v, pre, L);
+        }
+        add_vit_embed(e, v, pre);
+        e->buckets.push_back({bb, e->ptotal});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// workspace plan
+// ---------------------------------------------------------------------------------------------------------------
+struct Bump {
+    char* base; size_t off = 0;
+    template <typename U> U* take(size_t bytes) { off = (off + 255) & ~(size_t)255; U* p = (U*)(base + off); off += bytes; return p; }
+};
+
+size_t plan(vcad_engine* e, int B, int T, char* base) {
+    const vcad_config& c = e->c;
+    Bump b{base};
+    const size_t es = e->esz;
+    const long M = (long)B * T, H = c.hidden_size, D = c.vit_dim, inner = (long)c.vit_heads * c.vit_dim_head;
+    const long g = c.image_size / c.patch_size, P = g * g, pd = (long)c.patch_size * c.patch_size;
+    for (int v = 0; v < 2; ++v) {
+        VitActs& a = e->va[v];
+        a.N = v == 0 ? M : B;
+        const long R = a.N * (P + 1), Rp = a.N * P;
+        a.pn = b.take<void>(Rp * pd * es); a.pstat = b.take<float>(Rp * 2 * 4); a.pe = b.take<float>(Rp * D * 4);
+        a.stat2 = b.take<float>(Rp * 2 * 4); a.x0 = b.take<float>(R * D * 4);
+        a.L.resize(c.vit_depth);
+        for (auto& l : a.L) {
+            l.stat_a = b.take<float>(R * 2 * 4); l.h_a = b.take<void>(R * D * es); l.qkv = b.take<void>(R * 3 * inner * es);
+            l.lse = b.take<float>(a.N * c.vit_heads * (P + 1) * 4); l.ao = b.take<void>(R * inner * es); l.xm = b.take<float>(R * D * 4);
+            l.stat_f = b.take<float>(R * 2 * 4); l.h_f = b.take<void>(R * D * es); l.z = b.take<void>(R * c.vit_mlp * es);
+            l.g = b.take<void>(R * c.vit_mlp * es); l.xo = b.take<float>(R * D * 4);
+        }
+        a.statn = b.take<float>(a.N * 2 * 4); a.e = b.take<void>(a.N * D * es);
+    }
+    e->ui = b.take<float>(M * H * 4); e->cadE = b.take<void>((long)B * H * es); e->cadterm = b.take<float>((long)B * H * 4);
+    e->mem = b.take<float>(M * H * 4); e->act = b.take<float>(M * H * 4);
+    e->da.resize(c.num_decoder_layers);
+    for (auto& d : e->da) {
+        d.qkv_s = b.take<void>(M * 3 * H * es); d.lse_s = b.take<float>((long)B * c.nhead * T * 4); d.ao_s = b.take<void>(M * H * es);
+        d.s1 = b.take<float>(M * H * 4); d.st1 = b.take<float>(M * 2 * 4); d.x1 = b.take<float>(M * H * 4);
+        d.q_c = b.take<void>(M * H * es); d.kv_c = b.take<void>(M * 2 * H * es); d.lse_c = b.take<float>((long)B * c.nhead * T * 4);
+        d.ao_c = b.take<void>(M * H * es); d.s2 = b.take<float>(M * H * 4); d.st2 = b.take<float>(M * 2 * 4); d.x2 = b.take<float>(M * H * 4);
+        d.f1 = b.take<void>(M * c.dim_feedforward * es); d.s3 = b.take<float>(M * H * 4); d.st3 = b.take<float>(M * 2 * 4); d.x3 = b.take<float>(M * H * 4);
+    }
+    // backward temporaries (ViT ones sized for the frame ViT, shared with the CAD ViT)
+    const long R = M * (P + 1), Rp = M * P;
+    e->t_dx = b.take<float>(R * D * 4); e->t_dpe = b.take<float>(Rp * D * 4); e->t_dz = b.take<void>(R * c.vit_mlp * es);
+    e->t_dh = b.take<void>(R * D * es); e->t_dao = b.take<void>(R * inner * es); e->t_dqkv = b.take<void>(R * 3 * inner * es);
+    e->t_dpn = b.take<void>(Rp * pd * es);
+    long dmax = (long)B * c.nhead * T; long vmax = M * c.vit_heads * (P + 1);
+    e->t_delta = b.take<float>((dmax > vmax ? dmax : vmax) * 4);
+    e->t_dmem = b.take<float>(M * H * 4); e->t_dcur = b.take<float>(M * H * 4); e->t_dui = b.take<float>(M * H * 4); e->t_dpre = b.take<float>(M * H * 4);
+    e->t_dcadterm = b.take<float>((long)B * H * 4); e->t_dcadE = b.take<float>((long)B * H * 4);
+    e->t_dec = b.take<float>((long)B * D * 4); e->t_des = b.take<float>(M * D * 4);
+    e->t_df1 = b.take<void>(M * c.dim_feedforward * es); e->t_dq = b.take<void>(M * H * es); e->t_dkv = b.take<void>(M * 2 * H * es);
+    e->t_dao_d = b.take<void>(M * H * es); e->t_dqkv_d = b.take<void>(M * 3 * H * es);
+    // scratch
+    e->scr_splitk_bytes = 64ul << 20; e->scr_splitk = b.take<float>(e->scr_splitk_bytes);
+    e->scr_colsum_bytes = 64ul << 20; e->scr_colsum = b.take<float>(e->scr_colsum_bytes);
+    e->scr_lnpart_bytes = 1024ul * 2 * 1024 * 4; e->scr_lnpart = b.take<float>(e->scr_lnpart_bytes);
+    e->loss_rows = b.take<float>(M * 7 * 3 * 4); e->loss_arg = b.take<int>(M * 7 * 4);
+    e->loss_small = b.take<float>(64 * 4); e->loss_metrics = b.take<int>(VC_NMETRIC * 4);
+    const long nlog = (long)c.num_params * c.num_params_values;
+    e->dl_cmds = b.take<float>(M * c.num_classes * 4); e->dl_pars = b.take<float>(M * nlog * 4);
+    e->norm_part = b.take<float>(1024 * 4); e->norm_out = b.take<float>(8 * 4);
+    return b.off + 256;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------------
+#define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct Ctx {
+    vcad_engine* e; vc_stream_t s;
+    int dt() const { return e->dt; }
+    Mat W(long off, long ld) const { return e->dt == VC_BF16 ? Mat{(const void*)(e->S + off), VC_BF16, ld} : Mat{(const void*)(e->P + off), VC_F32, ld}; }
+    const float* Pf(long off) const { return e->P + off; }
+    float* Gf(long off) const { return e->G + off; }
+    Mat A32(const float* p, long ld) const { return Mat{p, VC_F32, ld}; }
+    Mat AT(const void* p, long ld) const { return Mat{p, e->dt, ld}; }
+
+    int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep) const {
+        GemmCall c; memset(&c, 0, sizeof(c));
+        c.ct = e->dt; c.sa = A.dt; c.sb = B.dt; c.to = C.dt; c.tra = tra; c.trb = trb;
+        GemmParams& p = c.p;
+        p.A = A.p; p.B = B.p; p.C = (void*)C.p; p.M = M; p.N = N; p.K = K; p.lda = A.ld; p.ldb = B.ld; p.ldc = C.ld;
+        p.alpha = 1.0f; p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr;
+        p.rowadd = ep.rowadd; p.rowadd_div = ep.rdiv; p.rowadd_mod = ep.rmod; p.ld_rowadd = ep.ldrow;
+        p.aux = ep.aux; p.ldaux = ep.ldaux; p.dact_src = ep.dact; p.lddact = ep.lddact; p.dact_kind = ep.dkind;
+        return vc_gemm(c, e->scr_splitk, e->scr_splitk_bytes, s);
+    }
+    // Y[M,N] = X[M,K] W[N,K]^T (+ epilogue)
+    int lin_fwd(Mat X, Mat Wm, Mat Y, int M, int N, int K, const Epi& ep) const { return gemm(X, 0, Wm, 0, Y, M, N, K, ep); }
+    // dX[M,K] = dY[M,N] W[N,K]
+    int lin_dgrad(Mat dY, Mat Wm, Mat dX, int M, int N, int K, const Epi& ep) const { return gemm(dY, 0, Wm, 1, dX, M, K, N, ep); }
+    // dW[N,K] = dY[tok,N]^T X[tok,K]   (fp32, written);  db[N] = colsum(dY)
+    int lin_wgrad(Mat dY, Mat X, float* dW, long lddw, float* db, int tok, int N, int K) const {
+        CK(gemm(dY, 1, X, 1, Mat{dW, VC_F32, lddw}, N, K, tok, Epi()));
+        if (db) CK(colsum(dY, tok, N, db, 0));
+        return 0;
+    }
+    int colsum(Mat X, long rows, int cols, float* out, int accumulate, int batch = 1, long bsx = 0, long bso = 0) const {
+        size_t need = (size_t)batch * vc_colsum_chunks(rows) * cols * 4;
+        if (need > e->scr_colsum_bytes) { vc_set_error("colsum scratch too small (%zu)", need); return VC_ERR_WORKSPACE; }
+        return vc_colsum(X.dt, X.p, X.ld, rows, cols, out, accumulate, batch, bsx, bso, e->scr_colsum, s);
+    }
+    int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C) const {
+        LnFwdParams p; memset(&p, 0, sizeof(p));
+        p.x = x; p.ldx = ldx; p.gamma = Pf(wo); p.beta = Pf(bo); p.y32 = y32; p.ldy32 = ldy32; p.yt = yt; p.ldyt = ldyt;
+        p.stats = stats; p.rows = rows; p.eps = 1e-5f;
+        return vc_ln_fwd(tx, e->dt, C, 0, p, s);
+    }
+    // dx32 (+T copy) = add_in + LNbwd(dy);  dgamma/dbeta written to the grad buffer
+    int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
+               const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C) const {
+        LnBwdParams p; memset(&p, 0, sizeof(p));
+        p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
+        p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
+        return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, e->scr_lnpart, Gf(wo), Gf(bo), e->scr_colsum, s);
+    }
+};
+
+int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bstride) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
+    const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
+    const long N = a.N, R = N * (P + 1), Rp = N * P;
+    if (pd != 1024 || D != 512) { vc_set_error("engine: ViT dims (patch_dim=%d, dim=%d) unsupported by the LN kernels", pd, D); return VC_ERR_UNSUPPORTED; }
+    {   // patchify + LN(1024)
+        LnFwdParams p; memset(&p, 0, sizeof(p));
+        p.x = img; p.gamma = cx.Pf(w.ln1w); p.beta = cx.Pf(w.ln1b); p.yt = a.pn; p.ldyt = pd; p.stats = a.pstat; p.rows = Rp; p.eps = 1e-5f;
+        p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.ldx = img_bstride;
+        CK(vc_ln_fwd(VC_F32, e->dt, pd, 1, p, cx.s));
+    }
+    { Epi ep; ep.bias = cx.Pf(w.peb); CK(cx.lin_fwd(cx.AT(a.pn, pd), cx.W(w.pew, pd), cx.A32(a.pe, D), (int)Rp, D, pd, ep)); }
+    {   // LN(512) + cls + pos  -> x0
+        LnFwdParams p; memset(&p, 0, sizeof(p));
+        p.x = a.pe; p.ldx = D; p.gamma = cx.Pf(w.ln2w); p.beta = cx.Pf(w.ln2b); p.y32 = a.x0; p.ldy32 = D; p.stats = a.stat2;
+        p.rows = R; p.eps = 1e-5f; p.pos = cx.Pf(w.pos); p.cls = cx.Pf(w.cls); p.P = P;
+        CK(vc_ln_fwd(VC_F32, VC_F32, D, 2, p, cx.s));
+    }
+    const float* x = a.x0;
+    for (int L = 0; L < c.vit_depth; ++L) {
+        const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
+        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D));
+        CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
+        {
+            AttnParams p; memset(&p, 0, sizeof(p));
+            const char* q = (const char*)l.qkv;
+            p.q = q; p.k = q + (size_t)inner * e->esz; p.v = q + (size_t)2 * inner * e->esz; p.o = l.ao;
+            p.ldq = p.ldk = p.ldv = 3 * inner; p.ldo = inner; p.lse = l.lse;
+            p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
+            CK(vc_attn_fwd(e->dt, c.vit_dim_head, p, cx.s));
+        }
+        { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
+        CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
+        { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp;
+          CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
+        { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D;
+          CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
+        x = l.xo;
+    }
+    // final LN on the cls row only (pool = 'cls', mlp_head = Identity)
+    CK(cx.ln_fwd(VC_F32, x, (long)(P + 1) * D, w.normw, w.normb, nullptr, 0, a.e, D, a.statn, N, D));
+    return 0;
+}
+
+// de: fp32 [N, D] gradient of the cls embedding.  first/last layer range lets the caller split into DDP stages.
+int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 = top half (cls-LN + upper layers), 2 = bottom half + embed*/,
+                 const float* img, long img_T, long img_bstride) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
+    const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
+    const long N = a.N, R = N * (P + 1), Rp = N * P;
+    float* dx = e->t_dx;
+    const int split = c.vit_depth / 2;
+    int Lhi = c.vit_depth - 1, Llo = 0;
+    if (part == 1) Llo = split; if (part == 2) Lhi = split - 1;
+    if (part != 2) {
+        CK(vc_memset_async(dx, 0, (size_t)R * D * 4, cx.s));
+        const float* xl = a.L[c.vit_depth - 1].xo;
+        CK(cx.ln_bwd(VC_F32, de, D, xl, (long)(P + 1) * D, a.statn, w.normw, w.normb, nullptr, 0, dx, (long)(P + 1) * D, N, D));
+    }
+    for (int L = Lhi; L >= Llo; --L) {
+        const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
+        const float* xin = L == 0 ? a.x0 : a.L[L - 1].xo;
+        // MLP
+        CK(cx.lin_wgrad(cx.A32(dx, D), cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)R, D, c.vit_mlp));
+        { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU;
+          CK(cx.lin_dgrad(cx.A32(dx, D), cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)R, D, c.vit_mlp, ep)); }
+        CK(cx.lin_wgrad(cx.AT(e->t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)R, c.vit_mlp, D));
+        CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)R, c.vit_mlp, D, Epi()));
+        CK(cx.ln_bwd(e->dt, e->t_dh, D, l.xm, D, l.stat_f, wl.fnw, wl.fnb, dx, D, dx, D, R, D));
+        // attention block
+        CK(cx.lin_wgrad(cx.A32(dx, D), cx.AT(l.ao, inner), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)R, D, inner));
+        CK(cx.lin_dgrad(cx.A32(dx, D), cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)R, D, inner, Epi()));
+        {
+            AttnParams p; memset(&p, 0, sizeof(p));
+            const char* q = (const char*)l.qkv; char* dq = (char*)e->t_dqkv;
+            p.q = q; p.k = q + (size_t)inner * e->esz; p.v = q + (size_t)2 * inner * e->esz;
+            p.ldq = p.ldk = p.ldv = 3 * inner; p.lse = l.lse; p.delta = e->t_delta;
+            p.dout = e->t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
+            p.lddq = p.lddk = p.lddv = 3 * inner;
+            p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
+            CK(vc_attn_bwd(e->dt, c.vit_dim_head, p, cx.s));
+        }
+        CK(cx.lin_wgrad(cx.AT(e->t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
+        CK(cx.lin_dgrad(cx.AT(e->t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(e->t_dh, D), (int)R, 3 * inner, D, Epi()));
+        CK(cx.ln_bwd(e->dt, e->t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
+    }
+    if (part != 1) {
+        // pos / cls gradients: column sums over frames of dx viewed as [N, (P+1)*D]
+        CK(cx.colsum(cx.A32(dx, (long)(P + 1) * D), N, (P + 1) * D, cx.Gf(w.pos), 0));
+        CK(vc_memcpy_d2d_async(cx.Gf(w.cls), cx.Gf(w.pos), (size_t)D * 4, cx.s));
+        {   // LN(512) backward through the embed mapping
+            LnBwdParams p; memset(&p, 0, sizeof(p));
+            p.dy = dx; p.lddy = D; p.x = a.pe; p.ldx = D; p.stats = a.stat2; p.gamma = cx.Pf(w.ln2w);
+            p.dx32 = e->t_dpe; p.lddx32 = D; p.rows = Rp; p.P = P;
+            CK(vc_ln_bwd(VC_F32, VC_F32, VC_F32, D, 2, p, e->scr_lnpart, cx.Gf(w.ln2w), cx.Gf(w.ln2b), e->scr_colsum, cx.s));
+        }
+        CK(cx.lin_wgrad(cx.A32(e->t_dpe, D), cx.AT(a.pn, pd), cx.Gf(w.pew), pd, cx.Gf(w.peb), (int)Rp, D, pd));
+        CK(cx.lin_dgrad(cx.A32(e->t_dpe, D), cx.W(w.pew, pd), cx.AT(e->t_dpn, pd), (int)Rp, D, pd, Epi()));
+        {   // LN(1024) parameter gradients (input frames need no gradient)
+            LnBwdParams p; memset(&p, 0, sizeof(p));
+            p.dy = e->t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
+            p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T;
+            CK(vc_ln_bwd(e->dt, VC_F32, e->dt, pd, 1, p, e->scr_lnpart, cx.Gf(w.ln1w), cx.Gf(w.ln1b), e->scr_colsum, cx.s));
+        }
+    }
+    return 0;
+}
+
+int dec_attn(const Ctx& cx, bool bwd, const void* q, long ldq, const void* k, const void* v, long ldkv, void* o, float* lse,
+             int window, const void* dout, void* dq, void* dk, void* dv, long lddq, long lddkv) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c;
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.o = o; p.ldq = ldq; p.ldk = p.ldv = ldkv; p.ldo = c.hidden_size; p.lse = lse;
+    p.B = e->B; p.H = c.nhead; p.Tq = p.Tk = e->T; p.window = window; p.causal = 1;
+    const int hd = c.hidden_size / c.nhead;
+    p.scale = 1.0f / sqrtf((float)hd);
+    if (!bwd) return vc_attn_fwd(e->dt, hd, p, cx.s);
+    p.dout = dout; p.lddo = c.hidden_size; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = p.lddv = lddkv; p.delta = e->t_delta;
+    return vc_attn_bwd(e->dt, hd, p, cx.s);
+}
+
+int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t s) {
+    Ctx cx{e, s}; const vcad_config& c = e->c;
+    const int B = e->B, T = e->T, H = c.hidden_size, D = c.vit_dim; const long M = (long)B * T;
+    const size_t es = e->esz;
+    if (H != 1024) { vc_set_error("engine: hidden_size %d unsupported (LN kernels: 1024)", H); return VC_ERR_UNSUPPORTED; }
+    CK(vit_forward(cx, 0, e->in_frames, T, e->in_fbstride));
+    CK(vit_forward(cx, 1, e->in_cad, 1, (long)c.image_size * c.image_size));
+    const float* ts = cx.Pf(e->o_ts);
+    { Epi ep; ep.bias = cx.Pf(e->o_es_b); ep.rowadd = ts; ep.rdiv = T; ep.rmod = 1; ep.ldrow = H; ep.act = VC_ACT_TANH;
+      CK(cx.lin_fwd(cx.AT(e->va[0].e, D), cx.W(e->o_es_w, D), cx.A32(e->ui, H), (int)M, H, D, ep)); }
+    { Epi ep; ep.bias = cx.Pf(e->o_ei_b); CK(cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep)); }
+    { Epi ep; ep.bias = cx.Pf(e->o_ip_b);
+      Mat w2 = cx.W(e->o_ip_w + H, 2 * H);
+      CK(cx.lin_fwd(cx.AT(e->cadE, H), w2, cx.A32(e->cadterm, H), B, H, H, ep)); }
+    { Epi ep; ep.rowadd = e->cadterm; ep.rdiv = T; ep.rmod = 0; ep.ldrow = H; ep.act = VC_ACT_TANH;
+      CK(cx.lin_fwd(cx.A32(e->ui, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->mem, H), (int)M, H, H, ep)); }
+    CK(vc_embed_action(VC_F32, e->in_actions, cx.Pf(e->o_ea_w), cx.Pf(e->o_ea_b), ts, e->act, nullptr, M, H, c.act_dim, T, s));
+    const float* x = e->act;
+    for (int L = 0; L < c.num_decoder_layers; ++L) {
+        const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
+        { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, 3 * H), (int)M, 3 * H, H, ep)); }
+        { const char* q = (const char*)d.qkv_s;
+          CK(dec_attn(cx, false, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, T, nullptr, nullptr, nullptr, nullptr, 0, 0)); }
+        { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), (int)M, H, H, ep)); }
+        CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, nullptr, 0, d.st1, M, H));
+        { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), (int)M, H, H, ep)); }
+        { Epi ep; ep.bias = cx.Pf(w.ca_b + H); CK(cx.lin_fwd(cx.A32(e->mem, H), cx.W(w.ca_w + (long)H * H, H), cx.AT(d.kv_c, 2 * H), (int)M, 2 * H, H, ep)); }
+        { const char* kv = (const char*)d.kv_c;
+          CK(dec_attn(cx, false, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, d.ao_c, d.lse_c, c.window_size, nullptr, nullptr, nullptr, nullptr, 0, 0)); }
+        { Epi ep; ep.bias = cx.Pf(w.ca_ob); ep.residual = d.x1; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.ao_c, H), cx.W(w.ca_ow, H), cx.A32(d.s2, H), (int)M, H, H, ep)); }
+        CK(cx.ln_fwd(VC_F32, d.s2, H, w.n2w, w.n2b, d.x2, H, nullptr, 0, d.st2, M, H));
+        { Epi ep; ep.bias = cx.Pf(w.b1); ep.act = VC_ACT_RELU; CK(cx.lin_fwd(cx.A32(d.x2, H), cx.W(w.w1, H), cx.AT(d.f1, c.dim_feedforward), (int)M, c.dim_feedforward, H, ep)); }
+        { Epi ep; ep.bias = cx.Pf(w.b2); ep.residual = d.x2; ep.ldr = H;
+          CK(cx.lin_fwd(cx.AT(d.f1, c.dim_feedforward), cx.W(w.w2, c.dim_feedforward), cx.A32(d.s3, H), (int)M, H, c.dim_feedforward, ep)); }
+        CK(cx.ln_fwd(VC_F32, d.s3, H, w.n3w, w.n3b, d.x3, H, nullptr, 0, d.st3, M, H));
+        x = d.x3;
+    }
+    e->xfinal = (float*)x;
+    const int n5 = c.num_classes, n6 = c.num_params * c.num_params_values;
+    { Epi ep; ep.bias = cx.Pf(e->o_h5_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(e->o_h5_w, H), cx.A32(cmds_out, n5), (int)M, n5, H, ep)); }
+    { Epi ep; ep.bias = cx.Pf(e->o_h6_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(e->o_h6_w, H), cx.A32(pars_out, n6), (int)M, n6, H, ep)); }
+    return 0;
+}
+
+// stage 0: heads + decoder + stem (bucket 0).  Leaves d(cls_state) in t_des and d(cls_cad) in t_dec.
+int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_stream_t s) {
+    Ctx cx{e, s}; const vcad_config& c = e->c;
+    const int B = e->B, T = e->T, H = c.hidden_size, D = c.vit_dim, ff = c.dim_feedforward; const long M = (long)B * T;
+    const size_t es = e->esz;
+    const int n5 = c.num_classes, n6 = c.num_params * c.num_params_values;
+    float* dx = e->t_dcur;
+    const float* xf = e->xfinal;
+    CK(cx.lin_wgrad(cx.A32(dcmds, n5), cx.A32(xf, H), cx.Gf(e->o_h5_w), H, cx.Gf(e->o_h5_b), (int)M, n5, H));
+    CK(cx.lin_wgrad(cx.A32(dpars, n6), cx.A32(xf, H), cx.Gf(e->o_h6_w), H, cx.Gf(e->o_h6_b), (int)M, n6, H));
+    CK(cx.lin_dgrad(cx.A32(dpars, n6), cx.W(e->o_h6_w, H), cx.A32(dx, H), (int)M, n6, H, Epi()));
+    { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.A32(dcmds, n5), cx.W(e->o_h5_w, H), cx.A32(dx, H), (int)M, n5, H, ep)); }
+    for (int L = c.num_decoder_layers - 1; L >= 0; --L) {
+        const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
+        const float* xin = L == 0 ? e->act : e->da[L - 1].x3;
+        // ---- FFN
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H));
+        CK(cx.lin_wgrad(cx.A32(dx, H), cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
+        { Epi ep; ep.dact = d.f1; ep.lddact = ff; ep.dkind = VC_ACT_RELU;
+          CK(cx.lin_dgrad(cx.A32(dx, H), cx.W(w.w2, ff), cx.AT(e->t_df1, ff), (int)M, H, ff, ep)); }
+        CK(cx.lin_wgrad(cx.AT(e->t_df1, ff), cx.A32(d.x2, H), cx.Gf(w.w1), H, cx.Gf(w.b1), (int)M, ff, H));
+        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_df1, ff), cx.W(w.w1, H), cx.A32(dx, H), (int)M, ff, H, ep)); }
+        // ---- cross attention
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H));
+        CK(cx.lin_wgrad(cx.A32(dx, H), cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
+        CK(cx.lin_dgrad(cx.A32(dx, H), cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
+        { const char* kv = (const char*)d.kv_c; char* dkv = (char*)e->t_dkv;
+          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, nullptr, d.lse_c, c.window_size, e->t_dao_d, e->t_dq, dkv, dkv + (size_t)H * es, H, 2 * H)); }
+        CK(cx.lin_wgrad(cx.AT(e->t_dq, H), cx.A32(d.x1, H), cx.Gf(w.ca_w), H, cx.Gf(w.ca_b), (int)M, H, H));
+        CK(cx.lin_wgrad(cx.AT(e->t_dkv, 2 * H), cx.A32(e->mem, H), cx.Gf(w.ca_w + (long)H * H), H, cx.Gf(w.ca_b + H), (int)M, 2 * H, H));
+        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dq, H), cx.W(w.ca_w, H), cx.A32(dx, H), (int)M, H, H, ep)); }
+        { Epi ep; if (L != c.num_decoder_layers - 1) { ep.residual = e->t_dmem; ep.ldr = H; }
+          CK(cx.lin_dgrad(cx.AT(e->t_dkv, 2 * H), cx.W(w.ca_w + (long)H * H, H), cx.A32(e->t_dmem, H), (int)M, 2 * H, H, ep)); }
+        // ---- self attention
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H));
+        CK(cx.lin_wgrad(cx.A32(dx, H), cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
+        CK(cx.lin_dgrad(cx.A32(dx, H), cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
+        { const char* q = (const char*)d.qkv_s; char* dq = (char*)e->t_dqkv_d;
+          CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, nullptr, d.lse_s, T, e->t_dao_d,
+                      dq, dq + (size_t)H * es, dq + (size_t)2 * H * es, 3 * H, 3 * H)); }
+        CK(cx.lin_wgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.A32(xin, H), cx.Gf(w.sa_w), H, cx.Gf(w.sa_b), (int)M, 3 * H, H));
+        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }
+    }
+    // ---- stem (reference model/autoregressive_transformer.py:144-178)
+    float* dpre = e->t_dpre;
+    CK(vc_memset_async(cx.Gf(e->o_ts), 0, (size_t)c.max_ep_len * H * 4, s));       // rows >= T receive no gradient
+    CK(vc_dtanh(VC_F32, dx, e->act, dpre, nullptr, M * H, s));                     // d pre-tanh of the action embedding
+    CK(cx.lin_wgrad(cx.A32(dpre, H), cx.A32(e->in_actions, c.act_dim), cx.Gf(e->o_ea_w), c.act_dim, cx.Gf(e->o_ea_b), (int)M, H, c.act_dim));
+    CK(cx.colsum(cx.A32(dpre, (long)T * H), B, T * H, cx.Gf(e->o_ts), 0));
+    CK(vc_dtanh(VC_F32, e->t_dmem, e->mem, dpre, nullptr, M * H, s));              // d pre-tanh of the image projection
+    CK(cx.gemm(cx.A32(dpre, H), 1, cx.A32(e->ui, H), 1, Mat{cx.Gf(e->o_ip_w), VC_F32, 2L * H}, H, H, (int)M, Epi()));
+    CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadterm, 0, B, (long)T * H, H));    // sum over t -> [B, H]
+    CK(cx.colsum(cx.A32(e->t_dcadterm, H), B, H, cx.Gf(e->o_ip_b), 0));
+    CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->cadE, H), 1, Mat{cx.Gf(e->o_ip_w + H), VC_F32, 2L * H}, H, H, B, Epi()));
+    CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + H, 2 * H), cx.A32(e->t_dcadE, H), B, H, H, Epi()));
+    CK(cx.lin_wgrad(cx.A32(e->t_dcadE, H), cx.AT(e->va[1].e, D), cx.Gf(e->o_ei_w), D, cx.Gf(e->o_ei_b), B, H, D));
+    CK(cx.lin_dgrad(cx.A32(e->t_dcadE, H), cx.W(e->o_ei_w, D), cx.A32(e->t_dec, D), B, H, D, Epi()));
+    CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->t_dui, H), (int)M, H, H, Epi()));
+    CK(vc_dtanh(VC_F32, e->t_dui, e->ui, dpre, nullptr, M * H, s));                // d pre-tanh of the state embedding
+    CK(cx.lin_wgrad(cx.A32(dpre, H), cx.AT(e->va[0].e, D), cx.Gf(e->o_es_w), D, cx.Gf(e->o_es_b), (int)M, H, D));
+    CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_es_w, D), cx.A32(e->t_des, D), (int)M, H, D, Epi()));
+    CK(cx.colsum(cx.A32(dpre, (long)T * H), B, T * H, cx.Gf(e->o_ts), 1));
+    return 0;
+}
+
+}  // namespace
+
+// ===============================================================================================================
+// C ABI
+// ===============================================================================================================
+extern "C" {
+
+const char* vcad_last_error(void) { return vc_get_error(); }
+const char* vcad_version(void) { return "videocad_amd 0.1 (gfx950)"; }
+
+int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
+    if (!cfg || !out) { vc_set_error("null argument"); return VC_ERR_ARG; }
+    if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_BF16) { vc_set_error("bad dtype %d", cfg->dtype); return VC_ERR_ARG; }
+    if (cfg->hidden_size % cfg->nhead) { vc_set_error("hidden_size %% nhead != 0"); return VC_ERR_ARG; }
+    const int hd = cfg->hidden_size / cfg->nhead;
+    if ((hd != 256 && hd != 64) || cfg->vit_dim_head != 64) { vc_set_error("head dims (%d, %d) unsupported (64/256)", hd, cfg->vit_dim_head); return VC_ERR_UNSUPPORTED; }
+    if (cfg->window_size < 1) { vc_set_error("window_size must be > 0 (reference model/autoregressive_transformer.py:52)"); return VC_ERR_ARG; }
+    vcad_engine* e = new vcad_engine();
+    e->c = *cfg; e->dt = cfg->dtype; e->esz = cfg->dtype == VCAD_BF16 ? 2 : 4;
+    build_params(e);
+    *out = e;
+    return 0;
+}
+void vcad_engine_destroy(vcad_engine* e) { delete e; }
+
+int64_t vcad_param_total(const vcad_engine* e) { return e->ptotal; }
+int vcad_param_count(const vcad_engine* e) { return (int)e->plist.size(); }
+int vcad_param_info(const vcad_engine* e, int i, char* name, size_t cap, int64_t* off, int64_t* numel, int64_t shape[4], int* ndim) {
+    if (i < 0 || i >= (int)e->plist.size()) { vc_set_error("param index %d out of range", i); return VC_ERR_ARG; }
+    const PInfo& p = e->plist[i];
+    if (name && cap) { strncpy(name, p.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (off) *off = p.off; if (numel) *numel = p.numel; if (ndim) *ndim = p.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+    return 0;
+}
+int vcad_bucket_count(const vcad_engine* e) { return (int)e->buckets.size(); }
+int vcad_bucket_range(const vcad_engine* e, int b, int64_t* begin, int64_t* end) {
+    if (b < 0 || b >= (int)e->buckets.size()) { vc_set_error("bucket %d out of range", b); return VC_ERR_ARG; }
+    *begin = e->buckets[b].first; *end = e->buckets[b].second; return 0;
+}
+int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, void* shadow) {
+    if (!params) { vc_set_error("vcad_bind: params is null"); return VC_ERR_ARG; }
+    if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
+    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow;
+    return 0;
+}
+int vcad_sync_shadow(vcad_engine* e, void* stream) {
+    if (e->dt != VC_BF16) return 0;
+    if (!e->P || !e->S) { vc_set_error("vcad_sync_shadow: not bound"); return VC_ERR_ARG; }
+    return vc_cast(VC_BF16, e->P, e->S, e->ptotal, (vc_stream_t)stream);
+}
+size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
+    vcad_engine tmp = *e;
+    return plan(&tmp, B, T, nullptr);
+}
+int vcad_set_workspace(vcad_engine* e, void* ws, size_t bytes) { e->ws = (char*)ws; e->ws_bytes = bytes; e->fwd_valid = false; e->B = e->T = 0; return 0; }
+
+int vcad_forward(vcad_engine* e, const float* frames, int64_t fbstride, const float* actions, const float* cad, int B, int T,
+                 float* cmds_out, float* pars_out, void* stream) {
+    if (!e->P) { vc_set_error("vcad_forward: parameters not bound"); return VC_ERR_ARG; }
+    if (B < 1 || T < 1 || T > e->c.max_ep_len) { vc_set_error("vcad_forward: bad B=%d T=%d", B, T); return VC_ERR_ARG; }
+    if (T > 192) { vc_set_error("vcad_forward: T=%d exceeds the attention kernels' 192-key limit", T); return VC_ERR_UNSUPPORTED; }
+    if (!e->ws) { vc_set_error("vcad_forward: no workspace"); return VC_ERR_WORKSPACE; }
+    size_t need = plan(e, B, T, e->ws);
+    if (need > e->ws_bytes) { vc_set_error("vcad_forward: workspace %zu < %zu bytes", e->ws_bytes, need); return VC_ERR_WORKSPACE; }
+    e->B = B; e->T = T; e->in_frames = frames; e->in_fbstride = fbstride; e->in_actions = actions; e->in_cad = cad;
+    e->fwd_valid = false;
+    int rc = engine_forward(e, cmds_out, pars_out, (vc_stream_t)stream);
+    if (rc) return rc;
+    if (vc_last_launch_error()) { vc_set_error("vcad_forward: kernel launch failed"); return VC_ERR_LAUNCH; }
+    e->fwd_valid = true;
+    return 0;
+}
+
+static void fill_loss_params(vcad_engine* e, LossParams& p, const float* cmds, const float* pars, const float* targets, int B, int T,
+                             int use_mse, const float* class_w) {
+    memset(&p, 0, sizeof(p));
+    const vcad_config& c = e->c; const long M = (long)B * T;
+    p.cmds = cmds; p.ldc = c.num_classes; p.pars = pars; p.ldp = (long)c.num_params * c.num_params_values; p.targets = targets;
+    p.M = M; p.T = T; p.use_mse = use_mse;
+    const int tol[6] = {2, 2, 50, 200, 500, 2};            // reference trainer.py:827 (TOLERANCE = 3)
+    const int above[6] = {0, 0, 1, 1, 1, 0};               // reference trainer.py:829 (metrics only; the loss window is always one-sided)
+    const float lw[5] = {0.04332685213392362f, 0.02915898563179938f, 0.267566828114559f, 0.6005346809501417f, 0.05941265316957628f};
+    const int p2l[6] = {0, 0, 1, 1, 2, 3};                 // reference trainer.py:825
+    for (int i = 0; i < 6; ++i) { p.tol[i] = tol[i]; p.above[i] = above[i]; p.param_to_label[i] = p2l[i]; }
+    for (int i = 0; i < 5; ++i) p.label_w[i] = lw[i];
+    p.class_w = class_w;
+    p.row_num = e->loss_rows; p.row_den = e->loss_rows + M * 7; p.row_lse = e->loss_rows + 2 * M * 7; p.row_arg = e->loss_arg;
+    p.loss_out = e->loss_small; p.scales = e->loss_small + 16; p.metrics = e->loss_metrics;
+    p.dcmds = e->dl_cmds; p.lddc = c.num_classes; p.dpars = e->dl_pars; p.lddp = p.ldp;
+}
+
+int vcad_loss(vcad_engine* e, const float* cmds, const float* pars, const float* targets, int B, int T, int use_mse,
+              const float* class_w, float* loss_out, int32_t* metrics_out, void* stream) {
+    if (!e->ws || B != e->B || T != e->T) { vc_set_error("vcad_loss: call vcad_forward with the same (B,T) first"); return VC_ERR_ARG; }
+    if (e->c.num_classes != 5 || e->c.num_params != 6 || e->c.num_params_values != 1000) { vc_set_error("vcad_loss: heads must be 5 + 6x1000 (reference autoregressive_transformer.py:218)"); return VC_ERR_UNSUPPORTED; }
+    if (!use_mse && !class_w) { vc_set_error("vcad_loss: use_mse=0 needs class_weights"); return VC_ERR_ARG; }
+    LossParams p; fill_loss_params(e, p, cmds, pars, targets, B, T, use_mse, class_w);
+    vc_stream_t s = (vc_stream_t)stream;
+    CK(vc_loss_fwd(p, s));
+    CK(vc_loss_bwd(p, s));
+    if (loss_out) CK(vc_memcpy_d2d_async(loss_out, e->loss_small, 8 * 4, s));
+    if (metrics_out) CK(vc_memcpy_d2d_async(metrics_out, e->loss_metrics, VC_NMETRIC * 4, s));
+    return 0;
+}
+
+int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const float* dpars, void* stream) {
+    if (!e->fwd_valid) { vc_set_error("vcad_backward: no forward activations (call vcad_forward first)"); return VC_ERR_ARG; }
+    if (!e->G) { vc_set_error("vcad_backward: gradient buffer not bound"); return VC_ERR_ARG; }
+    if ((dcmds == nullptr) != (dpars == nullptr)) { vc_set_error("vcad_backward: dcmds/dparams must both be given or both be NULL"); return VC_ERR_ARG; }
+    vc_stream_t s = (vc_stream_t)stream; Ctx cx{e, s};
+    const long img2 = (long)e->c.image_size * e->c.image_size;
+    int rc = 0;
+    switch (stage) {
+        case 0: rc = backward_stage0(e, dcmds ? dcmds : e->dl_cmds, dpars ? dpars : e->dl_pars, s); break;
+        case 1: rc = vit_backward(cx, 1, e->t_dec, 0, e->in_cad, 1, img2); break;
+        case 2: rc = vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride); break;
+        case 3: rc = vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride); break;
+        default: vc_set_error("vcad_backward_stage: stage %d out of range", stage); return VC_ERR_ARG;
+    }
+    if (rc) return rc;
+    if (vc_last_launch_error()) { vc_set_error("vcad_backward: kernel launch failed"); return VC_ERR_LAUNCH; }
+    return 0;
+}
+int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
+    for (int st = 0; st < NB_BUCKETS; ++st) CK(vcad_backward_stage(e, st, dcmds, dpars, stream));
+    return 0;
+}
+
+int vcad_optimizer_step(vcad_engine* e, float lr, float b1, float b2, float eps, float max_norm, int step, float gscale,
+                        float* norm_out, void* stream) {
+    if (!e->P || !e->G || !e->Mm || !e->Vv) { vc_set_error("vcad_optimizer_step: buffers not bound"); return VC_ERR_ARG; }
+    if (!e->ws) { vc_set_error("vcad_optimizer_step: no workspace"); return VC_ERR_WORKSPACE; }
+    if (step < 1) { vc_set_error("vcad_optimizer_step: step must be >= 1"); return VC_ERR_ARG; }
+    if (e->B == 0) plan(e, 1, 1, e->ws);
+    vc_stream_t s = (vc_stream_t)stream;
+    // the norm the reference clips against is that of the (already averaged) gradients
+    CK(vc_grad_norm(e->G, e->ptotal, max_norm, gscale, e->norm_part, e->norm_out, s));
+    AdamParams a; memset(&a, 0, sizeof(a));
+    a.p = e->P; a.g = e->G; a.m = e->Mm; a.v = e->Vv; a.n = e->ptotal; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
+    a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
+    a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S;
+    CK(vc_adam(a, s));
+    if (norm_out) CK(vc_memcpy_d2d_async(norm_out, e->norm_out, 2 * 4, s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+// norm.h — LayerNorm family (one wave64 per row, wave-shuffle reductions, 16-byte loads), the fused
+// patchify+LayerNorm(1024) that feeds the patch-embed GEMM, and the LN(512)+cls+pos "embed finalize".
+// Statistics are two-pass in registers (mean, then centred variance) like ATen's, eps inside the sqrt.
+#pragma once
+#include "vc_rt.h"
+
+// ---- row access helpers: a wave owns one row of C = 64*VPL elements; lane l owns VPL/4 groups of 4
+// consecutive elements at columns g*256 + l*4 + (0..3)  (16-byte loads for fp32, 8-byte for bf16).
+template <typename T, int VPL>
+VC_DEV void row_load(const T* p, float (&v)[VPL], int lane) {
+#pragma unroll
+    for (int g = 0; g < VPL / 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[g * 4 + j] = vc_ld(p + g * 256 + lane * 4 + j);
+}
+template <typename T, int VPL>
+VC_DEV void row_store(T* p, const float (&v)[VPL], int lane) {
+#pragma unroll
+    for (int g = 0; g < VPL / 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vc_st(p + g * 256 + lane * 4 + j, v[g * 4 + j]);
+}
+template <int VPL>
+VC_DEV void row_stats(const float (&v)[VPL], float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += v[i];
+    mean = vc_wave_sum(s) * (1.0f / (64 * VPL));
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { float d = v[i] - mean; q += d * d; }
+    rstd = rsqrtf(vc_wave_sum(q) * (1.0f / (64 * VPL)) + eps);
+}
+
+// patch p of frame n: vector index e = p1*32 + p2 (c = 1) <- frame[n][ph*32+p1][pw*32+p2]
+// ('b c (h p1) (w p2) -> b (h w) (p1 p2 c)', reference model/trajectory_model.py:54-65 via vit-pytorch)
+// image n = b*T + t lives at frames + b*bstride + t*img*img (so the [:, :-1] view of the loader batch needs no copy)
+template <int VPL>
+VC_DEV void patch_load(const float* frames, long row, float (&v)[VPL], int lane, int img, int patch, int T, long bstride) {
+    const int g_ = img / patch;
+    const long n = row / (g_ * g_);
+    const int pp = (int)(row % (g_ * g_)), ph = pp / g_, pw = pp % g_;
+    const float* base = frames + (n / T) * bstride + (n % T) * (long)img * img + (long)(ph * patch) * img + pw * patch;
+#pragma unroll
+    for (int g = 0; g < VPL / 4; ++g) {
+        int e = g * 256 + lane * 4;
+        int p1 = e / patch, p2 = e % patch;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[g * 4 + j] = base[(long)p1 * img + p2 + j];
+    }
+}
+
+struct LnFwdParams {
+    const void* x; long ldx;          // input rows (type TX), or frames when PATCH
+    const float* gamma; const float* beta;
+    float* y32; long ldy32;           // optional fp32 output
+    void* yt; long ldyt;              // optional T output
+    float* stats;                     // optional [rows][2] = mean, rstd
+    long rows; float eps;
+    int img, patch;                   // PATCH mode
+    // EMBED mode: input row r = n*P + p  ->  output row n*(P+1) + p + 1, plus pos[p+1]; extra rows write cls+pos[0]
+    const float* pos; const float* cls; int P;
+};
+
+// MODE 0 plain, 1 PATCH (x = frames), 2 EMBED (see above; grid covers N*(P+1) output rows)
+template <typename TX, typename TY, int VPL, int MODE>
+VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    constexpr int C = 64 * VPL;
+    if (row >= p.rows) return;
+    float v[VPL];
+    long in_row = row, out_row = row;
+    if constexpr (MODE == 2) {
+        const long n = row / (p.P + 1); const int t = (int)(row % (p.P + 1));
+        if (t == 0) {                                   // cls token + pos[0]
+            float c[VPL], q[VPL];
+            row_load<float, VPL>(p.cls, c, lane); row_load<float, VPL>(p.pos, q, lane);
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) c[i] += q[i];
+            row_store<float, VPL>(p.y32 + row * p.ldy32, c, lane);
+            return;
+        }
+        in_row = n * p.P + (t - 1);
+    }
+    if constexpr (MODE == 1) patch_load<VPL>((const float*)p.x, row, v, lane, p.img, p.patch, p.P, p.ldx);   // P = T, ldx = batch stride
+    else row_load<TX, VPL>((const TX*)p.x + in_row * p.ldx, v, lane);
+    float mean, rstd;
+    row_stats<VPL>(v, p.eps, mean, rstd);
+    float g[VPL], b[VPL];
+    row_load<float, VPL>(p.gamma, g, lane); row_load<float, VPL>(p.beta, b, lane);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * g[i] + b[i];
+    if constexpr (MODE == 2) {
+        float q[VPL];
+        row_load<float, VPL>(p.pos + (long)(row % (p.P + 1)) * C, q, lane);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] += q[i];
+    }
+    if (p.y32) row_store<float, VPL>(p.y32 + out_row * p.ldy32, v, lane);
+    if (p.yt) row_store<TY, VPL>((TY*)p.yt + out_row * p.ldyt, v, lane);
+    if (p.stats && lane == 0) { p.stats[in_row * 2] = mean; p.stats[in_row * 2 + 1] = rstd; }
+}
+
+struct LnBwdParams {
+    const void* dy; long lddy;        // type TD
+    const void* x; long ldx;          // type TX (fp32 residual stream / pre-LN sum), or frames when PATCH
+    const float* stats;               // [rows][2]
+    const float* gamma;
+    const float* add_in; long ldadd;  // optional fp32 tensor added to dx (the residual-path gradient)
+    float* dx32; long lddx32;         // optional fp32 dx output (may alias add_in)
+    void* dxt; long lddxt;            // optional T dx output
+    float* partial;                   // [gridDim.x][2][C] dgamma / dbeta partial sums (fixed order => deterministic)
+    long rows;
+    int img, patch; int P;            // PATCH / EMBED mapping (EMBED: dy row = n*(P+1)+p+1 for x row n*P+p)
+};
+
+template <typename TD, typename TX, typename TY, int VPL, int MODE>
+VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
+    constexpr int C = 64 * VPL;
+    VC_SHARED float red[4][2][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[VPL], db[VPL], g[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    row_load<float, VPL>(p.gamma, g, lane);
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+        float x[VPL], dy[VPL];
+        long dy_row = row;
+        if constexpr (MODE == 2) dy_row = (row / p.P) * (p.P + 1) + (row % p.P) + 1;
+        if constexpr (MODE == 1) patch_load<VPL>((const float*)p.x, row, x, lane, p.img, p.patch, p.P, p.ldx);
+        else row_load<TX, VPL>((const TX*)p.x + row * p.ldx, x, lane);
+        row_load<TD, VPL>((const TD*)p.dy + dy_row * p.lddy, dy, lane);
+        const float mean = p.stats[row * 2], rstd = p.stats[row * 2 + 1];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            x[i] = (x[i] - mean) * rstd;               // xhat
+            dg[i] += dy[i] * x[i]; db[i] += dy[i];
+            dy[i] *= g[i];
+            c1 += dy[i]; c2 += dy[i] * x[i];
+        }
+        if (p.dx32 || p.dxt) {
+            c1 = vc_wave_sum(c1) * (1.0f / C); c2 = vc_wave_sum(c2) * (1.0f / C);
+            float dx[VPL];
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) dx[i] = rstd * (dy[i] - c1 - x[i] * c2);
+            if (p.add_in) {
+                float a[VPL];
+                row_load<float, VPL>(p.add_in + row * p.ldadd, a, lane);
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) dx[i] += a[i];
+            }
+            if (p.dx32) row_store<float, VPL>(p.dx32 + row * p.lddx32, dx, lane);
+            if (p.dxt) row_store<TY, VPL>((TY*)p.dxt + row * p.lddxt, dx, lane);
+        }
+    }
+    if (p.partial) {
+        row_store<float, VPL>(&red[wave][0][0], dg, lane);
+        row_store<float, VPL>(&red[wave][1][0], db, lane);
+        vc_sync();
+        const float* r0 = &red[0][0][0];                                          // [wave][2*C]
+        for (int i = threadIdx.x; i < 2 * C; i += 256)
+            p.partial[(long)blockIdx.x * 2 * C + i] = r0[i] + r0[2 * C + i] + r0[4 * C + i] + r0[6 * C + i];
+    }
+}
+
+// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c], two-stage & deterministic.  Batched over blockIdx.z.
+struct ColsumParams {
+    const void* x; long ld; long rows; int cols; long batch_stride_x;
+    float* out; long batch_stride_out; int accumulate;
+    float* partial;                   // [batch][gridDim.y][cols]
+    int rows_per_block;
+};
+template <typename TX>
+VC_KERNEL __launch_bounds__(256) void colsum_stage1_kernel(ColsumParams p) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.cols) return;
+    const TX* x = (const TX*)p.x + (long)blockIdx.z * p.batch_stride_x;
+    long r0 = (long)blockIdx.y * p.rows_per_block, r1 = r0 + p.rows_per_block;
+    if (r1 > p.rows) r1 = p.rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += vc_ld(x + r * p.ld + c);
+    p.partial[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.cols + c] = s;
+}
+VC_KERNEL __launch_bounds__(256) void colsum_stage2_kernel(ColsumParams p, int nchunk) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= p.cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += p.partial[((long)blockIdx.z * nchunk + k) * p.cols + c];
+    float* o = p.out + (long)blockIdx.z * p.batch_stride_out + c;
+    *o = p.accumulate ? (*o + s) : s;
+}
+
+// ---- elementwise: dpre = d * (1 - y^2)   (tanh backward; y fp32)
+template <typename TY>
+VC_KERNEL __launch_bounds__(256) void dtanh_kernel(const float* d, const float* y, float* out32, TY* outt, long n) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float yy = y[i];
+    float v = d[i] * (1.0f - yy * yy);
+    if (out32) out32[i] = v;
+    if (outt) vc_st(outt + i, v);
+}
+
+// ---- act = tanh(a W^T + b + ts[t])  with K = act_dim (7): too skinny for MFMA, one thread per output
+// (reference model/autoregressive_transformer.py:112,176-178)
+template <typename TY>
+VC_KERNEL __launch_bounds__(256) void embed_action_kernel(const float* a, const float* W, const float* b, const float* ts,
+                                                          float* y32, TY* yt, long M, int H, int K, int T) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * H) return;
+    long m = i / H; int n = (int)(i % H);
+    float s = b[n] + ts[(m % T) * (long)H + n];
+    for (int k = 0; k < K; ++k) s += a[m * K + k] * W[n * K + k];
+    s = tanhf(s);
+    y32[i] = s;
+    if (yt) vc_st(yt + i, s);
+}
+
+// ---- fp32 -> T cast (weight shadows) and generic fill
+template <typename TY>
+VC_KERNEL __launch_bounds__(256) void cast_kernel(const float* x, TY* y, long n) {
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (int j = 0; j < 4; ++j) if (i + j < n) vc_st(y + i + j, x[i + j]);
+}

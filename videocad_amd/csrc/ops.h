@@ -1,0 +1,46 @@
+// ops.h — host-side launchers for the hot-path kernels (used by engine.cpp and by the per-op C ABI).
+#pragma once
+#include "vc_rt.h"
+#include "gemm.h"
+#include "norm.h"
+#include "attn.h"
+#include "loss.h"
+#include "optim.h"
+
+enum { VC_F32 = 0, VC_BF16 = 1 };
+enum { VC_OK = 0, VC_ERR_ARG = 1, VC_ERR_UNSUPPORTED = 2, VC_ERR_LAUNCH = 3, VC_ERR_WORKSPACE = 4 };
+
+void vc_set_error(const char* fmt, ...);
+const char* vc_get_error();
+
+struct GemmCall {
+    int ct, sa, sb, to;         // compute / A-source / B-source / output dtypes
+    int tra, trb;
+    GemmParams p;               // vecA/vecB/k_per_split/partial are filled by vc_gemm
+};
+// scratch: fp32 workspace for split-K partial slabs (may be null -> no split)
+int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s);
+
+int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s);
+// partial_ws: >= ln_bwd_blocks(rows) * 2 * C floats; dgamma/dbeta written (not accumulated)
+long vc_ln_bwd_blocks(long rows);
+int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* partial_ws, float* dgamma, float* dbeta,
+              float* colsum_ws, vc_stream_t s);
+// out[b][c] (=|+=) sum_r x[b][r][c];  ws >= batch * nchunk(rows) * cols floats
+long vc_colsum_chunks(long rows);
+int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
+              int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s);
+int vc_dtanh(int ty, const float* d, const float* y, float* out32, void* outt, long n, vc_stream_t s);
+int vc_embed_action(int ty, const float* a, const float* W, const float* b, const float* ts, float* y32, void* yt,
+                    long M, int H, int K, int T, vc_stream_t s);
+int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
+
+int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s);
+int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s);
+
+int vc_loss_fwd(LossParams p, vc_stream_t s);          // rows + finalize
+int vc_loss_bwd(LossParams p, vc_stream_t s);          // dlogits
+
+// norm_out[0] = |g|, norm_out[1] = clip coef.  partial >= 1024 floats.
+int vc_grad_norm(const float* g, long n, float max_norm, float gscale, float* partial, float* norm_out, vc_stream_t s);
+int vc_adam(AdamParams a, vc_stream_t s);

@@ -1,0 +1,43 @@
+// ops_attn.hip — launchers for the windowed attention kernels.
+#include "ops.h"
+
+static int clampw(const AttnParams& p) { int mx = p.Tq > p.Tk ? p.Tq : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
+static int max_keys(const AttnParams& p) { int w = clampw(p); return w < p.Tk ? w : p.Tk; }        // visible keys per query
+static int max_queries(const AttnParams& p) { int w = clampw(p); return w < p.Tq ? w : p.Tq; }     // queries per key
+
+template <typename T>
+static int attn_fwd_t(int D, AttnParams p, vc_stream_t s) {
+    const long waves = (long)p.B * p.H * p.Tq;
+    dim3 g((unsigned)VC_CEIL_DIV(waves, 4));
+    const int np = VC_CEIL_DIV(max_keys(p), 64);
+    if (D == 64 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 1, 1>), g, dim3(256), 0, s, p);
+    else if (D == 256 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 4, 1>), g, dim3(256), 0, s, p);
+    else if (D == 256 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 4, 3>), g, dim3(256), 0, s, p);
+    else if (D == 64 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 1, 3>), g, dim3(256), 0, s, p);
+    else { vc_set_error("attn_fwd: D=%d keys=%d unsupported", D, max_keys(p)); return VC_ERR_UNSUPPORTED; }
+    return VC_OK;
+}
+template <typename T>
+static int attn_bwd_t(int D, AttnParams p, vc_stream_t s) {
+    dim3 gq((unsigned)VC_CEIL_DIV((long)p.B * p.H * p.Tq, 4)), gk((unsigned)VC_CEIL_DIV((long)p.B * p.H * p.Tk, 4));
+    const int npk = VC_CEIL_DIV(max_keys(p), 64), npq = VC_CEIL_DIV(max_queries(p), 64);
+    if (D == 64 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 1>), gq, dim3(256), 0, s, p);
+    else if (D == 256 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 1>), gq, dim3(256), 0, s, p);
+    else if (D == 256 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 3>), gq, dim3(256), 0, s, p);
+    else if (D == 64 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 3>), gq, dim3(256), 0, s, p);
+    else { vc_set_error("attn_bwd_q: D=%d keys=%d unsupported", D, max_keys(p)); return VC_ERR_UNSUPPORTED; }
+    if (D == 64 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 1>), gk, dim3(256), 0, s, p);
+    else if (D == 256 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 1>), gk, dim3(256), 0, s, p);
+    else if (D == 256 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 3>), gk, dim3(256), 0, s, p);
+    else if (D == 64 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 3>), gk, dim3(256), 0, s, p);
+    else { vc_set_error("attn_bwd_kv: D=%d queries=%d unsupported", D, max_queries(p)); return VC_ERR_UNSUPPORTED; }
+    return VC_OK;
+}
+int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
+    p.window = clampw(p);
+    return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
+}
+int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
+    p.window = clampw(p);
+    return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);
+}

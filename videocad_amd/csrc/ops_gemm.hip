@@ -1,0 +1,72 @@
+// ops_gemm.hip — GEMM dispatch: picks the template instantiation, the 16-byte-load legality flags and the
+// split-K factor (small tile counts with a long reduction, e.g. every wgrad: K = number of tokens).
+#include "ops.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+void vc_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
+const char* vc_get_error() { return g_err; }
+
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
+static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
+    constexpr size_t lds = gemm_lds_bytes<CT>();
+#ifndef VC_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<CT, SA, SB, TO, TRA, TRB>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+        attr_set = true;
+    }
+#endif
+    dim3 grid(VC_CEIL_DIV(c.p.N, GEMM_BN), VC_CEIL_DIV(c.p.M, GEMM_BM), nsplit);
+    VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB>), grid, dim3(GEMM_THREADS), lds, s, c.p);
+    if (nsplit > 1) {
+        long total = (long)c.p.M * c.p.N;
+        VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total, 256)), dim3(256), 0, s, c.p, nsplit);
+    }
+    return VC_OK;
+}
+
+static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
+
+int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
+    GemmParams& p = c.p;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
+    if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
+    p.vecA = (((uintptr_t)p.A) % 16 == 0) && ((p.lda * dsize(c.sa)) % 16 == 0);
+    p.vecB = (((uintptr_t)p.B) % 16 == 0) && ((p.ldb * dsize(c.sb)) % 16 == 0);
+    const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
+    long tiles = (long)VC_CEIL_DIV(p.M, GEMM_BM) * VC_CEIL_DIV(p.N, GEMM_BN);
+    int nsplit = 1;
+    if (scratch && tiles < 256 && p.K >= 8 * BK) {
+        nsplit = (int)VC_CEIL_DIV(512, tiles);
+        int maxs = p.K / (4 * BK); if (nsplit > maxs) nsplit = maxs;
+        size_t per = (size_t)p.M * p.N * sizeof(float);
+        if ((size_t)nsplit * per > scratch_bytes) nsplit = (int)(scratch_bytes / per);
+        if (nsplit < 1) nsplit = 1;
+    }
+    int kps = VC_CEIL_DIV(p.K, nsplit); kps = VC_CEIL_DIV(kps, BK) * BK;
+    nsplit = VC_CEIL_DIV(p.K, kps);
+    p.k_per_split = kps;
+    p.partial = nsplit > 1 ? scratch : nullptr;
+
+#define G(CT_, SA_, SB_, TO_, TRA_, TRB_) return gemm_launch<CT_, SA_, SB_, TO_, TRA_, TRB_>(c, nsplit, s)
+    const int lay = c.tra * 2 + c.trb;
+    if (c.ct == VC_F32) {
+        switch (lay) { case 0: G(float, float, float, float, false, false); case 1: G(float, float, float, float, false, true);
+                       case 2: G(float, float, float, float, true, false); case 3: G(float, float, float, float, true, true); }
+    } else if (c.sb == VC_BF16 && lay != 2) {
+        const int key = (c.sa == VC_F32) * 2 + (c.to == VC_F32);
+        if (lay == 0) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, false, false); case 1: G(vc_bf16, vc_bf16, vc_bf16, float, false, false);
+                                     case 2: G(vc_bf16, float, vc_bf16, vc_bf16, false, false);   case 3: G(vc_bf16, float, vc_bf16, float, false, false); }
+        if (lay == 1) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, false, true);  case 1: G(vc_bf16, vc_bf16, vc_bf16, float, false, true);
+                                     case 2: G(vc_bf16, float, vc_bf16, vc_bf16, false, true);    case 3: G(vc_bf16, float, vc_bf16, float, false, true); }
+        if (lay == 3) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, true, true);   case 1: G(vc_bf16, vc_bf16, vc_bf16, float, true, true);
+                                     case 2: G(vc_bf16, float, vc_bf16, vc_bf16, true, true);     case 3: G(vc_bf16, float, vc_bf16, float, true, true); }
+    }
+#undef G
+    vc_set_error("vc_gemm: unsupported combination ct=%d sa=%d sb=%d to=%d tra=%d trb=%d", c.ct, c.sa, c.sb, c.to, c.tra, c.trb);
+    return VC_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,119 @@
+// ops_misc.hip — launchers for LayerNorm / reductions / elementwise / loss / optimizer kernels.
+#include "ops.h"
+
+template <typename TX, typename TY, int MODE>
+static int ln_fwd_c(int C, LnFwdParams p, long out_rows, vc_stream_t s) {
+    dim3 grid((unsigned)VC_CEIL_DIV(out_rows, 4));
+    if (C == 512) VC_LAUNCH((ln_fwd_kernel<TX, TY, 8, MODE>), grid, dim3(256), 0, s, p);
+    else if (C == 1024) VC_LAUNCH((ln_fwd_kernel<TX, TY, 16, MODE>), grid, dim3(256), 0, s, p);
+    else { vc_set_error("ln_fwd: C=%d unsupported (512/1024)", C); return VC_ERR_UNSUPPORTED; }
+    return VC_OK;
+}
+template <typename TX, typename TY>
+static int ln_fwd_m(int C, int mode, LnFwdParams p, vc_stream_t s) {
+    if (mode == 0) return ln_fwd_c<TX, TY, 0>(C, p, p.rows, s);
+    if (mode == 1) return ln_fwd_c<float, TY, 1>(C, p, p.rows, s);
+    if (mode == 2) return ln_fwd_c<TX, TY, 2>(C, p, p.rows, s);      // p.rows = output rows N*(P+1)
+    vc_set_error("ln_fwd: bad mode %d", mode); return VC_ERR_ARG;
+}
+int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s) {
+    if (p.rows <= 0) return VC_OK;
+    if (tx == VC_F32 && ty == VC_F32) return ln_fwd_m<float, float>(C, mode, p, s);
+    if (tx == VC_F32 && ty == VC_BF16) return ln_fwd_m<float, vc_bf16>(C, mode, p, s);
+    if (tx == VC_BF16 && ty == VC_BF16) return ln_fwd_m<vc_bf16, vc_bf16>(C, mode, p, s);
+    vc_set_error("ln_fwd: dtype combo %d %d", tx, ty); return VC_ERR_UNSUPPORTED;
+}
+
+long vc_ln_bwd_blocks(long rows) { long b = VC_CEIL_DIV(rows, 4); return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
+
+template <typename TD, typename TX, typename TY, int MODE>
+static int ln_bwd_c(int C, LnBwdParams p, unsigned nblk, vc_stream_t s) {
+    if (C == 512) VC_LAUNCH((ln_bwd_kernel<TD, TX, TY, 8, MODE>), dim3(nblk), dim3(256), 0, s, p);
+    else if (C == 1024) VC_LAUNCH((ln_bwd_kernel<TD, TX, TY, 16, MODE>), dim3(nblk), dim3(256), 0, s, p);
+    else { vc_set_error("ln_bwd: C=%d unsupported", C); return VC_ERR_UNSUPPORTED; }
+    return VC_OK;
+}
+template <typename TD, typename TX, typename TY>
+static int ln_bwd_m(int C, int mode, LnBwdParams p, unsigned nblk, vc_stream_t s) {
+    if (mode == 0) return ln_bwd_c<TD, TX, TY, 0>(C, p, nblk, s);
+    if (mode == 1) return ln_bwd_c<TD, float, TY, 1>(C, p, nblk, s);
+    if (mode == 2) return ln_bwd_c<TD, TX, TY, 2>(C, p, nblk, s);
+    vc_set_error("ln_bwd: bad mode %d", mode); return VC_ERR_ARG;
+}
+int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* partial_ws, float* dgamma, float* dbeta,
+              float* colsum_ws, vc_stream_t s) {
+    if (p.rows <= 0) return VC_OK;
+    const unsigned nblk = (unsigned)vc_ln_bwd_blocks(p.rows);
+    p.partial = partial_ws;
+    int rc;
+    if (td == VC_F32 && tx == VC_F32 && ty == VC_F32) rc = ln_bwd_m<float, float, float>(C, mode, p, nblk, s);
+    else if (td == VC_BF16 && tx == VC_F32 && ty == VC_BF16) rc = ln_bwd_m<vc_bf16, float, vc_bf16>(C, mode, p, nblk, s);
+    else if (td == VC_F32 && tx == VC_F32 && ty == VC_BF16) rc = ln_bwd_m<float, float, vc_bf16>(C, mode, p, nblk, s);
+    else { vc_set_error("ln_bwd: dtype combo %d %d %d", td, tx, ty); return VC_ERR_UNSUPPORTED; }
+    if (rc) return rc;
+    if (partial_ws) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C)
+        rc = vc_colsum(VC_F32, partial_ws, 2L * C, nblk, C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+        rc = vc_colsum(VC_F32, partial_ws + C, 2L * C, nblk, C, dbeta, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+    }
+    return VC_OK;
+}
+
+long vc_colsum_chunks(long rows) { long c = VC_CEIL_DIV(rows, 256); return c > 512 ? 512 : (c < 1 ? 1 : c); }
+
+int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
+              int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s) {
+    if (rows <= 0 || cols <= 0) return VC_OK;
+    ColsumParams p;
+    p.x = x; p.ld = ld; p.rows = rows; p.cols = cols; p.batch_stride_x = bstride_x;
+    p.out = out; p.batch_stride_out = bstride_out; p.accumulate = accumulate; p.partial = ws;
+    const long nchunk = vc_colsum_chunks(rows);
+    p.rows_per_block = (int)VC_CEIL_DIV(rows, nchunk);
+    dim3 g1(VC_CEIL_DIV(cols, 256), (unsigned)nchunk, batch);
+    if (tx == VC_F32) VC_LAUNCH((colsum_stage1_kernel<float>), g1, dim3(256), 0, s, p);
+    else VC_LAUNCH((colsum_stage1_kernel<vc_bf16>), g1, dim3(256), 0, s, p);
+    VC_LAUNCH(colsum_stage2_kernel, dim3(VC_CEIL_DIV(cols, 256), 1, batch), dim3(256), 0, s, p, (int)nchunk);
+    return VC_OK;
+}
+
+int vc_dtanh(int ty, const float* d, const float* y, float* out32, void* outt, long n, vc_stream_t s) {
+    dim3 g((unsigned)VC_CEIL_DIV(n, 256));
+    if (ty == VC_BF16) VC_LAUNCH((dtanh_kernel<vc_bf16>), g, dim3(256), 0, s, d, y, out32, (vc_bf16*)outt, n);
+    else VC_LAUNCH((dtanh_kernel<float>), g, dim3(256), 0, s, d, y, out32, (float*)outt, n);
+    return VC_OK;
+}
+int vc_embed_action(int ty, const float* a, const float* W, const float* b, const float* ts, float* y32, void* yt,
+                    long M, int H, int K, int T, vc_stream_t s) {
+    dim3 g((unsigned)VC_CEIL_DIV(M * H, 256));
+    if (ty == VC_BF16) VC_LAUNCH((embed_action_kernel<vc_bf16>), g, dim3(256), 0, s, a, W, b, ts, y32, (vc_bf16*)yt, M, H, K, T);
+    else VC_LAUNCH((embed_action_kernel<float>), g, dim3(256), 0, s, a, W, b, ts, y32, (float*)yt, M, H, K, T);
+    return VC_OK;
+}
+int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
+    dim3 g((unsigned)VC_CEIL_DIV(n, 1024));
+    if (ty == VC_BF16) VC_LAUNCH((cast_kernel<vc_bf16>), g, dim3(256), 0, s, x, (vc_bf16*)y, n);
+    else VC_LAUNCH((cast_kernel<float>), g, dim3(256), 0, s, x, (float*)y, n);
+    return VC_OK;
+}
+
+int vc_loss_fwd(LossParams p, vc_stream_t s) {
+    VC_LAUNCH(loss_rows_kernel, dim3((unsigned)VC_CEIL_DIV(p.M * VC_NPARAM, 4)), dim3(256), 0, s, p);
+    VC_LAUNCH(loss_cmd_rows_kernel, dim3((unsigned)VC_CEIL_DIV(p.M, 256)), dim3(256), 0, s, p);
+    VC_LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, s, p);
+    return VC_OK;
+}
+int vc_loss_bwd(LossParams p, vc_stream_t s) {
+    VC_LAUNCH(loss_dlogits_kernel, dim3((unsigned)VC_CEIL_DIV(p.M * 7, 4)), dim3(256), 0, s, p);
+    return VC_OK;
+}
+
+int vc_grad_norm(const float* g, long n, float max_norm, float gscale, float* partial, float* norm_out, vc_stream_t s) {
+    long nb = VC_CEIL_DIV(n, 1024); if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+    VC_LAUNCH(sumsq_stage1_kernel, dim3((unsigned)nb), dim3(256), 0, s, g, n, partial);
+    VC_LAUNCH(sumsq_stage2_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, (int)nb, max_norm, gscale, norm_out);
+    return VC_OK;
+}
+int vc_adam(AdamParams a, vc_stream_t s) {
+    long nb = VC_CEIL_DIV(a.n, 256); if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+    VC_LAUNCH(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, a);
+    return VC_OK;
+}

@@ -1,0 +1,56 @@
+// optim.h — clip_grad_norm_(1.0) + Adam over ONE flat fp32 parameter buffer
+// (reference trainer.py:493-494; torch.optim.Adam defaults, lr from main.py:80).
+//
+// HBM-bound: the norm pass reads 4 B/param, the Adam pass reads p,g,m,v and writes p,m,v (28 B/param)
+// plus the optional bf16 weight shadow (2 B/param).  The clip coefficient stays on the device
+// (norm_out[1]), so there is no host sync between backward and the update.
+#pragma once
+#include "vc_rt.h"
+
+VC_KERNEL __launch_bounds__(256) void sumsq_stage1_kernel(const float* g, long n, float* partial) {
+    VC_SHARED float red[256];
+    float s = 0.f;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (i + j < n) { float v = g[i + j]; s += v * v; }
+    }
+    red[threadIdx.x] = s;
+    vc_sync();
+    for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; vc_sync(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// norm_out[0] = total L2 norm, norm_out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+VC_KERNEL __launch_bounds__(256) void sumsq_stage2_kernel(const float* partial, int nblk, float max_norm, float gscale, float* norm_out) {
+    VC_SHARED double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    vc_sync();
+    for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; vc_sync(); }
+    if (threadIdx.x == 0) {
+        float nrm = (float)sqrt(red[0]) * gscale;      // norm of the averaged gradient (gscale = 1/world)
+        float coef = max_norm / (nrm + 1e-6f);
+        norm_out[0] = nrm; norm_out[1] = coef < 1.0f ? coef : 1.0f;
+    }
+}
+
+struct AdamParams {
+    float* p; const float* g; float* m; float* v; long n;
+    float lr, beta1, beta2, eps, bc1, bc2;      // bc = 1 - beta^t
+    const float* clip;                          // device scalar (norm_out + 1) or null
+    float gscale;                               // extra gradient scale (1/world for DDP sum -> mean)
+    vc_bf16* shadow;                            // optional bf16 copy of p (same flat offsets)
+};
+VC_KERNEL __launch_bounds__(256) void adam_kernel(AdamParams a) {
+    const float c = (a.clip ? a.clip[0] : 1.0f) * a.gscale;
+    const float step = a.lr / a.bc1, rs2 = 1.0f / sqrtf(a.bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
+        const float g = a.g[i] * c;
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        const float p = a.p[i] - step * (m / (sqrtf(v) * rs2 + a.eps));
+        a.m[i] = m; a.v[i] = v; a.p[i] = p;
+        if (a.shadow) a.shadow[i] = vc_f32_to_bf16(p);
+    }
+}

@@ -1,0 +1,160 @@
+// vc_rt.h — thin runtime layer for the VideoCAD hot-path kernels.
+//
+// Product build (hipcc --offload-arch=gfx950): plain HIP, wave64, MFMA builtins.
+// Test build (-DVC_EMU, host C++): the same kernel sources run under tests/emu/emu_rt.cpp, a
+// fiber-per-lane CPU emulator used ONLY by the `-m "not gpu"` tests to check kernel indexing logic
+// (it is test infrastructure, never shipped, never a fallback: the product library has no CPU path).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+
+#ifndef VC_EMU
+// ------------------------------------------------------------------------------------------ HIP
+#include <hip/hip_runtime.h>
+
+#define VC_KERNEL static __global__
+#define VC_DEV __device__ __forceinline__
+#define VC_HD __host__ __device__ __forceinline__
+#define VC_SHARED __shared__
+#define VC_DYN_SHARED(type, name) extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw[]; type* name = reinterpret_cast<type*>(name##_raw)
+
+typedef hipStream_t vc_stream_t;
+
+#define VC_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
+
+static inline int vc_memset_async(void* p, int v, size_t n, vc_stream_t s) { return (int)hipMemsetAsync(p, v, n, s); }
+static inline int vc_memcpy_d2d_async(void* d, const void* s_, size_t n, vc_stream_t s) { return (int)hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
+static inline int vc_last_launch_error() { return (int)hipGetLastError(); }
+
+VC_DEV void vc_sync() { __syncthreads(); }
+// orders a wave's own LDS writes before its later LDS reads (hardware is in-order per wave; this pins the compiler)
+VC_DEV void vc_wave_barrier() { __builtin_amdgcn_wave_barrier(); }
+VC_DEV float vc_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+VC_DEV int vc_shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+VC_DEV float vc_shfl(float v, int src) { return __shfl(v, src, 64); }
+VC_DEV int vc_shfl(int v, int src) { return __shfl(v, src, 64); }
+
+typedef float vc_f32x16 __attribute__((ext_vector_type(16)));
+typedef float vc_f32x4 __attribute__((ext_vector_type(4)));
+typedef short vc_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vc_bf16x8_hw __attribute__((ext_vector_type(8)));
+
+// D(32x32) += A(32x16) * B(16x32), bf16 in / f32 acc.  lane l: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31];
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)   (cdna_hip_programming.md §3)
+VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vc_bf16x8_hw, a), __builtin_bit_cast(vc_bf16x8_hw, b), c, 0, 0, 0);
+}
+// D(32x32) += A(32x2) * B(2x32), exact f32.  lane l: A[i=l&31][k=l>>5], B[k=l>>5][n=l&31]; D as above.
+VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+#else
+// ------------------------------------------------------------------------------------------ EMU
+#include <string.h>
+#include <algorithm>
+namespace vcemu {
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct Ctx { dim3 tid, bid, bdim, gdim; };
+Ctx* cur();                                  // per-fiber context
+void sync_block();
+void sync_wave();
+float shfl_f(float v, int src_lane);         // all 64 lanes of the wave must call
+int shfl_i(int v, int src_lane);
+void* dyn_shared();
+void mfma_32x32x16_bf16(const short* a8, const short* b8, float* c16);   // in-place on c16
+void mfma_32x32x2_f32(float a, float b, float* c16);
+void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem);
+}  // namespace vcemu
+using vcemu::dim3;
+#define threadIdx (vcemu::cur()->tid)
+#define blockIdx (vcemu::cur()->bid)
+#define blockDim (vcemu::cur()->bdim)
+#define gridDim (vcemu::cur()->gdim)
+
+#define VC_KERNEL static
+#define VC_DEV inline
+#define VC_HD inline
+#define VC_SHARED static thread_local
+#define VC_DYN_SHARED(type, name) type* name = reinterpret_cast<type*>(vcemu::dyn_shared())
+#define __launch_bounds__(...)
+#define __restrict__
+
+typedef void* vc_stream_t;
+
+#include <tuple>
+#include <utility>
+namespace vcemu {
+template <typename... KArgs, typename... Args>
+void launch_k(void (*k)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
+    struct Pack { void (*k)(KArgs...); std::tuple<KArgs...> a; };
+    Pack p{k, std::tuple<KArgs...>(static_cast<KArgs>(args)...)};
+    launch([](void* q) { Pack* pp = (Pack*)q; std::apply(pp->k, pp->a); }, &p, grid, block, shmem);
+}
+}  // namespace vcemu
+#define VC_LAUNCH(kernel, grid, block, shmem, stream, ...) vcemu::launch_k(kernel, grid, block, shmem, __VA_ARGS__)
+
+static inline int vc_memset_async(void* p, int v, size_t n, vc_stream_t) { memset(p, v, n); return 0; }
+static inline int vc_memcpy_d2d_async(void* d, const void* s_, size_t n, vc_stream_t) { memmove(d, s_, n); return 0; }
+static inline int vc_last_launch_error() { return 0; }
+
+VC_DEV void vc_sync() { vcemu::sync_block(); }
+VC_DEV void vc_wave_barrier() { vcemu::sync_wave(); }
+VC_DEV float vc_shfl_xor(float v, int mask) { return vcemu::shfl_f(v, (int)((threadIdx.x & 63) ^ mask)); }
+VC_DEV int vc_shfl_xor(int v, int mask) { return vcemu::shfl_i(v, (int)((threadIdx.x & 63) ^ mask)); }
+VC_DEV float vc_shfl(float v, int src) { return vcemu::shfl_f(v, src); }
+VC_DEV int vc_shfl(int v, int src) { return vcemu::shfl_i(v, src); }
+
+struct vc_f32x16 { float v[16]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+struct vc_f32x4 { float v[4]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+struct vc_s16x8 { short v[8]; short& operator[](int i) { return v[i]; } const short& operator[](int i) const { return v[i]; } };
+VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) { vcemu::mfma_32x32x16_bf16(a.v, b.v, c.v); return c; }
+VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) { vcemu::mfma_32x32x2_f32(a, b, c.v); return c; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+#endif
+
+// ------------------------------------------------------------------------------------------ common
+struct vc_bf16 { uint16_t bits; };
+
+VC_HD float vc_bf16_to_f32(vc_bf16 h) {
+    uint32_t u = ((uint32_t)h.bits) << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+VC_HD vc_bf16 vc_f32_to_bf16(float f) {     // round-to-nearest-even; NaN stays NaN
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    vc_bf16 r;
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) { r.bits = (uint16_t)((u >> 16) | 0x40); return r; }
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    r.bits = (uint16_t)(u >> 16);
+    return r;
+}
+
+template <typename T> struct vc_cvt;
+template <> struct vc_cvt<float> {
+    VC_HD static float to_f32(float v) { return v; }
+    VC_HD static float from_f32(float v) { return v; }
+};
+template <> struct vc_cvt<vc_bf16> {
+    VC_HD static float to_f32(vc_bf16 v) { return vc_bf16_to_f32(v); }
+    VC_HD static vc_bf16 from_f32(float v) { return vc_f32_to_bf16(v); }
+};
+template <typename T> VC_HD float vc_ld(const T* p) { return vc_cvt<T>::to_f32(*p); }
+template <typename T> VC_HD void vc_st(T* p, float v) { *p = vc_cvt<T>::from_f32(v); }
+
+VC_DEV float vc_wave_sum(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v += vc_shfl_xor(v, m);
+    return v;
+}
+VC_DEV float vc_wave_max(float v) {
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, vc_shfl_xor(v, m));
+    return v;
+}
+
+struct vc_u32x4 { uint32_t x, y, z, w; };   // 16-byte POD for vector copies
+
+#define VC_CEIL_DIV(a, b) (((a) + (b) - 1) / (b))

@@ -1,0 +1,85 @@
+"""ctypes binding of libvcad_hip.so (include/vcad.h).  There is NO fallback: if the HIP library is missing
+or fails to load, importing the native path raises — the product never computes on the CPU.
+
+Build:  make -C videocad_amd/csrc        (or `python __graft_entry__.py`, which calls build())
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvcad_hip.so")
+
+VCAD_F32, VCAD_BF16 = 0, 1
+NMETRIC = 32
+
+# metric slots (csrc/loss.h)
+MET_CMD_CORRECT, MET_CMD_COUNT, MET_PAR_CORRECT, MET_PAR_COUNT = 0, 5, 10, 16
+MET_CMD_CORRECT_TOPK, MET_CMD_COUNT_TOPK, MET_PAR_CORRECT_TOPK, MET_PAR_COUNT_TOPK, MET_CORRECT, MET_TOTAL = 22, 23, 24, 25, 26, 27
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim",
+        "num_classes", "num_params", "num_params_values", "max_ep_len",
+        "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size", "dtype")]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+PROTOTYPES = {
+    "vcad_last_error": (C.c_char_p, []),
+    "vcad_version": (C.c_char_p, []),
+    "vcad_engine_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
+    "vcad_engine_destroy": (None, [_vp]),
+    "vcad_param_total": (_i64, [_vp]),
+    "vcad_param_count": (_i, [_vp]),
+    "vcad_param_info": (_i, [_vp, _i, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64 * 4), C.POINTER(_i)]),
+    "vcad_bucket_count": (_i, [_vp]),
+    "vcad_bucket_range": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "vcad_bind": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "vcad_sync_shadow": (_i, [_vp, _vp]),
+    "vcad_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "vcad_set_workspace": (_i, [_vp, _vp, _sz]),
+    "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "vcad_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "vcad_backward": (_i, [_vp, _vp, _vp, _vp]),
+    "vcad_backward_stage": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vcad_optimizer_step": (_i, [_vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, _vp]),
+    "vcad_op_layernorm_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
+    "vcad_op_layernorm_bwd": (_i, [_i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "vcad_op_attention_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "vcad_op_attention_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                   _i, _i, _i, _i, _i, _i, _f, _vp]),
+}
+
+
+def declare(lib):
+    """Attach argtypes/restype for every symbol of include/vcad.h (raises AttributeError if one is missing)."""
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fail loudly (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C videocad_amd/csrc` "
+                               "(the VideoCAD MI355X path has no CPU fallback)")
+        _lib = declare(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(lib, rc, what=""):
+    if rc != 0:
+        msg = lib.vcad_last_error()
+        raise RuntimeError(f"libvcad {what} failed (code {rc}): {msg.decode() if msg else ''}")
