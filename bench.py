@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""bench.py — training frames/s of the VideoCAD behaviour-cloning step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = BaseTrainer._process_batch on one synthetic loader-shaped batch already resident in HBM:
+forward -> fused loss -> backward -> (gradient all-reduce over RCCL, overlapped, N > 1) -> clip(1.0) -> Adam.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from videocad_amd.bench_impl import run
+    run(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,11 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
 int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, float eps, float max_norm, int step,
                         float grad_scale, float* norm_out, void* stream);
 
+/* ---- optional HIP-event profiler: per kernel family (8 categories: gemm fwd/dgrad/wgrad, attention, norm, loss,
+ * optimiser, other) elapsed ms, algorithmic FLOPs, algorithmic bytes, launches — measured on the launch stream. */
+void vcad_profile_begin(void);
+int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launches[8]);
+
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,

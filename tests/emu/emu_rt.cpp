@@ -15,8 +15,41 @@
 
 namespace vcemu {
 
+// Fiber switch.  glibc's swapcontext makes a sigprocmask syscall per switch (~0.3 us); on x86-64 a 12-instruction
+// callee-saved-register switch is ~30x cheaper, which is what makes whole-engine runs under the emulator practical.
+#if defined(__x86_64__)
+#define VCEMU_FAST_SWITCH 1
+extern "C" void vcemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl vcemu_switch
+.type vcemu_switch,@function
+vcemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size vcemu_switch,.-vcemu_switch
+)");
+#endif
+
 struct Fiber {
+#ifdef VCEMU_FAST_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t uc;
+#endif
     Ctx ctx;
     bool done = false;
     char* stack = nullptr;
@@ -33,7 +66,11 @@ struct WaveState {
 struct BlockState {
     std::vector<Fiber> fibers;
     std::vector<WaveState> waves;
+#ifdef VCEMU_FAST_SWITCH
+    void* sched_sp = nullptr;
+#else
     ucontext_t sched;
+#endif
     int cur = -1;
     int alive = 0;
     int bar_arrived = 0, bar_gen = 0;
@@ -48,9 +85,16 @@ static const size_t kStack = 256 * 1024;
 Ctx* cur() { return &g_bs->fibers[g_bs->cur].ctx; }
 void* dyn_shared() { return g_bs->dyn.data(); }
 
+static void to_sched(BlockState* bs, Fiber& f) {
+#ifdef VCEMU_FAST_SWITCH
+    vcemu_switch(&f.sp, bs->sched_sp);
+#else
+    swapcontext(&f.uc, &bs->sched);
+#endif
+}
 static void yield_() {
     BlockState* bs = g_bs;
-    swapcontext(&bs->fibers[bs->cur].uc, &bs->sched);
+    to_sched(bs, bs->fibers[bs->cur]);
 }
 
 static void fiber_main() {
@@ -60,7 +104,8 @@ static void fiber_main() {
     f.done = true;
     bs->alive--;
     bs->waves[bs->cur / 64].alive--;
-    swapcontext(&f.uc, &bs->sched);
+    to_sched(bs, f);
+    abort();   // never resumed
 }
 
 void sync_block() {
@@ -160,9 +205,19 @@ void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t
             f.ctx.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
             f.ctx.bid = dim3(bx, by, bz);
             f.ctx.bdim = block; f.ctx.gdim = grid;
+#ifdef VCEMU_FAST_SWITCH
+            {   // initial frame: 6 callee-saved slots + return address (16-byte aligned slot) -> fiber_main
+                uintptr_t top = ((uintptr_t)f.stack + kStack - 64) & ~(uintptr_t)15;
+                void** slot = (void**)top;
+                slot[0] = (void*)fiber_main;
+                for (int r = 1; r <= 6; ++r) slot[-r] = nullptr;
+                f.sp = (void*)(slot - 6);
+            }
+#else
             getcontext(&f.uc);
             f.uc.uc_stack.ss_sp = f.stack; f.uc.uc_stack.ss_size = kStack; f.uc.uc_link = nullptr;
             makecontext(&f.uc, (void (*)())fiber_main, 0);
+#endif
         }
         int idle_rounds = 0;
         while (bs.alive > 0) {
@@ -170,7 +225,11 @@ void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t
             for (int t = 0; t < nthreads; ++t) {
                 if (bs.fibers[t].done) continue;
                 bs.cur = t;
+#ifdef VCEMU_FAST_SWITCH
+                vcemu_switch(&bs.sched_sp, bs.fibers[t].sp);
+#else
                 swapcontext(&bs.sched, &bs.fibers[t].uc);
+#endif
             }
             (void)before;
             if (++idle_rounds > 100000000) { fprintf(stderr, "emu: deadlock?\n"); abort(); }

@@ -1,0 +1,63 @@
+"""Per-kernel parity on a real MI355X through the C ABI (libvcad_hip.so) against plain PyTorch fp32/fp64 math."""
+import pytest
+import torch
+
+import oputil as U
+from videocad_amd import lib as L
+
+pytestmark = pytest.mark.gpu
+F32, BF16 = torch.float32, torch.bfloat16
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return L.load()
+
+
+@pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_f32_layouts(hip, tra, trb):
+    U.check_gemm(hip, DEV, 300, 200, 260, F32, tra=tra, trb=trb, pad=4, bias=True, residual=True, splitk=False)
+    U.check_gemm(hip, DEV, 77, 41, 53, F32, tra=tra, trb=trb, pad=3, bias=True, act=1, splitk=False)
+
+
+def test_gemm_f32_big_and_splitk(hip):
+    U.check_gemm(hip, DEV, 2048, 512, 1024, F32, bias=True, act=1)
+    U.check_gemm(hip, DEV, 512, 384, 8192, F32, tra=1, trb=1)              # wgrad-shaped: split-K
+    U.check_gemm(hip, DEV, 16, 5, 1024, F32, bias=True)                    # cmd head
+
+
+@pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("sa,to", [(BF16, BF16), (BF16, F32), (F32, BF16), (F32, F32)])
+def test_gemm_bf16(hip, tra, trb, sa, to):
+    if tra == 1 and to == BF16:
+        pytest.skip("wgrad always writes fp32")
+    U.check_gemm(hip, DEV, 520, 264, 392, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=8, bias=True, act=2, splitk=False)
+    U.check_gemm(hip, DEV, 33, 7, 100, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=1, splitk=False)
+
+
+def test_gemm_bf16_big(hip):
+    U.check_gemm(hip, DEV, 5000, 3072, 512, BF16, to=BF16)                 # ViT QKV shape
+    U.check_gemm(hip, DEV, 3072, 512, 20000, BF16, sa=BF16, to=F32, tra=1, trb=1)   # ViT QKV wgrad, split-K
+    U.check_gemm(hip, DEV, 4096, 512, 1024, BF16, sa=F32, to=F32, trb=1, residual=True)
+
+
+@pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16), (1024, BF16)])
+def test_layernorm(hip, C_, dt):
+    U.check_layernorm(hip, DEV, 5003, C_, dt)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_vit(hip, dt):
+    U.check_attention(hip, DEV, 6, 16, 50, 64, window=50, causal=0, dt=dt)
+
+
+@pytest.mark.parametrize("T", [8, 64, 186])
+def test_attention_decoder_causal(hip, T):
+    U.check_attention(hip, DEV, 2, 4, T, 256, window=T, causal=1, dt=F32)
+
+
+@pytest.mark.parametrize("window", [1, 5, 10])
+def test_attention_band(hip, window):
+    U.check_attention(hip, DEV, 2, 4, 64, 256, window=window, causal=1, dt=F32)
+    U.check_attention(hip, DEV, 2, 4, 186, 256, window=window, causal=1, dt=BF16)

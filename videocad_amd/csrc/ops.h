@@ -11,6 +11,17 @@ enum { VC_F32 = 0, VC_BF16 = 1 };
 enum { VC_OK = 0, VC_ERR_ARG = 1, VC_ERR_UNSUPPORTED = 2, VC_ERR_LAUNCH = 3, VC_ERR_WORKSPACE = 4 };
 
 void vc_set_error(const char* fmt, ...);
+
+// ---- optional HIP-event profiler (off by default; bench.py turns it on for ONE extra step after the timed region).
+// Each launcher opens a scope: events are recorded on the launch stream around the kernel(s); vcad_profile_end sums
+// elapsed time, algorithmic FLOPs and algorithmic bytes per category.
+enum { VC_CAT_GEMM_FWD = 0, VC_CAT_GEMM_DGRAD = 1, VC_CAT_GEMM_WGRAD = 2, VC_CAT_ATTN = 3, VC_CAT_NORM = 4, VC_CAT_LOSS = 5,
+       VC_CAT_OPTIM = 6, VC_CAT_OTHER = 7, VC_NCAT = 8 };
+struct ProfScope {
+    void* rec;
+    ProfScope(int cat, double flops, double bytes, vc_stream_t s);
+    ~ProfScope();
+};
 const char* vc_get_error();
 
 struct GemmCall {

@@ -33,11 +33,16 @@ static int attn_bwd_t(int D, AttnParams p, vc_stream_t s) {
     else { vc_set_error("attn_bwd_kv: D=%d queries=%d unsupported", D, max_queries(p)); return VC_ERR_UNSUPPORTED; }
     return VC_OK;
 }
+static double attn_flops(const AttnParams& p, int D) {      // 2 GEMM-like contractions over the visible keys
+    return 4.0 * p.B * p.H * (double)p.Tq * max_keys(p) * D;
+}
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
+    ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), 0, s);
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
 }
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
+    ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), 0, s);
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);
 }

@@ -8,6 +8,38 @@ static thread_local char g_err[512] = "";
 void vc_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap); }
 const char* vc_get_error() { return g_err; }
 
+// ---------------------------------------------------------------------------------------------- profiler
+#ifndef VC_EMU
+#include <vector>
+namespace { struct PRec { hipEvent_t a, b; hipStream_t s; int cat; double flops, bytes; }; bool g_on = false; std::vector<PRec*> g_recs; }
+ProfScope::ProfScope(int cat, double flops, double bytes, vc_stream_t s) : rec(nullptr) {
+    if (!g_on) return;
+    PRec* r = new PRec(); r->cat = cat; r->flops = flops; r->bytes = bytes; r->s = s;
+    hipEventCreate(&r->a); hipEventCreate(&r->b); hipEventRecord(r->a, s);
+    rec = r;
+}
+ProfScope::~ProfScope() { if (rec) { PRec* r = (PRec*)rec; hipEventRecord(r->b, r->s); g_recs.push_back(r); } }
+extern "C" void vcad_profile_begin(void) { g_on = true; }
+// out arrays of VC_NCAT: milliseconds, flops, bytes, launches.  Synchronises the recorded events.
+extern "C" int vcad_profile_end(double* ms, double* flops, double* bytes, int* launches) {
+    g_on = false;
+    for (int i = 0; i < VC_NCAT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    for (PRec* r : g_recs) {
+        hipEventSynchronize(r->b);
+        float t = 0.f; hipEventElapsedTime(&t, r->a, r->b);
+        ms[r->cat] += t; flops[r->cat] += r->flops; bytes[r->cat] += r->bytes; launches[r->cat]++;
+        hipEventDestroy(r->a); hipEventDestroy(r->b); delete r;
+    }
+    g_recs.clear();
+    return 0;
+}
+#else
+ProfScope::ProfScope(int, double, double, vc_stream_t) : rec(nullptr) {}
+ProfScope::~ProfScope() {}
+extern "C" void vcad_profile_begin(void) {}
+extern "C" int vcad_profile_end(double*, double*, double*, int*) { return 0; }
+#endif
+
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
 static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
     constexpr size_t lds = gemm_lds_bytes<CT>();
@@ -20,6 +52,8 @@ static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
         attr_set = true;
     }
 #endif
+    ProfScope ps(TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD), 2.0 * c.p.M * c.p.N * c.p.K,
+                 (double)c.p.M * c.p.K * sizeof(SA) + (double)c.p.N * c.p.K * sizeof(SB) + (double)c.p.M * c.p.N * sizeof(TO), s);
     dim3 grid(VC_CEIL_DIV(c.p.N, GEMM_BN), VC_CEIL_DIV(c.p.M, GEMM_BM), nsplit);
     VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB>), grid, dim3(GEMM_THREADS), lds, s, c.p);
     if (nsplit > 1) {

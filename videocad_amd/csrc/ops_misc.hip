@@ -18,6 +18,7 @@ static int ln_fwd_m(int C, int mode, LnFwdParams p, vc_stream_t s) {
 }
 int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s) {
     if (p.rows <= 0) return VC_OK;
+    ProfScope ps(VC_CAT_NORM, 0, (double)p.rows * C * ((tx == VC_BF16 ? 2 : 4) + (p.y32 ? 4 : 0) + (p.yt ? (ty == VC_BF16 ? 2 : 4) : 0)), s);
     if (tx == VC_F32 && ty == VC_F32) return ln_fwd_m<float, float>(C, mode, p, s);
     if (tx == VC_F32 && ty == VC_BF16) return ln_fwd_m<float, vc_bf16>(C, mode, p, s);
     if (tx == VC_BF16 && ty == VC_BF16) return ln_fwd_m<vc_bf16, vc_bf16>(C, mode, p, s);
@@ -45,6 +46,7 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     if (p.rows <= 0) return VC_OK;
     const unsigned nblk = (unsigned)vc_ln_bwd_blocks(p.rows);
     p.partial = partial_ws;
+    ProfScope ps(VC_CAT_NORM, 0, (double)p.rows * C * ((td == VC_BF16 ? 2 : 4) + 4 + (p.add_in ? 4 : 0) + (p.dx32 ? 4 : 0)), s);
     int rc;
     if (td == VC_F32 && tx == VC_F32 && ty == VC_F32) rc = ln_bwd_m<float, float, float>(C, mode, p, nblk, s);
     else if (td == VC_BF16 && tx == VC_F32 && ty == VC_BF16) rc = ln_bwd_m<vc_bf16, float, vc_bf16>(C, mode, p, nblk, s);
@@ -67,6 +69,7 @@ int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, i
     p.x = x; p.ld = ld; p.rows = rows; p.cols = cols; p.batch_stride_x = bstride_x;
     p.out = out; p.batch_stride_out = bstride_out; p.accumulate = accumulate; p.partial = ws;
     const long nchunk = vc_colsum_chunks(rows);
+    ProfScope ps(VC_CAT_OTHER, 0, (double)batch * rows * cols * (tx == VC_BF16 ? 2 : 4), s);
     p.rows_per_block = (int)VC_CEIL_DIV(rows, nchunk);
     dim3 g1(VC_CEIL_DIV(cols, 256), (unsigned)nchunk, batch);
     if (tx == VC_F32) VC_LAUNCH((colsum_stage1_kernel<float>), g1, dim3(256), 0, s, p);
@@ -96,23 +99,27 @@ int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
 }
 
 int vc_loss_fwd(LossParams p, vc_stream_t s) {
+    ProfScope ps(VC_CAT_LOSS, 0, (double)p.M * (VC_NPARAM * VC_NVAL + VC_NCMD) * 4, s);
     VC_LAUNCH(loss_rows_kernel, dim3((unsigned)VC_CEIL_DIV(p.M * VC_NPARAM, 4)), dim3(256), 0, s, p);
     VC_LAUNCH(loss_cmd_rows_kernel, dim3((unsigned)VC_CEIL_DIV(p.M, 256)), dim3(256), 0, s, p);
     VC_LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, s, p);
     return VC_OK;
 }
 int vc_loss_bwd(LossParams p, vc_stream_t s) {
+    ProfScope ps(VC_CAT_LOSS, 0, (double)p.M * (VC_NPARAM * VC_NVAL + VC_NCMD) * 8, s);
     VC_LAUNCH(loss_dlogits_kernel, dim3((unsigned)VC_CEIL_DIV(p.M * 7, 4)), dim3(256), 0, s, p);
     return VC_OK;
 }
 
 int vc_grad_norm(const float* g, long n, float max_norm, float gscale, float* partial, float* norm_out, vc_stream_t s) {
+    ProfScope ps(VC_CAT_OPTIM, 0, (double)n * 4, s);
     long nb = VC_CEIL_DIV(n, 1024); if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
     VC_LAUNCH(sumsq_stage1_kernel, dim3((unsigned)nb), dim3(256), 0, s, g, n, partial);
     VC_LAUNCH(sumsq_stage2_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, (int)nb, max_norm, gscale, norm_out);
     return VC_OK;
 }
 int vc_adam(AdamParams a, vc_stream_t s) {
+    ProfScope ps(VC_CAT_OPTIM, 0, (double)a.n * (28 + (a.shadow ? 2 : 0)), s);
     long nb = VC_CEIL_DIV(a.n, 256); if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
     VC_LAUNCH(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, a);
     return VC_OK;

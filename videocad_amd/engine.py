@@ -1,0 +1,137 @@
+"""Thin Python handle on a `vcad_engine` (include/vcad.h): owns the flat fp32 parameter / gradient / Adam buffers
+and the activation workspace as torch tensors (PyTorch = device memory + streams only) and forwards every call
+to the C ABI on torch's current HIP stream."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import lib as L
+
+VIT_DEFAULTS = dict(vit_dim=512, vit_depth=6, vit_heads=16, vit_dim_head=64, vit_mlp=512, image_size=224, patch_size=32)
+# ^ the ViT(...) call at reference model/trajectory_model.py:54-65
+
+
+def make_config(hidden_size, nhead=4, num_decoder_layers=8, dim_feedforward=512, window_size=1, act_dim=7, num_classes=5,
+                num_params=6, num_params_values=1000, max_ep_len=1000, dtype=L.VCAD_F32, **vit) -> L.Config:
+    v = dict(VIT_DEFAULTS); v.update({k: vit[k] for k in vit if k in VIT_DEFAULTS})
+    return L.Config(hidden_size=hidden_size, nhead=nhead, num_decoder_layers=num_decoder_layers, dim_feedforward=dim_feedforward,
+                    window_size=window_size, act_dim=act_dim, num_classes=num_classes, num_params=num_params,
+                    num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dtype, **v)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class NativeEngine:
+    def __init__(self, cfg: L.Config, device, lib=None):
+        self.lib = lib if lib is not None else L.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        L.check(self.lib, self.lib.vcad_engine_create(C.byref(cfg), C.byref(h)), "engine_create")
+        self.h = h
+        self.total = int(self.lib.vcad_param_total(h))
+        self.table: Dict[str, tuple] = {}
+        name = C.create_string_buffer(256)
+        for i in range(self.lib.vcad_param_count(h)):
+            off, numel, nd = C.c_int64(), C.c_int64(), C.c_int()
+            shape = (C.c_int64 * 4)()
+            L.check(self.lib, self.lib.vcad_param_info(h, i, name, 256, C.byref(off), C.byref(numel), C.byref(shape), C.byref(nd)), "param_info")
+            self.table[name.value.decode()] = (off.value, numel.value, tuple(shape[k] for k in range(nd.value)))
+        self.buckets = []
+        for b in range(self.lib.vcad_bucket_count(h)):
+            lo, hi = C.c_int64(), C.c_int64()
+            L.check(self.lib, self.lib.vcad_bucket_range(h, b, C.byref(lo), C.byref(hi)), "bucket_range")
+            self.buckets.append((lo.value, hi.value))
+        self.params = self.grads = self.m = self.v = self.shadow = None
+        self.ws = None
+        self.step_count = 0
+        self.allocate(self.device)
+
+    # ------------------------------------------------------------------ buffers
+    def allocate(self, device, params: Optional[torch.Tensor] = None):
+        self.device = torch.device(device)
+        z = lambda dt=torch.float32: torch.zeros(self.total, dtype=dt, device=self.device)
+        self.params = params.to(self.device) if params is not None else z()
+        self.grads, self.m, self.v = z(), z(), z()
+        self.shadow = z(torch.bfloat16) if self.cfg.dtype == L.VCAD_BF16 else None
+        self.ws = None
+        self._bind()
+
+    def _bind(self):
+        L.check(self.lib, self.lib.vcad_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(self.shadow)), "bind")
+        if self.ws is not None:
+            L.check(self.lib, self.lib.vcad_set_workspace(self.h, _ptr(self.ws), self.ws.numel()), "set_workspace")
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.device.type == "cuda" else None
+
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, numel, shape = self.table[name]
+        return (self.params if buf is None else buf)[off: off + numel].view(shape)
+
+    def sync_shadow(self):
+        L.check(self.lib, self.lib.vcad_sync_shadow(self.h, self.stream()), "sync_shadow")
+
+    def ensure_workspace(self, B: int, T: int):
+        need = int(self.lib.vcad_workspace_bytes(self.h, B, T))
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = None
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            L.check(self.lib, self.lib.vcad_set_workspace(self.h, _ptr(self.ws), need), "set_workspace")
+
+    # ------------------------------------------------------------------ hot path
+    def forward(self, frames: torch.Tensor, actions_norm: torch.Tensor, cad: torch.Tensor):
+        """frames [B,T,1,S,S] fp32 (any batch stride, frames contiguous within a clip), actions_norm [B,T,7], cad [B,1,S,S]."""
+        B, T = int(actions_norm.shape[0]), int(actions_norm.shape[1])
+        S = self.cfg.image_size
+        assert frames.dtype == torch.float32 and frames.shape[1] == T and tuple(frames.shape[2:]) == (1, S, S)
+        if frames.stride()[1:] != (S * S, S * S, S, 1):
+            frames = frames.contiguous()
+        fb = frames.stride(0) if B > 1 else T * S * S
+        actions_norm = actions_norm.contiguous().float(); cad = cad.contiguous().float()
+        self.ensure_workspace(B, T)
+        cmds = torch.empty(B, T, self.cfg.num_classes, device=self.device)
+        pars = torch.empty(B, T, self.cfg.num_params, self.cfg.num_params_values, device=self.device)
+        self._keep = (frames, actions_norm, cad)          # backward re-reads the inputs (patch-LN grads, embed_action wgrad)
+        L.check(self.lib, self.lib.vcad_forward(self.h, _ptr(frames), fb, _ptr(actions_norm), _ptr(cad), B, T, _ptr(cmds), _ptr(pars),
+                                                self.stream()), "forward")
+        return cmds, pars
+
+    def loss(self, cmds, pars, targets, use_mse=True, class_weights: Optional[torch.Tensor] = None):
+        B, T = cmds.shape[0], cmds.shape[1]
+        targets = targets.reshape(B * T, 7).contiguous().float()
+        out = torch.empty(8, device=self.device); met = torch.empty(L.NMETRIC, dtype=torch.int32, device=self.device)
+        L.check(self.lib, self.lib.vcad_loss(self.h, _ptr(cmds), _ptr(pars), _ptr(targets), B, T, int(use_mse), _ptr(class_weights),
+                                             _ptr(out), _ptr(met), self.stream()), "loss")
+        self._keep_t = targets
+        return out, met
+
+    def backward(self, dcmds=None, dpars=None, stage: Optional[int] = None):
+        if dcmds is not None:
+            dcmds = dcmds.contiguous().float(); dpars = dpars.contiguous().float()
+        if stage is None:
+            L.check(self.lib, self.lib.vcad_backward(self.h, _ptr(dcmds), _ptr(dpars), self.stream()), "backward")
+        else:
+            L.check(self.lib, self.lib.vcad_backward_stage(self.h, stage, _ptr(dcmds), _ptr(dpars), self.stream()), "backward_stage")
+
+    def optimizer_step(self, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0):
+        self.step_count += 1
+        if self.ws is None:
+            self.ensure_workspace(1, 1)
+        norm = torch.empty(2, device=self.device)
+        L.check(self.lib, self.lib.vcad_optimizer_step(self.h, lr, betas[0], betas[1], eps, max_norm, self.step_count, grad_scale,
+                                                       _ptr(norm), self.stream()), "optimizer_step")
+        return norm
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.vcad_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

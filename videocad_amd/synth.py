@@ -130,3 +130,57 @@ def make_batch(B: int, T: int, seed: int, lengths=None, img: int = 224) -> dict:
         "timesteps": np.tile(np.arange(S, dtype=np.int64), (B, 1)),
         "multiview_images": None,
     }
+
+
+# ----------------------------------------------------------------------------------------
+# torch twins (bit-identical to the numpy generators; run on any device, used on the GPU box)
+# ----------------------------------------------------------------------------------------
+
+def _s64(x: int) -> int:
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _lsr(x, s: int):
+    import torch
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def hash_u64_torch(key: int, n: int, device, offset: int = 0):
+    """splitmix64 in wrapping int64 arithmetic (logical shifts emulated by masking)."""
+    import torch
+    idx = torch.arange(offset, offset + n, dtype=torch.int64, device=device)
+    x = idx * _s64(0xD1342543DE82EF95) + _s64(key)
+    x = x + _s64(0x9E3779B97F4A7C15)
+    z = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def hash_uniform_torch(key: int, n: int, device, offset: int = 0):
+    import torch
+    u = _lsr(hash_u64_torch(key, n, device, offset), 40)
+    return u.to(torch.float32) * (2.0 ** -23) - 1.0
+
+
+def make_param_torch(name: str, shape, device, seed: int = 0):
+    import torch
+    n = int(np.prod(shape))
+    scale, shift = init_scale(name, shape)
+    u = hash_uniform_torch(fnv1a64(name) ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF), n, device)
+    return (torch.tensor(shift, dtype=torch.float32, device=device) + torch.tensor(scale, dtype=torch.float32, device=device) * u).reshape(tuple(shape))
+
+
+def make_batch_torch(B: int, T: int, seed: int, device, lengths=None, img: int = 224) -> dict:
+    """Same tensors as make_batch, generated on `device` (actions are tiny and come from the numpy path)."""
+    import torch
+    S = T + 1
+    kf = fnv1a64("frames") ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
+    kc = fnv1a64("cad_image") ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
+    frames = hash_uniform_torch(kf, B * S * img * img, device).reshape(B, S, 1, img, img)
+    if lengths is not None:
+        for b, L in enumerate(lengths):
+            frames[b, L:] = -1.0
+    cad = hash_uniform_torch(kc, B * img * img, device).reshape(B, 1, img, img)
+    return {"frames": frames, "actions": torch.from_numpy(make_actions(B, S, seed, lengths)).to(device), "cad_image": cad,
+            "timesteps": torch.arange(S, device=device).repeat(B, 1), "multiview_images": None}
