@@ -43,16 +43,16 @@ def relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, tra=0, trb=0, bias=False, act=0, residual=False, seed=0,
+def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0, bias=False, act=0, residual=False, seed=0,
                pad=0, tol=None, splitk=True):
     """C = act(opA @ opB^T + bias) + residual ; operands stored with `pad` extra leading-dimension elements."""
     sa = ct if sa is None else sa
     to = ct if to is None else to
-    sb = ct
+    sb = ct if sb is None else sb
     A_log = rnd((M, K), "cpu", seed=seed + 1)
     B_log = rnd((N, K), "cpu", seed=seed + 2)
     A_q = A_log.to(sa).float() if ct == torch.float32 else A_log.to(torch.bfloat16).float()
-    B_q = B_log.to(sb).float()
+    B_q = B_log.to(sb).float() if ct == torch.float32 else B_log.to(torch.bfloat16).float()
 
     def store(x_log, tr, dt):
         x = x_log.t().contiguous() if tr else x_log.contiguous()

@@ -36,6 +36,10 @@ def test_gemm_bf16(emu, tra, trb, sa, to):
     U.check_gemm(emu, "cpu", 72, 48, 136, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=8, bias=True, act=2, splitk=False)
 
 
+def test_gemm_bf16_wgrad_f32_b(emu):
+    U.check_gemm(emu, "cpu", 40, 24, 70, BF16, sa=BF16, sb=F32, to=F32, tra=1, trb=1, pad=4, splitk=False)
+
+
 def test_gemm_bf16_unaligned_tail(emu):
     U.check_gemm(emu, "cpu", 33, 7, 100, BF16, sa=F32, to=F32, tra=1, trb=1, pad=1, splitk=False)
 

@@ -36,6 +36,12 @@ def test_gemm_bf16(hip, tra, trb, sa, to):
     U.check_gemm(hip, DEV, 33, 7, 100, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=1, splitk=False)
 
 
+def test_gemm_bf16_wgrad_f32_sources(hip):
+    for sa in (BF16, F32):
+        for sb in (BF16, F32):
+            U.check_gemm(hip, DEV, 260, 136, 1000, BF16, sa=sa, sb=sb, to=F32, tra=1, trb=1, pad=4)
+
+
 def test_gemm_bf16_big(hip):
     U.check_gemm(hip, DEV, 5000, 3072, 512, BF16, to=BF16)                 # ViT QKV shape
     U.check_gemm(hip, DEV, 3072, 512, 20000, BF16, sa=BF16, to=F32, tra=1, trb=1)   # ViT QKV wgrad, split-K

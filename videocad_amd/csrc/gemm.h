@@ -43,26 +43,73 @@ VC_DEV float vc_dgelu(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
+VC_DEV float vc_apply_act(float v, int act) {
+    if (act == VC_ACT_GELU) return vc_gelu(v);
+    if (act == VC_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == VC_ACT_TANH) return tanhf(v);
+    return v;
+}
+VC_DEV float vc_apply_dact(float v, float s, int kind) {
+    if (kind == VC_ACT_GELU) return v * vc_dgelu(s);
+    if (kind == VC_ACT_RELU) return (s > 0.0f) ? v : 0.0f;
+    if (kind == VC_ACT_TANH) return v * (1.0f - s * s);
+    return v;
+}
+
+// single-element epilogue (split-K reducer and edge tiles)
 template <typename TO>
-VC_DEV void gemm_epilogue_store(const GemmParams& p, int m, int n, float acc) {
-    float v = p.alpha * acc;
-    if (p.bias) v += p.bias[n];
+VC_DEV void gemm_epilogue_store(const GemmParams& p, int m, int n, float acc, float bias_n) {
+    float v = p.alpha * acc + bias_n;
     if (p.rowadd) {
         int r = p.rowadd_mod ? (m % p.rowadd_div) : (m / p.rowadd_div);
         v += p.rowadd[(long)r * p.ld_rowadd + n];
     }
     if (p.aux) vc_st(((TO*)p.aux) + (long)m * p.ldaux + n, v);
-    if (p.act == VC_ACT_GELU) v = vc_gelu(v);
-    else if (p.act == VC_ACT_RELU) v = fmaxf(v, 0.0f);
-    else if (p.act == VC_ACT_TANH) v = tanhf(v);
-    if (p.dact_src) {
-        float s = vc_ld(((const TO*)p.dact_src) + (long)m * p.lddact + n);
-        if (p.dact_kind == VC_ACT_GELU) v *= vc_dgelu(s);
-        else if (p.dact_kind == VC_ACT_RELU) v = (s > 0.0f) ? v : 0.0f;
-        else if (p.dact_kind == VC_ACT_TANH) v *= (1.0f - s * s);
-    }
+    v = vc_apply_act(v, p.act);
+    if (p.dact_src) v = vc_apply_dact(v, vc_ld(((const TO*)p.dact_src) + (long)m * p.lddact + n), p.dact_kind);
     if (p.residual) v += p.residual[(long)m * p.ldr + n];
     vc_st(((TO*)p.C) + (long)m * p.ldc + n, v);
+}
+
+// one 32x32 accumulator tile of an INTERIOR block: every optional input is loaded for all 16 rows first (loads in
+// flight together), then the math, then the 16 stores.  mrow(r) = mbase + (r&3) + 8*(r>>2).
+template <typename TO>
+VC_DEV void gemm_epilogue_tile(const GemmParams& p, int mbase, int n, const vc_f32x16& acc, float bias_n) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = p.alpha * acc[r] + bias_n;
+    if (p.rowadd) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            const int rr = p.rowadd_mod ? (m % p.rowadd_div) : (m / p.rowadd_div);
+            v[r] += p.rowadd[(long)rr * p.ld_rowadd + n];
+        }
+    }
+    if (p.aux) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vc_st(((TO*)p.aux) + (long)(mbase + (r & 3) + 8 * (r >> 2)) * p.ldaux + n, v[r]);
+    }
+    if (p.act) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = vc_apply_act(v[r], p.act);
+    }
+    if (p.dact_src) {
+        float sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = vc_ld(((const TO*)p.dact_src) + (long)(mbase + (r & 3) + 8 * (r >> 2)) * p.lddact + n);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = vc_apply_dact(v[r], sv[r], p.dact_kind);
+    }
+    if (p.residual) {
+        float q[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[r] = p.residual[(long)(mbase + (r & 3) + 8 * (r >> 2)) * p.ldr + n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += q[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vc_st(((TO*)p.C) + (long)(mbase + (r & 3) + 8 * (r >> 2)) * p.ldc + n, v[r]);
 }
 
 template <typename CT> struct GemmCfg;
@@ -74,33 +121,28 @@ template <> struct GemmCfg<vc_bf16> {
 };
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
 
-template <typename CT> constexpr size_t gemm_lds_bytes() {
-    return 2ul * (GEMM_BM + GEMM_BN) * GemmCfg<CT>::STRIDE * sizeof(CT);
+// LDS image of one operand tile:
+//   direct   (k contiguous in memory)       : [128 rows][BK + pad]           fragment = one ds_read_b128
+//   bf16 TR  (row dim contiguous in memory) : [BK k-rows][128 + 32 pad]      natural layout, coalesced ds_write_b128;
+//            fragment = two ds_read_b64_tr_b16 (hardware transpose); the 64-byte row pad puts the 4 k-rows a
+//            transpose-read touches on disjoint banks
+//   f32  TR  : transposed on the way into LDS (scalar ds_write_b32), same image as direct
+constexpr int GEMM_TSTRIDE = 160;
+template <typename CT, bool TR> constexpr int gemm_tile_elems() {
+    return (sizeof(CT) == 2 && TR) ? GemmCfg<CT>::BK * GEMM_TSTRIDE : 128 * GemmCfg<CT>::STRIDE;
+}
+template <typename CT, bool TRA, bool TRB> constexpr size_t gemm_lds_bytes() {
+    return 2ul * (gemm_tile_elems<CT, TRA>() + gemm_tile_elems<CT, TRB>()) * sizeof(CT);
 }
 
-// one staged chunk = CHUNK elements of CT = 16 bytes
-template <typename CT> struct GemmChunk { CT e[GemmCfg<CT>::CHUNK]; };
-
+// One staged chunk = CHUNK elements of CT = 16 bytes, kept as a raw 16-byte register quad (never repacked
+// element-wise: that would consume the load results immediately and serialise the global loads with the MFMAs).
 template <typename CT, typename ST>
-VC_DEV GemmChunk<CT> gemm_load_chunk(const ST* p, int nvalid, int vec_ok) {
-    constexpr int CH = GemmCfg<CT>::CHUNK;
-    GemmChunk<CT> c;
-    if (nvalid >= CH && vec_ok) {
-        if constexpr (sizeof(ST) == sizeof(CT)) {
-            *reinterpret_cast<vc_u32x4*>(&c) = *reinterpret_cast<const vc_u32x4*>(p);
-        } else {   // ST=float, CT=bf16: 8 floats -> 8 bf16
-            vc_u32x4 lo = reinterpret_cast<const vc_u32x4*>(p)[0];
-            vc_u32x4 hi = reinterpret_cast<const vc_u32x4*>(p)[1];
-            float f[8];
-            __builtin_memcpy(f, &lo, 16); __builtin_memcpy(f + 4, &hi, 16);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) c.e[i] = vc_cvt<CT>::from_f32(f[i]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) c.e[i] = vc_cvt<CT>::from_f32(i < nvalid ? vc_cvt<ST>::to_f32(p[i]) : 0.0f);
-    }
-    return c;
+VC_DEV vc_u32x4 gemm_pack_chunk(const float (&f)[GemmCfg<CT>::CHUNK]) {
+    vc_u32x4 r;
+    if constexpr (sizeof(CT) == 2) { r.x = vc_pack_bf16x2(f[0], f[1]); r.y = vc_pack_bf16x2(f[2], f[3]); r.z = vc_pack_bf16x2(f[4], f[5]); r.w = vc_pack_bf16x2(f[6], f[7]); }
+    else { r.x = vc_f32_bits(f[0]); r.y = vc_f32_bits(f[1]); r.z = vc_f32_bits(f[2]); r.w = vc_f32_bits(f[3]); }
+    return r;
 }
 
 // Stage one 128 x BK operand tile.  LDS image is always [row][k] (k contiguous, padded stride).
@@ -108,55 +150,98 @@ template <typename CT, typename ST, bool TR>
 struct GemmStager {
     static constexpr int BK = GemmCfg<CT>::BK, CH = GemmCfg<CT>::CHUNK, STRIDE = GemmCfg<CT>::STRIDE;
     static constexpr int NCH = 128 * BK / CH / GEMM_THREADS;      // chunks per thread (= 4)
-    GemmChunk<CT> regs[NCH];
+    vc_u32x4 regs[NCH];
 
-    // R = extent of the row dimension (M or N), Kend = end of this block's k-range
-    VC_DEV void load(const ST* base, long ld, int r0, int k0, int R, int Kend, int vec_ok, int tid) {
+    // interior tile + 16-byte-aligned operand: straight-line vector loads (no per-chunk branch, so all loads of a
+    // K-tile are in flight together; a divergent bounds test per chunk makes hipcc drain vmcnt after every load)
+    VC_DEV void load_fast(const ST* base, long ld, int r0, int k0, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + GEMM_THREADS * i;
+            const ST* p;
+            if constexpr (!TR) p = base + (long)(r0 + c / (BK / CH)) * ld + (k0 + (c % (BK / CH)) * CH);
+            else p = base + (long)(k0 + c / (128 / CH)) * ld + (r0 + (c % (128 / CH)) * CH);
+            if constexpr (sizeof(ST) == sizeof(CT)) {
+                regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
+            } else {   // fp32 source feeding bf16 MFMA
+                const vc_u32x4 lo = reinterpret_cast<const vc_u32x4*>(p)[0], hi = reinterpret_cast<const vc_u32x4*>(p)[1];
+                regs[i].x = vc_pack_bf16x2(vc_bits_f32(lo.x), vc_bits_f32(lo.y)); regs[i].y = vc_pack_bf16x2(vc_bits_f32(lo.z), vc_bits_f32(lo.w));
+                regs[i].z = vc_pack_bf16x2(vc_bits_f32(hi.x), vc_bits_f32(hi.y)); regs[i].w = vc_pack_bf16x2(vc_bits_f32(hi.z), vc_bits_f32(hi.w));
+            }
+        }
+    }
+    // edge tiles / unaligned operands: per-element bounds-checked loads, zero fill.
+    // R = extent of the row dimension (M or N), Kend = end of this block's k-range
+    VC_DEV void load(const ST* base, long ld, int r0, int k0, int R, int Kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + GEMM_THREADS * i;
+            int nv; const ST* p;
             if constexpr (!TR) {
                 int row = c / (BK / CH), kc = (c % (BK / CH)) * CH;
-                int nv = (r0 + row < R) ? (Kend - (k0 + kc)) : 0;
-                nv = nv < 0 ? 0 : (nv > CH ? CH : nv);
-                const ST* p = base + (long)(r0 + row) * ld + (k0 + kc);
-                regs[i] = gemm_load_chunk<CT, ST>(nv > 0 ? p : base, nv, vec_ok);
+                nv = (r0 + row < R) ? (Kend - (k0 + kc)) : 0;
+                p = base + (long)(r0 + row) * ld + (k0 + kc);
             } else {
                 int k = c / (128 / CH), rc = (c % (128 / CH)) * CH;
-                int nv = (k0 + k < Kend) ? (R - (r0 + rc)) : 0;
-                nv = nv < 0 ? 0 : (nv > CH ? CH : nv);
-                const ST* p = base + (long)(k0 + k) * ld + (r0 + rc);
-                regs[i] = gemm_load_chunk<CT, ST>(nv > 0 ? p : base, nv, vec_ok);
+                nv = (k0 + k < Kend) ? (R - (r0 + rc)) : 0;
+                p = base + (long)(k0 + k) * ld + (r0 + rc);
             }
+            float f[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) f[j] = (j < nv) ? vc_cvt<ST>::to_f32(p[j]) : 0.0f;
+            regs[i] = gemm_pack_chunk<CT, ST>(f);
         }
     }
     VC_DEV void store(CT* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + GEMM_THREADS * i;
+            const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
             if constexpr (!TR) {
                 int row = c / (BK / CH), kc = (c % (BK / CH)) * CH;
                 if constexpr (sizeof(CT) == 2) {
-                    *reinterpret_cast<vc_u32x4*>(lds + row * STRIDE + kc) = *reinterpret_cast<const vc_u32x4*>(&regs[i]);
+                    *reinterpret_cast<vc_u32x4*>(lds + row * STRIDE + kc) = regs[i];
                 } else {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(lds + row * STRIDE + kc);
 #pragma unroll
-                    for (int j = 0; j < CH; ++j) lds[row * STRIDE + kc + j] = regs[i].e[j];
+                    for (int j = 0; j < 4; ++j) d[j] = w[j];
                 }
             } else {
                 int k = c / (128 / CH), rc = (c % (128 / CH)) * CH;
+                if constexpr (sizeof(CT) == 2) {
+                    *reinterpret_cast<vc_u32x4*>(lds + k * GEMM_TSTRIDE + rc) = regs[i];      // [k][row], 16 lanes = one 256-byte row
+                } else {
+                    uint32_t* d = reinterpret_cast<uint32_t*>(lds);
 #pragma unroll
-                for (int j = 0; j < CH; ++j) lds[(rc + j) * STRIDE + k] = regs[i].e[j];
+                    for (int j = 0; j < 4; ++j) d[(rc + j) * STRIDE + k] = w[j];
+                }
             }
         }
     }
 };
 
+// bf16 MFMA fragment (8 k-values of one row) for k-step ks of the tile; row0 = first row of the wave's 32-row block
+template <bool TR>
+VC_DEV vc_s16x8 gemm_frag_bf16(const vc_bf16* tile, int row0, int ks, int lane) {
+    if constexpr (!TR) {
+        return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * GemmCfg<vc_bf16>::STRIDE + ks * 16 + (lane >> 5) * 8);
+    } else {
+        const int i = lane & 15;
+        const vc_bf16* p = tile + (ks * 16 + 8 * (lane >> 5) + (i >> 2)) * GEMM_TSTRIDE + row0 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+        const vc_s16x4 lo = vc_ds_read_tr16(p), hi = vc_ds_read_tr16(p + 4 * GEMM_TSTRIDE);
+        vc_s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
-VC_KERNEL __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
+VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     constexpr int BK = GemmCfg<CT>::BK, STRIDE = GemmCfg<CT>::STRIDE;
     VC_DYN_SHARED(CT, lds);
-    CT* As[2] = {lds, lds + (GEMM_BM + GEMM_BN) * STRIDE};
-    CT* Bs[2] = {As[0] + GEMM_BM * STRIDE, As[1] + GEMM_BM * STRIDE};
+    // NB: buffers are addressed as base + integer offset.  Keeping the two tile pointers in an array makes hipcc
+    // lose the LDS address space (flat_load/flat_store instead of ds_read_b128/ds_write_b128: ~10x slower).
+    constexpr int ATILE = gemm_tile_elems<CT, TRA>(), TILE = ATILE + gemm_tile_elems<CT, TRB>();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -178,30 +263,35 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
     const SA* Ag = (const SA*)p.A;
     const SB* Bg = (const SB*)p.B;
 
+    const bool rowsA = p.vecA && (m0 + GEMM_BM <= p.M), rowsB = p.vecB && (n0 + GEMM_BN <= p.N);   // block-uniform
     if (nt > 0) {
-        sa.load(Ag, p.lda, m0, kbeg, p.M, kend, p.vecA, tid);
-        sb.load(Bg, p.ldb, n0, kbeg, p.N, kend, p.vecB, tid);
-        sa.store(As[0], tid);
-        sb.store(Bs[0], tid);
+        if (rowsA && kbeg + BK <= kend) sa.load_fast(Ag, p.lda, m0, kbeg, tid); else sa.load(Ag, p.lda, m0, kbeg, p.M, kend, tid);
+        if (rowsB && kbeg + BK <= kend) sb.load_fast(Bg, p.ldb, n0, kbeg, tid); else sb.load(Bg, p.ldb, n0, kbeg, p.N, kend, tid);
+        sa.store(lds, tid);
+        sb.store(lds + ATILE, tid);
     }
     vc_sync();
 
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            sa.load(Ag, p.lda, m0, kbeg + (t + 1) * BK, p.M, kend, p.vecA, tid);
-            sb.load(Bg, p.ldb, n0, kbeg + (t + 1) * BK, p.N, kend, p.vecB, tid);
+            const int k1 = kbeg + (t + 1) * BK;
+            const bool kfull = k1 + BK <= kend;
+            if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid); else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
+            if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid); else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
         }
-        const CT* a_base = As[cur] + (wm * 64 + (lane & 31)) * STRIDE;
-        const CT* b_base = Bs[cur] + (wn * 64 + (lane & 31)) * STRIDE;
+        const CT* a_tile = lds + cur * TILE;
+        const CT* b_tile = a_tile + ATILE;
+        const CT* a_base = a_tile + (wm * 64 + (lane & 31)) * STRIDE;
+        const CT* b_base = b_tile + (wn * 64 + (lane & 31)) * STRIDE;
         if constexpr (sizeof(CT) == 2) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 vc_s16x8 af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const vc_s16x8*>(a_base + i * 32 * STRIDE + ks * 16 + (lane >> 5) * 8);
-                    bf[i] = *reinterpret_cast<const vc_s16x8*>(b_base + i * 32 * STRIDE + ks * 16 + (lane >> 5) * 8);
+                    af[i] = gemm_frag_bf16<TRA>(a_tile, wm * 64 + i * 32, ks, lane);
+                    bf[i] = gemm_frag_bf16<TRB>(b_tile, wn * 64 + i * 32, ks, lane);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -224,26 +314,38 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
             }
         }
         if (t + 1 < nt) {
-            sa.store(As[cur ^ 1], tid);
-            sb.store(Bs[cur ^ 1], tid);
+            sa.store(lds + (cur ^ 1) * TILE, tid);
+            sb.store(lds + (cur ^ 1) * TILE + ATILE, tid);
         }
         vc_sync();
     }
 
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (!p.partial && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {        // interior block (uniform): batched path
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            const float bias_n = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < 2; ++i) gemm_epilogue_tile<TO>(p, m0 + wm * 64 + i * 32 + 4 * (lane >> 5), n, acc[i][j], bias_n);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        const float bias_n = (p.bias && !p.partial && n < p.N) ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                int n = n0 + wn * 64 + j * 32 + (lane & 31);
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M && n < p.N) {
                     if (p.partial) p.partial[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
-                    else gemm_epilogue_store<TO>(p, m, n, acc[i][j][r]);
+                    else gemm_epilogue_store<TO>(p, m, n, acc[i][j][r], bias_n);
                 }
             }
+    }
 }
 
 // split-K reducer: sums the fp32 partial slabs in a fixed order (deterministic) and runs the epilogue.
@@ -254,5 +356,6 @@ VC_KERNEL __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, in
     if (idx >= total) return;
     float s = 0.0f;
     for (int z = 0; z < nsplit; ++z) s += p.partial[(long)z * total + idx];
-    gemm_epilogue_store<TO>(p, (int)(idx / p.N), (int)(idx % p.N), s);
+    const int n = (int)(idx % p.N);
+    gemm_epilogue_store<TO>(p, (int)(idx / p.N), n, s, p.bias ? p.bias[n] : 0.0f);
 }

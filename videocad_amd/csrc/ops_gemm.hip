@@ -15,20 +15,20 @@ namespace { struct PRec { hipEvent_t a, b; hipStream_t s; int cat; double flops,
 ProfScope::ProfScope(int cat, double flops, double bytes, vc_stream_t s) : rec(nullptr) {
     if (!g_on) return;
     PRec* r = new PRec(); r->cat = cat; r->flops = flops; r->bytes = bytes; r->s = s;
-    hipEventCreate(&r->a); hipEventCreate(&r->b); hipEventRecord(r->a, s);
+    (void)hipEventCreate(&r->a); (void)hipEventCreate(&r->b); (void)hipEventRecord(r->a, s);
     rec = r;
 }
-ProfScope::~ProfScope() { if (rec) { PRec* r = (PRec*)rec; hipEventRecord(r->b, r->s); g_recs.push_back(r); } }
+ProfScope::~ProfScope() { if (rec) { PRec* r = (PRec*)rec; (void)hipEventRecord(r->b, r->s); g_recs.push_back(r); } }
 extern "C" void vcad_profile_begin(void) { g_on = true; }
 // out arrays of VC_NCAT: milliseconds, flops, bytes, launches.  Synchronises the recorded events.
 extern "C" int vcad_profile_end(double* ms, double* flops, double* bytes, int* launches) {
     g_on = false;
     for (int i = 0; i < VC_NCAT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
     for (PRec* r : g_recs) {
-        hipEventSynchronize(r->b);
-        float t = 0.f; hipEventElapsedTime(&t, r->a, r->b);
+        (void)hipEventSynchronize(r->b);
+        float t = 0.f; (void)hipEventElapsedTime(&t, r->a, r->b);
         ms[r->cat] += t; flops[r->cat] += r->flops; bytes[r->cat] += r->bytes; launches[r->cat]++;
-        hipEventDestroy(r->a); hipEventDestroy(r->b); delete r;
+        (void)hipEventDestroy(r->a); (void)hipEventDestroy(r->b); delete r;
     }
     g_recs.clear();
     return 0;
@@ -42,7 +42,7 @@ extern "C" int vcad_profile_end(double*, double*, double*, int*) { return 0; }
 
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
 static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
-    constexpr size_t lds = gemm_lds_bytes<CT>();
+    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB>();
 #ifndef VC_EMU
     static bool attr_set = false;
     if (!attr_set) {
@@ -91,14 +91,17 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     if (c.ct == VC_F32) {
         switch (lay) { case 0: G(float, float, float, float, false, false); case 1: G(float, float, float, float, false, true);
                        case 2: G(float, float, float, float, true, false); case 3: G(float, float, float, float, true, true); }
+    } else if (lay == 3) {            // wgrad: fp32 output always; either operand may be an fp32 tensor (converted while staging)
+        if (c.to != VC_F32) { vc_set_error("vc_gemm: wgrad (tra=trb=1) writes fp32"); return VC_ERR_UNSUPPORTED; }
+        switch ((c.sa == VC_F32) * 2 + (c.sb == VC_F32)) {
+            case 0: G(vc_bf16, vc_bf16, vc_bf16, float, true, true); case 1: G(vc_bf16, vc_bf16, float, float, true, true);
+            case 2: G(vc_bf16, float, vc_bf16, float, true, true);   case 3: G(vc_bf16, float, float, float, true, true); }
     } else if (c.sb == VC_BF16 && lay != 2) {
         const int key = (c.sa == VC_F32) * 2 + (c.to == VC_F32);
         if (lay == 0) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, false, false); case 1: G(vc_bf16, vc_bf16, vc_bf16, float, false, false);
                                      case 2: G(vc_bf16, float, vc_bf16, vc_bf16, false, false);   case 3: G(vc_bf16, float, vc_bf16, float, false, false); }
         if (lay == 1) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, false, true);  case 1: G(vc_bf16, vc_bf16, vc_bf16, float, false, true);
                                      case 2: G(vc_bf16, float, vc_bf16, vc_bf16, false, true);    case 3: G(vc_bf16, float, vc_bf16, float, false, true); }
-        if (lay == 3) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, true, true);   case 1: G(vc_bf16, vc_bf16, vc_bf16, float, true, true);
-                                     case 2: G(vc_bf16, float, vc_bf16, vc_bf16, true, true);     case 3: G(vc_bf16, float, vc_bf16, float, true, true); }
     }
 #undef G
     vc_set_error("vc_gemm: unsupported combination ct=%d sa=%d sb=%d to=%d tra=%d trb=%d", c.ct, c.sa, c.sb, c.to, c.tra, c.trb);

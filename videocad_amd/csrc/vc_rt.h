@@ -46,6 +46,13 @@ typedef __bf16 vc_bf16x8_hw __attribute__((ext_vector_type(8)));
 VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vc_bf16x8_hw, a), __builtin_bit_cast(vc_bf16x8_hw, b), c, 0, 0, 0);
 }
+// LDS transpose read (gfx950 ds_read_b64_tr_b16), semantics measured with tools/probe_tr16.hip: within each 16-lane
+// group lane i points at 4 consecutive 16-bit elements D_i[0..3]; lane i receives { D_{4j + i/4}[i%4] : j = 0..3 }.
+// With lane i -> &tile[k0 + i/4][n0 + 4*(i%4)] of a row-major [k][n] tile it returns tile[k0 + j][n0 + i]: column i.
+typedef short vc_s16x4 __attribute__((ext_vector_type(4)));
+VC_DEV vc_s16x4 vc_ds_read_tr16(const void* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((vc_s16x4 __attribute__((address_space(3)))*)lds_ptr);
+}
 // D(32x32) += A(32x2) * B(2x32), exact f32.  lane l: A[i=l&31][k=l>>5], B[k=l>>5][n=l&31]; D as above.
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -66,6 +73,7 @@ int shfl_i(int v, int src_lane);
 void* dyn_shared();
 void mfma_32x32x16_bf16(const short* a8, const short* b8, float* c16);   // in-place on c16
 void mfma_32x32x2_f32(float a, float b, float* c16);
+void ds_read_tr16(const void* p, short* out4);
 void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem);
 }  // namespace vcemu
 using vcemu::dim3;
@@ -112,6 +120,8 @@ struct vc_f32x4 { float v[4]; float& operator[](int i) { return v[i]; } const fl
 struct vc_s16x8 { short v[8]; short& operator[](int i) { return v[i]; } const short& operator[](int i) const { return v[i]; } };
 VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) { vcemu::mfma_32x32x16_bf16(a.v, b.v, c.v); return c; }
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) { vcemu::mfma_32x32x2_f32(a, b, c.v); return c; }
+struct vc_s16x4 { short v[4]; short& operator[](int i) { return v[i]; } const short& operator[](int i) const { return v[i]; } };
+VC_DEV vc_s16x4 vc_ds_read_tr16(const void* p) { vc_s16x4 r; vcemu::ds_read_tr16(p, r.v); return r; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #endif
 
@@ -125,6 +135,9 @@ VC_HD float vc_bf16_to_f32(vc_bf16 h) {
     return f;
 }
 VC_HD vc_bf16 vc_f32_to_bf16(float f) {     // round-to-nearest-even; NaN stays NaN
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    { __bf16 h = (__bf16)f; vc_bf16 r; __builtin_memcpy(&r, &h, 2); return r; }   // v_cvt_pk_bf16_f32 on gfx950
+#endif
     uint32_t u;
     __builtin_memcpy(&u, &f, 4);
     vc_bf16 r;
@@ -155,6 +168,9 @@ VC_DEV float vc_wave_max(float v) {
     return v;
 }
 
-struct vc_u32x4 { uint32_t x, y, z, w; };   // 16-byte POD for vector copies
+struct alignas(16) vc_u32x4 { uint32_t x, y, z, w; };   // 16-byte POD for vector copies
+VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
+VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
 #define VC_CEIL_DIV(a, b) (((a) + (b) - 1) / (b))
