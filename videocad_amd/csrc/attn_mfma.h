@@ -1,0 +1,226 @@
+// attn_mfma.h — ViT self-attention on the matrix cores (bf16 in, fp32 accumulate): ONE wave64 per (frame, head).
+//
+// The per-frame problem is tiny and odd (50 tokens x 64 dims per head, 16 heads: vit-pytorch Attention at
+// reference model/trajectory_model.py:54-65): tokens are padded to 64 so the whole head is a 2x2 grid of 32x32 MFMA
+// tiles, Q/K/V (and dO) of the head are staged once into wave-private LDS tiles (natural [token][d] layout,
+// 16-byte coalesced copies, zero-filled padding rows) and everything else stays in registers:
+//
+//   forward   S^T = K Q^T          (lane = query column, regs = keys: the softmax row reduction is lane-local
+//                                    plus one xor-32 exchange — no LDS round trip for P)
+//             P   = softmax         (normalised before PV so no per-row rescale of O is needed)
+//             O   = P V             (A = P straight from the S^T accumulator registers: any k-slot <-> key
+//                                    assignment is legal as long as V's B fragment uses the same one, so V is read
+//                                    with two ds_read_b64_tr_b16 per fragment at rows 4h+16s+{0..3, 8..11})
+//   backward  both orientations are recomputed on the matrix cores (cheaper than transposing dS through LDS):
+//             lane = query:  S^T, dP^T = V dO^T -> D = sum_k P dP, dS^T -> dQ = dS K
+//             lane = key  :  S,   dP   = dO V^T -> P, dS (lse / D per register row from LDS) -> dV = P^T dO, dK = dS^T Q
+//   32 MFMAs forward, 112 backward per head, against ~6.6 / 16.5 MFLOP of useful work (22 % padding waste).
+#pragma once
+#include "vc_rt.h"
+#include "attn.h"
+
+constexpr int AM_T = 64;          // padded tokens
+constexpr int AM_D = 64;          // head dim
+constexpr int AM_S = 72;          // LDS row stride (elements): 144 B -> conflict-free ds_read_b128 fragments
+
+// stage one [T x 64] bf16 head slice into a wave-private LDS tile (rows >= T zero-filled)
+VC_DEV void am_stage(vc_bf16* tile, const vc_bf16* g, long ld, int T, int lane) {
+#pragma unroll
+    for (int it = 0; it < AM_T / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        vc_u32x4 v; v.x = v.y = v.z = v.w = 0u;
+        if (row < T) v = *reinterpret_cast<const vc_u32x4*>(g + (long)row * ld + c);
+        *reinterpret_cast<vc_u32x4*>(tile + row * AM_S + c) = v;
+    }
+}
+// direct fragment: row = row0 + (lane&31), 8 consecutive d at ks*16 + 8*(lane>>5)
+VC_DEV vc_s16x8 am_frag(const vc_bf16* tile, int row0, int ks, int lane) {
+    return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * AM_S + ks * 16 + (lane >> 5) * 8);
+}
+// transposed fragment for the "token" contraction: column n0 + (lane&31), token rows k0 + 4h + {0..3} and + 8 + {0..3}
+VC_DEV vc_s16x8 am_frag_tr(const vc_bf16* tile, int k0, int n0, int lane) {
+    const int i = lane & 15;
+    const vc_bf16* p = tile + (k0 + 4 * (lane >> 5) + (i >> 2)) * AM_S + n0 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+    const vc_s16x4 lo = vc_ds_read_tr16(p), hi = vc_ds_read_tr16(p + 8 * AM_S);
+    vc_s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+// accumulator registers 8s..8s+7 of a 32x32 tile -> bf16 A/B fragment (k-slots = rows 4h+16s+{0..3, 8..11})
+VC_DEV vc_s16x8 am_pack(const vc_f32x16& a, int s) {
+    vc_s16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)vc_f32_to_bf16(a[8 * s + j]).bits;
+    return r;
+}
+VC_DEV int am_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }   // row inside a 32x32 D tile
+
+VC_DEV void am_zero(vc_f32x16 (&a)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[i][j][r] = 0.f;
+}
+// acc[i][j] += X[rows i*32..][d] * Y[rows j*32..][d]^T over d = 0..63 (both direct fragments)
+VC_DEV void am_mm_nt(vc_f32x16 (&acc)[2][2], const vc_bf16* X, const vc_bf16* Y, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < AM_D / 16; ++ks) {
+        vc_s16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a[i] = am_frag(X, i * 32, ks, lane); b[i] = am_frag(Y, i * 32, ks, lane); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = vc_mfma_32x32x16_bf16(a[i], b[j], acc[i][j]);
+    }
+}
+// out[ot][dt] += sum over token tiles tt: W[tt][ot]^T-style contraction: A = pack(W[tt][ot]) (lane = out row), B = Ytile rows (tokens) via tr
+// W is indexed W[tt][ot] (accumulator grid whose *register rows* are the contracted tokens and lane column the output row)
+VC_DEV void am_mm_tok(vc_f32x16 (&out)[2][2], const vc_f32x16 (&W)[2][2], const vc_bf16* Y, int lane) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            vc_s16x8 a[2], b[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) { a[o] = am_pack(W[tt][o], s); b[o] = am_frag_tr(Y, tt * 32 + 16 * s, o * 32, lane); }
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
+        }
+}
+// store a [64 x 64] result grid (rows = tokens, lane column = d) as bf16, rows < T only
+VC_DEV void am_store(vc_bf16* g, long ld, const vc_f32x16 (&acc)[2][2], int T, int lane, float mul) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = o * 32 + am_row(r, lane);
+                if (row < T) g[(long)row * ld + d * 32 + (lane & 31)] = vc_f32_to_bf16(acc[o][d][r] * mul);
+            }
+}
+
+VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[3][AM_T * AM_S];
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    am_stage(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, lane);
+    am_stage(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, lane);
+    am_stage(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, lane);
+    vc_wave_barrier();
+    vc_f32x16 st[2][2];                       // S^T: [key tile][query tile], lane column = query
+    am_zero(st);
+    am_mm_nt(st, tiles[1], tiles[0], lane);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + am_row(r, lane);
+                const float s = (key < T) ? st[kt][qt][r] * p.scale : -INFINITY;
+                st[kt][qt][r] = s; m = fmaxf(m, s);
+            }
+        m = fmaxf(m, vc_shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
+        l += vc_shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][qt][r] *= inv;
+        const int query = qt * 32 + (lane & 31);
+        if (p.lse && lane < 32 && query < T) p.lse[(n * p.H + h) * T + query] = m + logf(l);
+    }
+    vc_f32x16 o[2][2];
+    am_zero(o);
+    am_mm_tok(o, st, tiles[2], lane);        // O[query][d] = sum_key P[query][key] V[key][d]
+    am_store((vc_bf16*)p.o + rowq * p.ldo + h * AM_D, p.ldo, o, T, lane, 1.0f);
+}
+
+VC_KERNEL __launch_bounds__(64) void attn_vit_bwd_mfma_kernel(AttnParams p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO
+    VC_SHARED float lse_s[AM_T];
+    VC_SHARED float del_s[AM_T];
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    am_stage(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, lane);
+    am_stage(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, lane);
+    am_stage(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, lane);
+    am_stage(tiles[3], (const vc_bf16*)p.dout + rowq * p.lddo + h * AM_D, p.lddo, T, lane);
+    lse_s[lane] = (lane < T) ? p.lse[(n * p.H + h) * T + lane] : 0.f;
+    vc_wave_barrier();
+    const vc_bf16 *Qs = tiles[0], *Ks = tiles[1], *Vs = tiles[2], *dOs = tiles[3];
+
+    {   // ---------------- lane = query:  dQ
+        vc_f32x16 st[2][2], dpt[2][2];
+        am_zero(st); am_zero(dpt);
+        am_mm_nt(st, Ks, Qs, lane);          // S^T[key][query]
+        am_mm_nt(dpt, Vs, dOs, lane);        // dP^T[key][query] = sum_d V[key][d] dO[query][d]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int query = qt * 32 + (lane & 31);
+            const float lse = lse_s[query];
+            float dsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + am_row(r, lane);
+                    const float pr = (key < T && query < T) ? expf(st[kt][qt][r] * p.scale - lse) : 0.f;
+                    st[kt][qt][r] = pr; dsum += pr * dpt[kt][qt][r];
+                }
+            dsum += vc_shfl_xor(dsum, 32);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kt][qt][r] = st[kt][qt][r] * (dpt[kt][qt][r] - dsum);   // dS^T (scale folded into the store)
+            if (lane < 32) del_s[query] = dsum;
+        }
+        vc_f32x16 dq[2][2];
+        am_zero(dq);
+        am_mm_tok(dq, st, Ks, lane);         // dQ[query][d] = sum_key dS[query][key] K[key][d]
+        am_store((vc_bf16*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, T, lane, p.scale);
+    }
+    vc_wave_barrier();                       // del_s written by lanes < 32, read by all below
+    {   // ---------------- lane = key:  dV, dK
+        vc_f32x16 sn[2][2], dp[2][2];
+        am_zero(sn); am_zero(dp);
+        am_mm_nt(sn, Qs, Ks, lane);          // S[query][key]   (grid [query tile][key tile], lane column = key)
+        am_mm_nt(dp, dOs, Vs, lane);         // dP[query][key]
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = kt * 32 + (lane & 31);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + am_row(r, lane);
+                    const float pr = (key < T && query < T) ? expf(sn[qt][kt][r] * p.scale - lse_s[query]) : 0.f;
+                    sn[qt][kt][r] = pr;
+                    dp[qt][kt][r] = pr * (dp[qt][kt][r] - del_s[query]);
+                }
+        }
+        vc_f32x16 acc[2][2];
+        am_zero(acc);
+        am_mm_tok(acc, sn, dOs, lane);       // dV[key][d] = sum_query P[query][key] dO[query][d]
+        am_store((vc_bf16*)p.dv + rowq * p.lddv + h * AM_D, p.lddv, acc, T, lane, 1.0f);
+        am_zero(acc);
+        am_mm_tok(acc, dp, Qs, lane);        // dK[key][d] = sum_query dS[query][key] Q[query][d]
+        am_store((vc_bf16*)p.dk + rowq * p.lddk + h * AM_D, p.lddk, acc, T, lane, p.scale);
+    }
+}

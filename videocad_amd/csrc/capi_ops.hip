@@ -30,7 +30,7 @@ int vcad_op_layernorm_bwd(int td, int ty, int C, const void* dy, const float* x,
                           const float* gamma, const float* add_in, float* dx32, void* dxt, float* dgamma, float* dbeta,
                           int64_t rows, float* scratch, size_t scratch_bytes, void* stream) {
     const size_t part = (size_t)vc_ln_bwd_blocks(rows) * 2 * C * 4;
-    const size_t cs = (size_t)vc_colsum_chunks(vc_ln_bwd_blocks(rows)) * C * 4;
+    const size_t cs = (size_t)vc_colsum_chunks(vc_ln_bwd_blocks(rows)) * 2 * C * 4;
     if (part + cs + 512 > scratch_bytes) { vc_set_error("layernorm_bwd: scratch %zu < %zu", scratch_bytes, part + cs + 512); return VC_ERR_WORKSPACE; }
     LnBwdParams p; memset(&p, 0, sizeof(p));
     p.dy = dy; p.lddy = C; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = gamma; p.add_in = add_in; p.ldadd = C;

@@ -257,7 +257,7 @@ struct Ctx {
         return 0;
     }
     int colsum(Mat X, long rows, int cols, float* out, int accumulate, int batch = 1, long bsx = 0, long bso = 0) const {
-        size_t need = (size_t)batch * vc_colsum_chunks(rows) * cols * 4;
+        size_t need = (size_t)batch * vc_colsum_chunks(rows) * cols * 4;      // both tree levels
         if (need > e->scr_colsum_bytes) { vc_set_error("colsum scratch too small (%zu)", need); return VC_ERR_WORKSPACE; }
         return vc_colsum(X.dt, X.p, X.ld, rows, cols, out, accumulate, batch, bsx, bso, e->scr_colsum, s);
     }

@@ -6,19 +6,34 @@
 
 // ---- row access helpers: a wave owns one row of C = 64*VPL elements; lane l owns VPL/4 groups of 4
 // consecutive elements at columns g*256 + l*4 + (0..3)  (16-byte loads for fp32, 8-byte for bf16).
+// (explicit 16-byte / 8-byte vector accesses: rows are 16-byte aligned everywhere on the hot path)
+template <typename T> VC_DEV void quad_load(const T* p, float* v);
+template <> VC_DEV void quad_load<float>(const float* p, float* v) {
+    const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p);
+    v[0] = vc_bits_f32(q.x); v[1] = vc_bits_f32(q.y); v[2] = vc_bits_f32(q.z); v[3] = vc_bits_f32(q.w);
+}
+template <> VC_DEV void quad_load<vc_bf16>(const vc_bf16* p, float* v) {
+    const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p);
+    v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u);
+}
+template <typename T> VC_DEV void quad_store(T* p, const float* v);
+template <> VC_DEV void quad_store<float>(float* p, const float* v) {
+    vc_u32x4 q; q.x = vc_f32_bits(v[0]); q.y = vc_f32_bits(v[1]); q.z = vc_f32_bits(v[2]); q.w = vc_f32_bits(v[3]);
+    *reinterpret_cast<vc_u32x4*>(p) = q;
+}
+template <> VC_DEV void quad_store<vc_bf16>(vc_bf16* p, const float* v) {
+    vc_u32x2 q; q.x = vc_pack_bf16x2(v[0], v[1]); q.y = vc_pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<vc_u32x2*>(p) = q;
+}
 template <typename T, int VPL>
 VC_DEV void row_load(const T* p, float (&v)[VPL], int lane) {
 #pragma unroll
-    for (int g = 0; g < VPL / 4; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[g * 4 + j] = vc_ld(p + g * 256 + lane * 4 + j);
+    for (int g = 0; g < VPL / 4; ++g) quad_load<T>(p + g * 256 + lane * 4, &v[g * 4]);
 }
 template <typename T, int VPL>
 VC_DEV void row_store(T* p, const float (&v)[VPL], int lane) {
 #pragma unroll
-    for (int g = 0; g < VPL / 4; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vc_st(p + g * 256 + lane * 4 + j, v[g * 4 + j]);
+    for (int g = 0; g < VPL / 4; ++g) quad_store<T>(p + g * 256 + lane * 4, &v[g * 4]);
 }
 template <int VPL>
 VC_DEV void row_stats(const float (&v)[VPL], float eps, float& mean, float& rstd) {
@@ -45,8 +60,7 @@ VC_DEV void patch_load(const float* frames, long row, float (&v)[VPL], int lane,
     for (int g = 0; g < VPL / 4; ++g) {
         int e = g * 256 + lane * 4;
         int p1 = e / patch, p2 = e % patch;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[g * 4 + j] = base[(long)p1 * img + p2 + j];
+        quad_load<float>(base + (long)p1 * img + p2, &v[g * 4]);
     }
 }
 
@@ -165,15 +179,15 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     }
 }
 
-// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c], two-stage & deterministic.  Batched over blockIdx.z.
+// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c].  Deterministic 32-way tree: every pass gives each block <= 32
+// rows of 256 columns (so there are always enough blocks in flight), partials are reduced by the next pass.
 struct ColsumParams {
     const void* x; long ld; long rows; int cols; long batch_stride_x;
-    float* out; long batch_stride_out; int accumulate;
-    float* partial;                   // [batch][gridDim.y][cols]
+    float* out; long ld_out_rows; long batch_stride_out; int accumulate;    // out row g = block-row index (partials) or 0 (final)
     int rows_per_block;
 };
 template <typename TX>
-VC_KERNEL __launch_bounds__(256) void colsum_stage1_kernel(ColsumParams p) {
+VC_KERNEL __launch_bounds__(256) void colsum_pass_kernel(ColsumParams p) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= p.cols) return;
     const TX* x = (const TX*)p.x + (long)blockIdx.z * p.batch_stride_x;
@@ -181,14 +195,7 @@ VC_KERNEL __launch_bounds__(256) void colsum_stage1_kernel(ColsumParams p) {
     if (r1 > p.rows) r1 = p.rows;
     float s = 0.f;
     for (long r = r0; r < r1; ++r) s += vc_ld(x + r * p.ld + c);
-    p.partial[((long)blockIdx.z * gridDim.y + blockIdx.y) * p.cols + c] = s;
-}
-VC_KERNEL __launch_bounds__(256) void colsum_stage2_kernel(ColsumParams p, int nchunk) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.cols) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += p.partial[((long)blockIdx.z * nchunk + k) * p.cols + c];
-    float* o = p.out + (long)blockIdx.z * p.batch_stride_out + c;
+    float* o = p.out + (long)blockIdx.z * p.batch_stride_out + (long)blockIdx.y * p.ld_out_rows + c;
     *o = p.accumulate ? (*o + s) : s;
 }
 

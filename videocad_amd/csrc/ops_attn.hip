@@ -1,5 +1,6 @@
 // ops_attn.hip — launchers for the windowed attention kernels.
 #include "ops.h"
+#include "attn_mfma.h"
 
 static int clampw(const AttnParams& p) { int mx = p.Tq > p.Tk ? p.Tq : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
 static int max_keys(const AttnParams& p) { int w = clampw(p); return w < p.Tk ? w : p.Tk; }        // visible keys per query
@@ -36,13 +37,29 @@ static int attn_bwd_t(int D, AttnParams p, vc_stream_t s) {
 static double attn_flops(const AttnParams& p, int D) {      // 2 GEMM-like contractions over the visible keys
     return 4.0 * p.B * p.H * (double)p.Tq * max_keys(p) * D;
 }
+// MFMA path: bf16, 64-dim heads, <= 64 tokens, full (non-causal) attention, 16-byte-aligned head slices (the ViT)
+static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
+    auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
+    bool ok = t == VC_BF16 && D == AM_D && p.Tq == p.Tk && p.Tq <= AM_T && !p.causal && clampw(p) >= p.Tk &&
+              al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    if (!bwd) return ok && al(p.o, p.ldo);
+    return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
+}
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), 0, s);
+    if (mfma_ok(t, D, p, false)) {
+        VC_LAUNCH(attn_vit_fwd_mfma_kernel, dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
+        return VC_OK;
+    }
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
 }
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), 0, s);
+    if (mfma_ok(t, D, p, true)) {
+        VC_LAUNCH(attn_vit_bwd_mfma_kernel, dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
+        return VC_OK;
+    }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);
 }

@@ -25,7 +25,7 @@ int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s) {
     vc_set_error("ln_fwd: dtype combo %d %d", tx, ty); return VC_ERR_UNSUPPORTED;
 }
 
-long vc_ln_bwd_blocks(long rows) { long b = VC_CEIL_DIV(rows, 4); return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
+long vc_ln_bwd_blocks(long rows) { long b = VC_CEIL_DIV(rows, 4); return b > 512 ? 512 : (b < 1 ? 1 : b); }
 
 template <typename TD, typename TX, typename TY, int MODE>
 static int ln_bwd_c(int C, LnBwdParams p, unsigned nblk, vc_stream_t s) {
@@ -54,27 +54,38 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     else { vc_set_error("ln_bwd: dtype combo %d %d %d", td, tx, ty); return VC_ERR_UNSUPPORTED; }
     if (rc) return rc;
     if (partial_ws) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C)
-        rc = vc_colsum(VC_F32, partial_ws, 2L * C, nblk, C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
-        rc = vc_colsum(VC_F32, partial_ws + C, 2L * C, nblk, C, dbeta, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+        if (dbeta == dgamma + C) {       // weight and bias adjacent in the flat gradient buffer: one reduction over 2C columns
+            rc = vc_colsum(VC_F32, partial_ws, 2L * C, nblk, 2 * C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+        } else {
+            rc = vc_colsum(VC_F32, partial_ws, 2L * C, nblk, C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+            rc = vc_colsum(VC_F32, partial_ws + C, 2L * C, nblk, C, dbeta, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+        }
     }
     return VC_OK;
 }
 
-long vc_colsum_chunks(long rows) { long c = VC_CEIL_DIV(rows, 256); return c > 512 ? 512 : (c < 1 ? 1 : c); }
+long vc_colsum_chunks(long rows) { return VC_CEIL_DIV(rows, 32) + VC_CEIL_DIV(VC_CEIL_DIV(rows, 32), 32) + 2; }   // partial rows, both ping-pong levels
 
 int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
               int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s) {
     if (rows <= 0 || cols <= 0) return VC_OK;
-    ColsumParams p;
-    p.x = x; p.ld = ld; p.rows = rows; p.cols = cols; p.batch_stride_x = bstride_x;
-    p.out = out; p.batch_stride_out = bstride_out; p.accumulate = accumulate; p.partial = ws;
-    const long nchunk = vc_colsum_chunks(rows);
     ProfScope ps(VC_CAT_OTHER, 0, (double)batch * rows * cols * (tx == VC_BF16 ? 2 : 4), s);
-    p.rows_per_block = (int)VC_CEIL_DIV(rows, nchunk);
-    dim3 g1(VC_CEIL_DIV(cols, 256), (unsigned)nchunk, batch);
-    if (tx == VC_F32) VC_LAUNCH((colsum_stage1_kernel<float>), g1, dim3(256), 0, s, p);
-    else VC_LAUNCH((colsum_stage1_kernel<vc_bf16>), g1, dim3(256), 0, s, p);
-    VC_LAUNCH(colsum_stage2_kernel, dim3(VC_CEIL_DIV(cols, 256), 1, batch), dim3(256), 0, s, p, (int)nchunk);
+    const void* cur = x; long cur_ld = ld, cur_rows = rows, cur_bs = bstride_x; int cur_t = tx;
+    float* wsA = ws; float* wsB = ws + (long)batch * VC_CEIL_DIV(rows, 32) * cols;
+    bool useA = true;
+    while (true) {
+        const bool last = cur_rows <= 32;
+        const long nblk = last ? 1 : VC_CEIL_DIV(cur_rows, 32);
+        ColsumParams p;
+        p.x = cur; p.ld = cur_ld; p.rows = cur_rows; p.cols = cols; p.batch_stride_x = cur_bs; p.rows_per_block = 32;
+        float* dst = last ? out : (useA ? wsA : wsB);
+        p.out = dst; p.ld_out_rows = last ? 0 : cols; p.batch_stride_out = last ? bstride_out : nblk * cols; p.accumulate = last ? accumulate : 0;
+        dim3 g(VC_CEIL_DIV(cols, 256), (unsigned)nblk, batch);
+        if (cur_t == VC_F32) VC_LAUNCH((colsum_pass_kernel<float>), g, dim3(256), 0, s, p);
+        else VC_LAUNCH((colsum_pass_kernel<vc_bf16>), g, dim3(256), 0, s, p);
+        if (last) break;
+        cur = dst; cur_ld = cols; cur_rows = nblk; cur_bs = nblk * cols; cur_t = VC_F32; useA = !useA;
+    }
     return VC_OK;
 }
 

@@ -169,6 +169,7 @@ VC_DEV float vc_wave_max(float v) {
 }
 
 struct alignas(16) vc_u32x4 { uint32_t x, y, z, w; };   // 16-byte POD for vector copies
+struct alignas(8) vc_u32x2 { uint32_t x, y; };
 VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
 VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
