@@ -76,6 +76,9 @@ int vcad_forward(vcad_engine* e, const float* frames, int64_t frame_bstride, con
 int vcad_loss(vcad_engine* e, const float* cmds, const float* params, const float* targets, int B, int T, int use_mse,
               const float* class_weights, float* loss_out, int32_t* metrics_out, void* stream);
 
+/* byte offsets (inside the caller's workspace) of the d(loss)/d(logits) tensors vcad_loss wrote: fp32 [B*T,5], [B*T,6000] */
+int vcad_dlogits_offsets(const vcad_engine* e, size_t* off_cmds, size_t* off_params);
+
 /* ---- autograd backward of forward (+ what `loss.backward()` does at reference trainer.py:492)
  * dcmds/dparams: fp32 gradients of the two outputs, or both NULL to use the ones vcad_loss left in the workspace.
  * Gradients are WRITTEN (not accumulated) into the bound flat grad buffer. */

@@ -352,6 +352,11 @@ class OracleTrainer:
     def step(self, batch: dict):
         loss, metrics, cmds, params = self.loss_and_grads(batch)
         grads = {k: p.grad for k, p in self.P.items() if p.grad is not None}
+        total = self.apply_grads(grads)
+        return loss, metrics, total, cmds, params
+
+    def apply_grads(self, grads: dict) -> float:
+        """clip_grad_norm_(1.0) + Adam on externally supplied gradients (e.g. the mean over data-parallel ranks)."""
         total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
         # clip_grad_norm_: coef = max_norm / (total + 1e-6), clamped to 1.0
         coef = torch.clamp(self.max_norm / (total + 1e-6), max=1.0)
@@ -365,4 +370,4 @@ class OracleTrainer:
                 bc1 = 1 - b1 ** self.t; bc2 = 1 - b2 ** self.t
                 denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
                 self.P[k].addcdiv_(self.m[k], denom, value=-self.lr / bc1)
-        return loss, metrics, float(total), cmds, params
+        return float(total)

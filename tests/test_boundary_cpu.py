@@ -1,0 +1,163 @@
+"""Drop-in boundary on the CPU: state_dict contract, ModelFactory / trainer surface, loud failure
+without a GPU, and — with the kernels running under the emulator — the autograd bridge and the native train step."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oputil as U
+from oracle import restatement as O
+from videocad_amd import lib as L
+from videocad_amd import synth
+from videocad_amd.model_factory import ModelFactory, ModelType
+from videocad_amd.trainer import create_trainer
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CANON = json.load(open(os.path.join(HERE, "golden", "model_configs.json")))["cad_past_10_actions_and_states_timestep_embedding"]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import ctypes
+    lib = ctypes.CDLL(L.LIB_PATH)                     # loads without a GPU (no compute calls here)
+    L.declare(lib)
+    assert b"gfx950" in lib.vcad_version()
+    hdr = open(os.path.join(HERE, "..", "include", "vcad.h")).read()
+    import re
+    declared = set(re.findall(r"\b(vcad_[a-z0-9_]+)\s*\(", hdr))
+    assert declared and all(hasattr(lib, n) for n in declared), [n for n in declared if not hasattr(lib, n)]
+    assert declared <= set(L.PROTOTYPES) | {"vcad_config", "vcad_engine"}, declared - set(L.PROTOTYPES)
+
+
+def test_state_dict_matches_appendix_b_and_factory_surface():
+    model, mtype = ModelFactory().create_model(CANON["model_name"], dict(CANON), "cpu")
+    assert mtype == ModelType.MULTI_CLASSES
+    sd = model.state_dict()
+    shapes = O.param_shapes()
+    assert set(sd) == set(shapes)
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    assert sum(v.numel() for v in sd.values()) == 126_963_573           # live parameters
+    assert hasattr(model, "state_embedding_model") and hasattr(model, "cad_embedding_model")   # reference trainer.py:244-245
+    assert model.transformer_decoder.layers[3].self_attn.in_proj_weight.shape == (3072, 1024)
+    # views of one flat buffer
+    assert model.embed_state.weight.data_ptr() == model._engine.view("embed_state.weight").data_ptr()
+    # load with DDP/compile prefixes + unknown (dead GPT-2) keys, strict=False like the reference factory
+    w = {"module._orig_mod.embed_state.bias": torch.full((1024,), 0.5), "transformer.h.0.ln_1.weight": torch.zeros(3)}
+    model2, _ = ModelFactory().create_model("x", dict(CANON), "cpu", state_dict=w)
+    assert float(model2.embed_state.bias[7]) == 0.5
+    with pytest.raises(RuntimeError):
+        model2.load_state_dict({"embed_state.bias": torch.zeros(1024)}, strict=True)
+    # no CPU fallback: the product path fails loudly without a ROCm device
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model({"frames": torch.zeros(1, 1, 1, 224, 224), "actions": torch.zeros(1, 1, 7), "cad_image": torch.zeros(1, 1, 224, 224)})
+    for bad in (dict(CANON, encoder="resnet"), dict(CANON, enable_past_actions=False), dict(CANON, window_size=0)):
+        with pytest.raises((NotImplementedError, AssertionError)):
+            ModelFactory().create_model("x", bad, "cpu")
+
+
+def small_model(emu, **over):
+    cfg = dict(CANON); cfg.update(num_decoder_layers=1, window_size=2, max_ep_len=8, compute_dtype="f32", _lib=emu, vit_depth=1); cfg.update(over)
+    ocfg = dict(O.CANONICAL_CONFIG); ocfg.update(vit_depth=1, num_decoder_layers=1, window_size=2, max_ep_len=8)
+    return cfg, ocfg
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return U.load_emu()
+
+
+def test_autograd_bridge_and_trainer_step_under_emulator(emu, tmp_path, monkeypatch):
+    """model(inputs) -> torch loss -> loss.backward() gives the oracle's gradients; trainer._process_batch == oracle step."""
+    monkeypatch.chdir(tmp_path)
+    # depth-reduced model (vit_depth=1, 1 decoder layer), B=1, T=2: the emulator executes every lane as a fiber
+    cfg, ocfg = small_model(emu)
+    model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
+    shapes = O.param_shapes(ocfg)
+    weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    batch = synth.make_batch(1, 2, seed=4)
+    tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
+    pk = {"loader": [tb], "sampler": None}
+    tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=0)
+
+    ot = O.OracleTrainer(weights, ocfg)
+    oloss, ometrics, ocmds, opars = ot.loss_and_grads(batch)
+    # (1) reference-style sequence: model(inputs) -> compute_loss -> backward, gradients through the autograd bridge
+    bd = tr.prepare_batch(tb)
+    preds = model(tr._prepare_model_inputs(bd, False))
+    assert U.relerr(preds[1], opars) < 1e-5
+    loss, metrics = tr.compute_loss(preds, bd["actions"][:, 1:])
+    assert metrics == ometrics
+    loss.backward()
+    worst = max((U.relerr(p.grad, ot.P[n].grad), n) for n, p in model.named_parameters() if float(ot.P[n].grad.norm()) > 0)
+    assert worst[0] < 2e-4, worst
+    # (2) fused native step == oracle step
+    total = ot.apply_grads({k: p.grad for k, p in ot.P.items()})
+    loss2, metrics2 = tr._process_batch(tb)
+    assert abs(float(loss2) - float(oloss)) < 1e-5 * abs(float(oloss)) and metrics2 == ometrics
+    d = max(float((p.detach() - ot.P[n].detach()).abs().max()) for n, p in model.named_parameters())
+    assert d < 2e-6, d
+
+
+def _ddp_worker(rank, world, port, tmp, q):
+    import torch.distributed as dist
+    os.chdir(tmp)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        emu = U.load_emu()
+        cfg, ocfg = small_model(emu)
+        model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
+        shapes = O.param_shapes(ocfg)
+        model.load_state_dict({k: torch.from_numpy(synth.make_param(k, s)) for k, s in shapes.items()}, strict=True)
+        batch = synth.make_batch(1, 2, seed=10 + rank)
+        tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
+        pk = {"loader": [tb], "sampler": None}
+        tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=rank)
+        assert tr.gradsync.world == world
+        tr._process_batch(tb)
+        if rank == 0:
+            q.put({n: p.detach().clone().numpy() for n, p in model.named_parameters()})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel_step_matches_mean_of_gradients(tmp_path):
+    """world_size=2 over gloo on the CPU (kernels under the emulator): rank-local backward, bucketed all-reduce(SUM) of
+    the flat gradient buffer, 1/world folded into Adam  ==  clip+Adam on the mean of the two ranks' oracle gradients
+    (what DDP does at reference experiment.py:104-109)."""
+    import torch.multiprocessing as mp
+    U.load_emu()                                    # build once before forking
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = q.get(timeout=900)
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    _, ocfg = small_model(None)
+    shapes = O.param_shapes(ocfg)
+    weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
+    ot = O.OracleTrainer(weights, ocfg)
+    gsum = None
+    for r in range(2):
+        ot.loss_and_grads(synth.make_batch(1, 2, seed=10 + r))
+        g = {k: p.grad.clone() for k, p in ot.P.items()}
+        gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
+    gavg = {k: v / 2 for k, v in gsum.items()}
+    ot.apply_grads(gavg)
+    # Adam's first step is lr * g / (|g| + eps): elements whose gradient is numerical noise around zero (e.g. the key
+    # bias of every attention: softmax is shift-invariant, so its true gradient is 0) are ill-conditioned by
+    # construction — in the reference too — and are only required to move by at most lr.
+    worst_sig, worst_noise = ("", 0.0), ("", 0.0)
+    for n in got:
+        diff = np.abs(got[n] - ot.P[n].detach().numpy())
+        sig = np.abs(gavg[n].numpy()) > 1e-6
+        if sig.any() and diff[sig].max() > worst_sig[1]:
+            worst_sig = (n, float(diff[sig].max()))
+        if (~sig).any() and diff[~sig].max() > worst_noise[1]:
+            worst_noise = (n, float(diff[~sig].max()))
+    assert worst_sig[1] < 2e-6, worst_sig
+    assert worst_noise[1] <= 2.1e-5, worst_noise

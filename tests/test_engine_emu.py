@@ -13,7 +13,7 @@ from videocad_amd.engine import NativeEngine, make_config
 
 def small_cfg(**over):
     cfg = dict(O.CANONICAL_CONFIG)
-    cfg.update(vit_depth=2, num_decoder_layers=2, window_size=2, max_ep_len=16)
+    cfg.update(vit_depth=1, num_decoder_layers=2, window_size=2, max_ep_len=16)
     cfg.update(over)
     return cfg
 

@@ -1,0 +1,60 @@
+"""Per-shape GEMM timing through the C ABI (the shapes one C2 train step launches).  Usage: python tools/gemm_bench.py"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videocad_amd import lib as L
+
+lib = L.load()
+dev = "cuda:0"
+BF, F32 = torch.bfloat16, torch.float32
+TD = {F32: 0, BF: 1}
+scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+
+
+def run(name, M, N, K, sa=BF, sb=BF, to=BF, tra=0, trb=0, bias=False, res=False, iters=20):
+    A = torch.randn((K, M) if tra else (M, K), device=dev).to(sa)
+    B = torch.randn((K, N) if trb else (N, K), device=dev).to(sb)
+    Cm = torch.empty(M, N, dtype=to, device=dev)
+    bias_t = torch.randn(N, device=dev) if bias else None
+    res_t = torch.randn(M, N, device=dev) if res else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call():
+        rc = lib.vcad_op_gemm(1, TD[sa], TD[sb], TD[to], tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0,
+                              p(res_t), N, 1.0, p(scratch), scratch.numel(), st)
+        assert rc == 0, lib.vcad_last_error()
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    print(f"{name:34s} M={M:6d} N={N:5d} K={K:6d} tra={tra} trb={trb} {str(sa)[6:]:>8s}->{str(to)[6:]:<8s} {ms*1e3:8.1f} us  {tf:7.1f} TF/s", flush=True)
+
+
+R = 104000
+run("vit qkv fwd", R, 3072, 512)
+run("vit out fwd (+res, f32 out)", R, 512, 1024, to=F32, bias=True, res=True)
+run("vit mlp1 fwd", R, 512, 512, bias=True)
+run("vit mlp2 fwd (+res, f32 out)", R, 512, 512, to=F32, bias=True, res=True)
+run("patch embed fwd (f32 out)", 101920, 512, 1024, to=F32, bias=True)
+run("vit dqkv dgrad", R, 512, 3072, trb=1)
+run("vit dao dgrad (f32 A)", R, 1024, 512, sa=F32, trb=1)
+run("vit dz dgrad (f32 A)", R, 512, 512, sa=F32, trb=1)
+run("vit qkv wgrad", 3072, 512, R, to=F32, tra=1, trb=1)
+run("vit out wgrad (f32 A)", 512, 1024, R, sa=F32, to=F32, tra=1, trb=1)
+run("vit mlp wgrad", 512, 512, R, to=F32, tra=1, trb=1)
+run("dec in_proj fwd (f32 A)", 2048, 3072, 1024, sa=F32, bias=True)
+run("dec 1024x1024 fwd (+res)", 2048, 1024, 1024, to=F32, bias=True, res=True)
+run("heads fwd (f32 A, f32 out)", 2048, 6000, 1024, sa=F32, to=F32, bias=True)
+run("heads wgrad (f32 A, f32 B)", 6000, 1024, 2048, sa=F32, sb=F32, to=F32, tra=1, trb=1)
+run("square 4096 (reference point)", 4096, 4096, 4096)
+run("square 8192 (reference point)", 8192, 8192, 8192)

@@ -1,0 +1,235 @@
+"""Drop-in `AutoRegressiveTransformer` (reference model/autoregressive_transformer.py:6-275) whose arithmetic runs in
+libvcad_hip.so.  Same constructor kwargs, same `forward(inputs) -> (cmds [B,T,5], params [B,T,6,1000])`, same
+`state_dict()` keys for every LIVE parameter, same helpers (`apply_action_mask`,
+`normalize_actions`, `sequential_inference`).
+
+Differences that are deliberate and documented in DESIGN.md:
+  * the 77.6 M dead parameters of the reference (GPT-2 trunk, embed_timestep, embed_ln, predict_action — constructed at
+    model/base_transformer.py:38-60 but never used by forward) are not materialised; the reference loads checkpoints with
+    strict=False (model/model_factory.py:35) so both directions interoperate
+  * parameters are views into ONE flat fp32 buffer (and `.grad` views into one flat gradient buffer) so that clipping,
+    Adam and the RCCL all-reduce run over contiguous memory
+  * wiring implemented natively: encoder="vit", enable_past_states and enable_past_actions both True (the configuration
+    `main.py` and the README run); other wirings raise NotImplementedError instead of silently computing something else
+  * dropout: the native path currently runs with p = 0 (DESIGN.md "Known gaps")
+There is no CPU fallback: calling forward on a non-CUDA module raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .engine import NativeEngine, make_config
+
+
+class _Holder(nn.Module):
+    """Parameter container mirroring the reference module tree (no compute).  Numeric children index like the
+    reference's ModuleList / Sequential (`transformer_decoder.layers[3]`, `transformer.layers[i][0]`)."""
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return sum(1 for k in self._modules if k.isdigit())
+
+    def __iter__(self):
+        return (self._modules[k] for k in sorted((k for k in self._modules if k.isdigit()), key=int))
+
+
+def _attach(root: nn.Module, dotted: str, p: nn.Parameter):
+    parts = dotted.split(".")
+    m = root
+    for part in parts[:-1]:
+        if not hasattr(m, part):
+            m.add_module(part, _Holder())
+        m = getattr(m, part)
+    m.register_parameter(parts[-1], p)
+
+
+class _EngineFn(torch.autograd.Function):
+    """autograd bridge: forward -> vcad_forward, backward -> vcad_backward (gradients land in the flat grad buffer and
+    are handed to autograd as views, so `loss.backward()`, `clip_grad_norm_` and torch optimisers work unchanged)."""
+
+    @staticmethod
+    def forward(ctx, model, frames, actions, cad, *params):
+        cmds, pars = model._engine.forward(frames, actions, cad)
+        ctx.model = model
+        return cmds, pars
+
+    @staticmethod
+    def backward(ctx, dcmds, dpars):
+        model = ctx.model
+        eng = model._engine
+        eng.backward(dcmds.contiguous(), dpars.reshape(dpars.shape[0], dpars.shape[1], -1).contiguous())
+        grads = tuple(eng.view(n, eng.grads) for n in model._param_names)
+        return (None, None, None, None) + grads
+
+
+class AutoRegressiveTransformer(nn.Module):
+    def __init__(self, state_dim, act_dim, hidden_size, max_length=None, max_ep_len=1000, action_tanh=True,
+                 enable_past_actions=False, enable_past_states=False, enable_timestep_embedding=False, num_classes=5,
+                 num_params=6, num_params_values=1000, num_decoder_layers=8, dim_feedforward=512,
+                 use_pretrained_cad_model=False, nhead=4, dropout=0.1, normalize=False, device=None, encoder="vit",
+                 num_views=0, window_size=1, compute_dtype: str = "bf16", _lib=None, **kwargs):
+        super().__init__()
+        assert window_size > 0, "Window size must be greater than 0"          # reference :52
+        if encoder != "vit" or use_pretrained_cad_model:
+            raise NotImplementedError(f"encoder={encoder!r}/gencad is out of scope of the MI355X path (needs torchvision weights; "
+                                      "reference model/trajectory_model.py:68-74)")
+        if not (enable_past_actions and enable_past_states):
+            raise NotImplementedError("native wiring covers enable_past_actions=True & enable_past_states=True "
+                                      "(reference :190-197); other branches are listed under 'next' in DESIGN.md")
+        if num_views:
+            raise NotImplementedError("multiview branch (reference :167-170) is not on the hot path (SURVEY §8 f4)")
+        self.state_dim, self.act_dim, self.hidden_size = state_dim, act_dim, hidden_size
+        self.max_length, self.max_ep_len = max_length, max_ep_len
+        self.enable_past_actions, self.enable_past_states = enable_past_actions, enable_past_states
+        self.enable_timestep_embedding = enable_timestep_embedding
+        self.window_size, self.normalize, self.num_views = window_size, normalize, num_views
+        self.use_pretrained_cad_model = use_pretrained_cad_model
+        self.num_inputs = 2
+        self.state_embedding_model_size = self.cad_embedding_model_size = 512
+        self.dropout_p = dropout
+        self.compute_dtype = compute_dtype
+        dt = L.VCAD_BF16 if compute_dtype == "bf16" else L.VCAD_F32
+        cfg = make_config(hidden_size=hidden_size, nhead=nhead, num_decoder_layers=num_decoder_layers,
+                          dim_feedforward=dim_feedforward, window_size=window_size, act_dim=act_dim, num_classes=num_classes,
+                          num_params=num_params, num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dt,
+                          **{k: kwargs[k] for k in ("vit_depth",) if k in kwargs})    # extension (tests): shallower ViT
+        self._engine = NativeEngine(cfg, "cpu", lib=_lib)
+        self._param_names = list(self._engine.table.keys())
+        for name in self._param_names:
+            _attach(self, name, nn.Parameter(self._engine.view(name), requires_grad=True))
+        self._plist = [dict(self.named_parameters())[n] for n in self._param_names]
+        self._shadow_fresh = False
+        self.reset_parameters()
+        if not enable_timestep_embedding:                                     # reference :144-147: zeros instead of the table
+            with torch.no_grad():
+                self.timestep_embedding.weight.zero_()
+            self.timestep_embedding.weight.requires_grad_(False)
+        self.action_mask = torch.tensor([[1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 1, 0],
+                                         [0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0]]).float()   # reference :83-89 (plain attribute)
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------------ parameters
+    @torch.no_grad()
+    def reset_parameters(self):
+        """PyTorch-default initialisation of the reference modules (SURVEY.md Appendix A 'Init')."""
+        import math
+        for name, p in self.named_parameters():
+            leaf = name.rsplit(".", 1)[-1]
+            if name.endswith("pos_embedding") or name.endswith("cls_token") or name.startswith("timestep_embedding"):
+                p.normal_(0.0, 1.0)
+            elif p.dim() == 1 and ("norm" in name or "to_patch_embedding.1." in name or "to_patch_embedding.3." in name or ".net.0." in name):
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif name.endswith("in_proj_weight"):
+                nn.init.xavier_uniform_(p)
+            elif name.endswith("in_proj_bias") or name.endswith("out_proj.bias"):
+                p.zero_()
+            elif p.dim() == 2:
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            else:   # Linear bias: U(+-1/sqrt(fan_in)) with fan_in of the matching weight
+                w = dict(self.named_parameters()).get(name[: -len("bias")] + "weight")
+                bound = 1.0 / math.sqrt(w.shape[1]) if w is not None and w.dim() == 2 else 0.02
+                p.uniform_(-bound, bound)
+        self._shadow_fresh = False
+
+    def _apply(self, fn, recurse=True):
+        """`.to(device)` / `.cuda()`: move the flat buffer once and re-point every parameter at its view."""
+        probe = fn(torch.empty(0, dtype=torch.float32, device=self._engine.params.device))
+        if probe.dtype != torch.float32:
+            raise TypeError("master weights stay fp32 (the compute dtype is chosen with compute_dtype=...)")
+        if probe.device != self._engine.params.device:
+            self._engine.allocate(probe.device, params=self._engine.params)
+            for name in self._param_names:
+                mod, leaf = self, name
+                parts = name.split(".")
+                for part in parts[:-1]:
+                    mod = getattr(mod, part)
+                p = mod._parameters[parts[-1]]
+                p.data = self._engine.view(name)
+                p.grad = None
+            self._shadow_fresh = False
+        self.action_mask = fn(self.action_mask)
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        own = set(self._param_names)
+        filtered = {k: v for k, v in state_dict.items() if k in own}
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}, unexpected {unexpected[:5]} "
+                               "(the reference's dead GPT-2 parameters are not materialised; use strict=False)")
+        with torch.no_grad():
+            for k, v in filtered.items():
+                self._engine.view(k).copy_(v.to(self._engine.params.device, torch.float32))
+        self._shadow_fresh = False
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    def mark_shadow_fresh(self):
+        """The native optimiser step rewrites the bf16 weight shadow itself; anything else (torch optimisers,
+        load_state_dict, manual edits) leaves it stale, so forward re-casts it unless this was called."""
+        self._shadow_fresh = True
+
+    # ------------------------------------------------------------------ reference helpers
+    def apply_action_mask(self, cmd_pred, param_pred):
+        """reference model/autoregressive_transformer.py:91-108 (cmd_pred [B,T] int, param_pred [B,T,6])"""
+        mask = self.action_mask.to(cmd_pred.device)[cmd_pred]
+        masked = param_pred.clone()
+        masked[mask == 0] = -1
+        masked[:, :, 3] = torch.where((masked[:, :, 2] >= 200) & (masked[:, :, 2] < 250), masked[:, :, 3], -1)
+        return masked
+
+    def process_actions(self, actions):
+        raise NotImplementedError("fused into the native forward (embed_action kernel)")
+
+    def normalize_actions(self, actions):
+        """in-place, like the reference (:115-118)"""
+        actions[:, :, 0] = actions[:, :, 0] / 4.0
+        actions[:, :, 1:] = actions[:, :, 1:] / 1000.0
+        return actions
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs, attention_mask=None):
+        """inputs: dict with 'frames' [B,T,1,224,224], 'actions' [B,T,7] (normalised), 'cad_image' [B,1,224,224]
+        ('timesteps' is ignored exactly as in the reference, :144).  Returns (cmds [B,T,5], params [B,T,6,1000])."""
+        frames, actions, cad = inputs["frames"], inputs["actions"], inputs["cad_image"]
+        if inputs.get("multiview_images", None) is not None and self.num_views > 0:
+            raise NotImplementedError("multiview")
+        if self._engine.params.device.type != "cuda" and self._engine.lib is L._lib:
+            raise RuntimeError("videocad_amd has no CPU fallback: move the model to a ROCm device (model.to('cuda'))")
+        if not self._shadow_fresh:
+            self._engine.sync_shadow()
+        self._shadow_fresh = False
+        frames = frames.float(); actions = actions.float(); cad = cad.float()
+        if torch.is_grad_enabled():
+            cmds, pars = _EngineFn.apply(self, frames, actions, cad, *self._plist)
+        else:
+            cmds, pars = self._engine.forward(frames, actions, cad)
+        return cmds, pars
+
+    @torch.no_grad()
+    def sequential_inference(self, ui_images, cad_image, action=False):
+        """reference :222-275 (step-by-step prediction; re-encodes the prefix each step like the reference does)"""
+        B, T = ui_images.shape[:2]
+        device = ui_images.device
+        cmds_out, pars_out = [], []
+        actions = torch.zeros(B, 1, self.act_dim, device=device) if action else None
+        for t in range(T):
+            inputs = {"frames": ui_images[:, : t + 1], "actions": actions if action else torch.zeros(B, t + 1, 7, device=device),
+                      "timesteps": torch.arange(t + 1, device=device), "cad_image": cad_image}
+            cmd, params = self.forward(inputs)
+            if action:
+                # (the reference indexes a [B,6] tensor with [:, :, 3] here and raises; we keep the time axis so it runs)
+                cmd_pred = torch.argmax(cmd[:, -1:], dim=-1)                       # [B,1]
+                param_pred = torch.argmax(params[:, -1:], dim=-1)                  # [B,1,6]
+                nxt = self.apply_action_mask(cmd_pred, param_pred).float()
+                nxt = torch.cat([cmd_pred.unsqueeze(-1).float(), nxt], dim=2)      # [B,1,7]
+                actions = torch.cat([actions, self.normalize_actions(nxt)], dim=1)
+            cmds_out.append(cmd[:, -1].clone()); pars_out.append(params[:, -1].clone())
+        return torch.stack(cmds_out, dim=1), torch.stack(pars_out, dim=1)

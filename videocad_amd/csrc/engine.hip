@@ -151,8 +151,8 @@ void build_params(vcad_engine* e) {
         e->wv[v].normb = add_param(e, pre + "transformer.norm.bias", {(long)c.vit_dim});
         const int split = c.vit_depth / 2;
         for (int L = c.vit_depth - 1; L >= 0; --L) {
-            if (v == 0 && L == split - 1) { e->buckets.push_back({bb, e->ptotal}); bb = e->ptotal; }
             add_vit_layer(e, v, pre, L);
+            if (v == 0 && L == split) { e->buckets.push_back({bb, e->ptotal}); bb = e->ptotal; }   // stage 2 = final norm + layers >= split
         }
         add_vit_embed(e, v, pre);
         e->buckets.push_back({bb, e->ptotal});
@@ -526,7 +526,9 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (cfg->window_size < 1) { vc_set_error("window_size must be > 0 (reference model/autoregressive_transformer.py:52)"); return VC_ERR_ARG; }
     vcad_engine* e = new vcad_engine();
     e->c = *cfg; e->dt = cfg->dtype; e->esz = cfg->dtype == VCAD_BF16 ? 2 : 4;
+    if (cfg->vit_depth < 1 || cfg->num_decoder_layers < 1) { vc_set_error("vit_depth / num_decoder_layers must be >= 1"); delete e; return VC_ERR_ARG; }
     build_params(e);
+    if ((int)e->buckets.size() != NB_BUCKETS) { vc_set_error("internal: %d buckets", (int)e->buckets.size()); delete e; return VC_ERR_ARG; }
     *out = e;
     return 0;
 }
@@ -610,6 +612,12 @@ int vcad_loss(vcad_engine* e, const float* cmds, const float* pars, const float*
     CK(vc_loss_bwd(p, s));
     if (loss_out) CK(vc_memcpy_d2d_async(loss_out, e->loss_small, 8 * 4, s));
     if (metrics_out) CK(vc_memcpy_d2d_async(metrics_out, e->loss_metrics, VC_NMETRIC * 4, s));
+    return 0;
+}
+
+int vcad_dlogits_offsets(const vcad_engine* e, size_t* off_cmds, size_t* off_params) {
+    if (!e->ws || !e->B) { vc_set_error("vcad_dlogits_offsets: no forward yet"); return VC_ERR_ARG; }
+    *off_cmds = (size_t)((const char*)e->dl_cmds - e->ws); *off_params = (size_t)((const char*)e->dl_pars - e->ws);
     return 0;
 }
 

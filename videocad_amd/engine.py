@@ -111,6 +111,15 @@ class NativeEngine:
         self._keep_t = targets
         return out, met
 
+    def dl_views(self, B: int, T: int):
+        """(dcmds [B,T,5], dparams [B,T,6000]) fp32 views of the workspace region vcad_loss filled."""
+        oc, op = C.c_size_t(), C.c_size_t()
+        L.check(self.lib, self.lib.vcad_dlogits_offsets(self.h, C.byref(oc), C.byref(op)), "dlogits_offsets")
+        nc, npar = self.cfg.num_classes, self.cfg.num_params * self.cfg.num_params_values
+        dc = self.ws[oc.value: oc.value + B * T * nc * 4].view(torch.float32).view(B, T, nc)
+        dp = self.ws[op.value: op.value + B * T * npar * 4].view(torch.float32).view(B, T, npar)
+        return dc, dp
+
     def backward(self, dcmds=None, dpars=None, stage: Optional[int] = None):
         if dcmds is not None:
             dcmds = dcmds.contiguous().float(); dpars = dpars.contiguous().float()

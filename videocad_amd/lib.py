@@ -44,6 +44,7 @@ PROTOTYPES = {
     "vcad_set_workspace": (_i, [_vp, _vp, _sz]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "vcad_dlogits_offsets": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "vcad_backward": (_i, [_vp, _vp, _vp, _vp]),
     "vcad_backward_stage": (_i, [_vp, _i, _vp, _vp, _vp]),
     "vcad_optimizer_step": (_i, [_vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
