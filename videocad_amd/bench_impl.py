@@ -79,13 +79,10 @@ class Stepper:
         return loss, met
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle restatement (fp32 PyTorch-CPU, validated against the imported reference) timed on this host's cores on a
-    bounded sample of the same workload.  Reported baseline only."""
+def _cpu_baseline_worker(q, threads, seconds_budget):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import restatement as O
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    torch.set_num_threads(threads)
     shapes = O.param_shapes()
     weights = {k: synth.make_param_torch(k, s, "cpu").numpy() for k, s in shapes.items()}
     ot = O.OracleTrainer(weights)
@@ -98,8 +95,29 @@ def cpu_baseline(seconds_budget=25.0):
         if time.time() - t0 > seconds_budget or n >= 20:
             break
     dt = time.time() - t0
-    return {"value": round(B * T * n / dt, 2), "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": f"{n} full train steps of the oracle restatement at B={B},T={T} (fp32, torch {torch.__version__} CPU)"}
+    q.put({"value": round(B * T * n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{n} full train steps of the oracle restatement at B={B},T={T} (fp32, torch {torch.__version__} CPU, "
+                     f"{threads} threads of {os.cpu_count()} host cores)"})
+
+
+def cpu_baseline(seconds_budget=20.0, hard_limit=150.0):
+    """The oracle restatement (fp32 PyTorch-CPU, validated against the imported reference) timed on this host's cores on a
+    bounded sample of the same workload, in a child process with a hard wall-clock limit.  Reported baseline only.
+    (Thread count is capped at 32: on a 256-core host the intra-op pool thrashes and one step takes minutes.)"""
+    import multiprocessing as mp
+    threads = min(os.cpu_count() or 1, 32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    pr = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, seconds_budget))
+    pr.start()
+    try:
+        out = q.get(timeout=hard_limit)
+    except Exception:
+        out = {"value": None, "unit": "frames/s", "cores": threads, "kind": "port", "sample": f"did not finish within {hard_limit:.0f} s"}
+    pr.join(timeout=5)
+    if pr.is_alive():
+        pr.terminate()
+    return out
 
 
 def run(args):

@@ -23,14 +23,23 @@ constexpr int AM_T = 64;          // padded tokens
 constexpr int AM_D = 64;          // head dim
 constexpr int AM_S = 72;          // LDS row stride (elements): 144 B -> conflict-free ds_read_b128 fragments
 
-// stage one [T x 64] bf16 head slice into a wave-private LDS tile (rows >= T zero-filled)
+// stage one [T x 64] bf16 head slice into a wave-private LDS tile (rows >= T zero-filled).  All eight 16-byte loads
+// are issued back to back on a clamped row index (a per-load bounds branch would make hipcc wait for each load in turn);
+// the zero fill is a select after the loads.
 VC_DEV void am_stage(vc_bf16* tile, const vc_bf16* g, long ld, int T, int lane) {
+    vc_u32x4 v[AM_T / 8];
 #pragma unroll
     for (int it = 0; it < AM_T / 8; ++it) {
         const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
-        vc_u32x4 v; v.x = v.y = v.z = v.w = 0u;
-        if (row < T) v = *reinterpret_cast<const vc_u32x4*>(g + (long)row * ld + c);
-        *reinterpret_cast<vc_u32x4*>(tile + row * AM_S + c) = v;
+        const int rr = row < T ? row : T - 1;
+        v[it] = *reinterpret_cast<const vc_u32x4*>(g + (long)rr * ld + c);
+    }
+#pragma unroll
+    for (int it = 0; it < AM_T / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        vc_u32x4 w = v[it];
+        if (row >= T) { w.x = 0u; w.y = 0u; w.z = 0u; w.w = 0u; }
+        *reinterpret_cast<vc_u32x4*>(tile + row * AM_S + c) = w;
     }
 }
 // direct fragment: row = row0 + (lane&31), 8 consecutive d at ks*16 + 8*(lane>>5)

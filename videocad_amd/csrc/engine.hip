@@ -296,24 +296,40 @@ int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bst
         CK(vc_ln_fwd(VC_F32, VC_F32, D, 2, p, cx.s));
     }
     const float* x = a.x0;
+    const long TD = (long)(P + 1) * D, TI = (long)(P + 1) * inner;      // per-frame strides: cls rows are rows n*(P+1)
     for (int L = 0; L < c.vit_depth; ++L) {
         const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
+        // Only the cls token of the LAST layer is consumed (pool='cls'): its Q projection, attention output, out-proj and
+        // MLP are computed for the cls row only; K/V still need every token.  Same numbers, ~60 % less work in that layer.
+        const bool cls_only = (L == c.vit_depth - 1);
+        const float scale = 1.0f / sqrtf((float)c.vit_dim_head);
+        const char* q = (const char*)l.qkv;
         CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D));
-        CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
-        {
-            AttnParams p; memset(&p, 0, sizeof(p));
-            const char* q = (const char*)l.qkv;
-            p.q = q; p.k = q + (size_t)inner * e->esz; p.v = q + (size_t)2 * inner * e->esz; p.o = l.ao;
-            p.ldq = p.ldk = p.ldv = 3 * inner; p.ldo = inner; p.lse = l.lse;
-            p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
-            CK(vc_attn_fwd(e->dt, c.vit_dim_head, p, cx.s));
+        AttnParams ap; memset(&ap, 0, sizeof(ap));
+        ap.q = q; ap.k = q + (size_t)inner * e->esz; ap.v = q + (size_t)2 * inner * e->esz; ap.o = l.ao;
+        ap.ldq = ap.ldk = ap.ldv = 3 * inner; ap.ldo = inner; ap.lse = l.lse;
+        ap.B = (int)N; ap.H = c.vit_heads; ap.Tq = ap.Tk = P + 1; ap.window = P + 1; ap.causal = 0; ap.scale = scale;
+        if (!cls_only) {
+            CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
+            CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
+            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
+            CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
+            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp;
+              CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
+            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D;
+              CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
+        } else {
+            CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv + (long)inner * D, D), cx.AT(q + (size_t)inner * e->esz, 3 * inner), (int)R, 2 * inner, D, Epi()));   // K, V: all tokens
+            CK(cx.lin_fwd(cx.AT(l.h_a, TD), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * TI), (int)N, inner, D, Epi()));                                       // Q: cls rows
+            ap.Tq = 1; ap.ldq = 3 * TI; ap.ldo = TI;                                   // query row b -> cls row of frame b
+            CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
+            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = TD; CK(cx.lin_fwd(cx.AT(l.ao, TI), cx.W(wl.ow, inner), cx.A32(l.xm, TD), (int)N, D, inner, ep)); }
+            CK(cx.ln_fwd(VC_F32, l.xm, TD, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, N, D));                   // h_f, z, g: compact [N, .]
+            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp;
+              CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)N, c.vit_mlp, D, ep)); }
+            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = TD;
+              CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, TD), (int)N, D, c.vit_mlp, ep)); }
         }
-        { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
-        CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
-        { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp;
-          CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
-        { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D;
-          CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
         x = l.xo;
     }
     // final LN on the cls row only (pool = 'cls', mlp_head = Identity)
@@ -336,19 +352,23 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         const float* xl = a.L[c.vit_depth - 1].xo;
         CK(cx.ln_bwd(VC_F32, de, D, xl, (long)(P + 1) * D, a.statn, w.normw, w.normb, nullptr, 0, dx, (long)(P + 1) * D, N, D));
     }
+    const long TD = (long)(P + 1) * D, TI = (long)(P + 1) * inner;
     for (int L = Lhi; L >= Llo; --L) {
         const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
         const float* xin = L == 0 ? a.x0 : a.L[L - 1].xo;
+        const bool cls_only = (L == c.vit_depth - 1);          // see vit_forward: dx is non-zero on cls rows only here
+        const long Rm = cls_only ? N : R;                       // rows the MLP / out-proj backward runs over
+        const long ldx = cls_only ? TD : D, ldao = cls_only ? TI : inner;
         // MLP
-        CK(cx.lin_wgrad(cx.A32(dx, D), cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)R, D, c.vit_mlp));
+        CK(cx.lin_wgrad(cx.A32(dx, ldx), cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU;
-          CK(cx.lin_dgrad(cx.A32(dx, D), cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)R, D, c.vit_mlp, ep)); }
-        CK(cx.lin_wgrad(cx.AT(e->t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)R, c.vit_mlp, D));
-        CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)R, c.vit_mlp, D, Epi()));
-        CK(cx.ln_bwd(e->dt, e->t_dh, D, l.xm, D, l.stat_f, wl.fnw, wl.fnb, dx, D, dx, D, R, D));
+          CK(cx.lin_dgrad(cx.A32(dx, ldx), cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
+        CK(cx.lin_wgrad(cx.AT(e->t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
+        CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
+        CK(cx.ln_bwd(e->dt, e->t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D));
         // attention block
-        CK(cx.lin_wgrad(cx.A32(dx, D), cx.AT(l.ao, inner), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)R, D, inner));
-        CK(cx.lin_dgrad(cx.A32(dx, D), cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)R, D, inner, Epi()));
+        CK(cx.lin_wgrad(cx.A32(dx, ldx), cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
+        CK(cx.lin_dgrad(cx.A32(dx, ldx), cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
         {
             AttnParams p; memset(&p, 0, sizeof(p));
             const char* q = (const char*)l.qkv; char* dq = (char*)e->t_dqkv;
@@ -357,6 +377,10 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             p.dout = e->t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
             p.lddq = p.lddk = p.lddv = 3 * inner;
             p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
+            if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero
+                CK(vc_memset_async(e->t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
+                p.Tq = 1; p.ldq = 3 * TI; p.lddq = 3 * TI;
+            }
             CK(vc_attn_bwd(e->dt, c.vit_dim_head, p, cx.s));
         }
         CK(cx.lin_wgrad(cx.AT(e->t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));

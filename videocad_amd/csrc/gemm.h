@@ -26,6 +26,7 @@ struct GemmParams {
     int M, N, K;
     long lda, ldb, ldc;
     int vecA, vecB;                 // 16-byte vector loads legal for A / B (host-checked alignment)
+    int vecC;                       // every epilogue tensor (C, residual, aux, dact_src, rowadd) allows 4-column vector rows
     // split-K: gridDim.z slices of k_per_split; partials (fp32, [z][M][N]) go to `partial`, epilogue runs in the reducer
     int k_per_split; float* partial;
     // epilogue (applied in this order): v = alpha*acc (+bias[n]) (+rowadd[row(m)][n]); aux[m,n]=v; v=act(v); v*=dact(src[m,n]); v+=residual[m,n]
@@ -110,6 +111,27 @@ VC_DEV void gemm_epilogue_tile(const GemmParams& p, int mbase, int n, const vc_f
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) vc_st(((TO*)p.C) + (long)(mbase + (r & 3) + 8 * (r >> 2)) * p.ldc + n, v[r]);
+}
+
+// 4-column vector accesses for the row-wise epilogue
+VC_DEV void quad_ld_f32(const float* p, float* v) {
+    const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p);
+    v[0] = vc_bits_f32(q.x); v[1] = vc_bits_f32(q.y); v[2] = vc_bits_f32(q.z); v[3] = vc_bits_f32(q.w);
+}
+template <typename T> VC_DEV void quad_ld(const T* p, float* v);
+template <> VC_DEV void quad_ld<float>(const float* p, float* v) { quad_ld_f32(p, v); }
+template <> VC_DEV void quad_ld<vc_bf16>(const vc_bf16* p, float* v) {
+    const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p);
+    v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u);
+}
+template <typename T> VC_DEV void quad_st(T* p, const float* v);
+template <> VC_DEV void quad_st<float>(float* p, const float* v) {
+    vc_u32x4 q; q.x = vc_f32_bits(v[0]); q.y = vc_f32_bits(v[1]); q.z = vc_f32_bits(v[2]); q.w = vc_f32_bits(v[3]);
+    *reinterpret_cast<vc_u32x4*>(p) = q;
+}
+template <> VC_DEV void quad_st<vc_bf16>(vc_bf16* p, const float* v) {
+    vc_u32x2 q; q.x = vc_pack_bf16x2(v[0], v[1]); q.y = vc_pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<vc_u32x2*>(p) = q;
 }
 
 template <typename CT> struct GemmCfg;
@@ -245,7 +267,16 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2s), so give each XCD a contiguous
+    // run of tiles, n fastest: the blocks that share one 128-row A panel (and sweep the small B) hit the same L2.
+    int tile_m, tile_n;
+    {
+        const int nx = gridDim.x, total = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any total
+        tile_m = t / nx; tile_n = t - tile_m * nx;
+    }
+    const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? (kbeg + p.k_per_split) : p.K;
     const int nt = (kend - kbeg + BK - 1) / BK;
@@ -321,7 +352,57 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     }
 
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (!p.partial && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {        // interior block (uniform): batched path
+    if (!p.partial && p.vecC && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {
+        // Interior block: stage the fp32 tile through LDS (free after the last barrier) and run the epilogue on whole
+        // rows — residual / activation-source loads and the final stores are coalesced 16-byte (fp32) or 8-byte (bf16)
+        // accesses of 512/256-byte row segments instead of 64 strided scalars per lane.
+        constexpr int ES = GEMM_BN + 4;                              // fp32 row stride (pad: conflict-free column writes)
+        static_assert(GEMM_BM * ES * 4 <= gemm_lds_bytes<CT, TRA, TRB>(), "epilogue tile must fit the staging LDS");
+        float* et = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    et[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ES + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+        vc_sync();
+        const int c4 = (tid & 31) * 4, n = n0 + c4;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) quad_ld_f32(p.bias + n, b4);
+#pragma unroll 4
+        for (int pass = 0; pass < GEMM_BM / 8; ++pass) {
+            const int row = pass * 8 + (tid >> 5), m = m0 + row;
+            float v[4];
+            quad_ld_f32(et + row * ES + c4, v);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = p.alpha * v[k] + b4[k];
+            if (p.rowadd) {
+                const int rr = p.rowadd_mod ? (m % p.rowadd_div) : (m / p.rowadd_div);
+                float a4[4]; quad_ld_f32(p.rowadd + (long)rr * p.ld_rowadd + n, a4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += a4[k];
+            }
+            if (p.aux) quad_st<TO>(((TO*)p.aux) + (long)m * p.ldaux + n, v);
+            if (p.act) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = vc_apply_act(v[k], p.act);
+            }
+            if (p.dact_src) {
+                float s4[4]; quad_ld<TO>(((const TO*)p.dact_src) + (long)m * p.lddact + n, s4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = vc_apply_dact(v[k], s4[k], p.dact_kind);
+            }
+            if (p.residual) {
+                float q4[4]; quad_ld_f32(p.residual + (long)m * p.ldr + n, q4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += q4[k];
+            }
+            quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
+        }
+        return;
+    }
+    if (!p.partial && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {        // interior block, unaligned tensors: batched scalar path
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);

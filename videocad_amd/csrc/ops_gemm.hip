@@ -71,6 +71,13 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
     p.vecA = (((uintptr_t)p.A) % 16 == 0) && ((p.lda * dsize(c.sa)) % 16 == 0);
     p.vecB = (((uintptr_t)p.B) % 16 == 0) && ((p.ldb * dsize(c.sb)) % 16 == 0);
+    {   // row-wise vector epilogue: every tensor it touches must allow aligned 4-column accesses
+        auto ok = [](const void* q, long ld, size_t es) { return !q || (((uintptr_t)q % 16 == 0) && ((ld * es) % 16 == 0)); };
+        const size_t eo = dsize(c.to);
+        p.vecC = (p.N % 4 == 0) && ok(p.C, p.ldc, eo) && ok(p.residual, p.ldr, 4) && ok(p.aux, p.ldaux, eo) &&
+                 ok(p.dact_src, p.lddact, eo) && ok(p.rowadd, p.ld_rowadd, 4) && ok(p.bias, 4, 4);
+        if (eo == 2) p.vecC = p.vecC && ((uintptr_t)p.C % 8 == 0);
+    }
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
     long tiles = (long)VC_CEIL_DIV(p.M, GEMM_BM) * VC_CEIL_DIV(p.N, GEMM_BN);
     int nsplit = 1;
