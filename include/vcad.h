@@ -96,6 +96,9 @@ int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, floa
 void vcad_profile_begin(void);
 int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launches[8]);
 
+/* test hook: force the GEMM block tile (64 or 128; 0 = automatic choice by problem size) */
+void vcad_debug_force_gemm_tile(int tile);
+
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,

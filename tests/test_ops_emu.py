@@ -14,6 +14,14 @@ def emu():
     return U.load_emu()
 
 
+@pytest.fixture(params=[64, 128], autouse=True)
+def gemm_tile(request, emu):
+    """every test in this file runs with both GEMM block tiles (64x64 and 128x128)"""
+    emu.vcad_debug_force_gemm_tile(request.param)
+    yield request.param
+    emu.vcad_debug_force_gemm_tile(0)
+
+
 @pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_f32_layouts(emu, tra, trb):
     U.check_gemm(emu, "cpu", 70, 40, 50, F32, tra=tra, trb=trb, pad=3, bias=True, residual=True, splitk=False)

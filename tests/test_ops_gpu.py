@@ -15,6 +15,14 @@ def hip():
     return L.load()
 
 
+@pytest.fixture(params=[64, 128], autouse=True)
+def gemm_tile(request, hip):
+    """every test in this file runs with both GEMM block tiles (64x64 and 128x128)"""
+    hip.vcad_debug_force_gemm_tile(request.param)
+    yield request.param
+    hip.vcad_debug_force_gemm_tile(0)
+
+
 @pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gemm_f32_layouts(hip, tra, trb):
     U.check_gemm(hip, DEV, 300, 200, 260, F32, tra=tra, trb=trb, pad=4, bias=True, residual=True, splitk=False)

@@ -207,3 +207,55 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < DPL; ++j) { vc_st(dkrow + j, dk[j] * p.scale); vc_st(dvrow + j, dv[j]); }
 }
+
+
+// ---- single-query attention backward (the ViT's last layer only consumes the cls token: Tq = 1).  One wave per
+// (batch, head): lane = key for the scores / dS (each lane walks its own K and V row), then lane = DPL output dims for
+// dq; dk_j = dS_j q and dv_j = P_j dO are written by the key's lane.  Replaces B*H*Tk one-key waves by B*H waves.
+template <typename T, int DPL>
+VC_KERNEL __launch_bounds__(256) void attn_bwd_single_query_kernel(AttnParams p) {
+    constexpr int D = 64 * DPL;
+    VC_SHARED float qs[4][D];
+    VC_SHARED float dos[4][D];
+    VC_SHARED float dss[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    if (wid >= (long)p.B * p.H) return;
+    const int h = (int)(wid % p.H); const long b = wid / p.H;
+    const T* qrow = (const T*)p.q + b * p.ldq + h * D;                     // Tq = 1: query row b
+    const T* dorow = (const T*)p.dout + b * p.lddo + h * D;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+        qs[wave][lane * DPL + j] = vc_ld(qrow + lane * DPL + j);
+        dos[wave][lane * DPL + j] = vc_ld(dorow + lane * DPL + j);
+    }
+    vc_wave_barrier();
+    const float lse = p.lse[wid];
+    const bool on = lane < p.Tk;
+    const T* krow = (const T*)p.k + (b * p.Tk + (on ? lane : 0)) * p.ldk + h * D;
+    const T* vrow = (const T*)p.v + (b * p.Tk + (on ? lane : 0)) * p.ldv + h * D;
+    float pr = 0.f, dp = 0.f;
+    if (on) { pr = expf(attn_dot_row<T, D>(krow, qs[wave]) * p.scale - lse); dp = attn_dot_row<T, D>(vrow, dos[wave]); }
+    const float dsum = vc_wave_sum(pr * dp);
+    const float ds = pr * (dp - dsum);
+    dss[wave][lane] = ds;
+    if (on) {                                                               // dk_j = scale * dS_j * q ;  dv_j = P_j * dO
+        T* dk = (T*)p.dk + (b * p.Tk + lane) * p.lddk + h * D;
+        T* dv = (T*)p.dv + (b * p.Tk + lane) * p.lddv + h * D;
+        for (int d = 0; d < D; ++d) { vc_st(dk + d, ds * p.scale * qs[wave][d]); vc_st(dv + d, pr * dos[wave][d]); }
+    }
+    vc_wave_barrier();
+    float acc[DPL];
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) acc[j] = 0.f;
+    for (int jj = 0; jj < p.Tk; ++jj) {                                     // dq = scale * sum_j dS_j k_j   (lane = dims, rows coalesced)
+        const float dsj = dss[wave][jj];
+        const T* kr = (const T*)p.k + (b * p.Tk + jj) * p.ldk + h * D + lane * DPL;
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) acc[j] += dsj * vc_ld(kr + j);
+    }
+    T* dq = (T*)p.dq + b * p.lddq + h * D + lane * DPL;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) vc_st(dq + j, acc[j] * p.scale);
+    if (lane == 0) p.delta[wid] = dsum;
+}

@@ -159,23 +159,46 @@ VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
     am_store((vc_bf16*)p.o + rowq * p.ldo + h * AM_D, p.ldo, o, T, lane, 1.0f);
 }
 
-VC_KERNEL __launch_bounds__(64) void attn_vit_bwd_mfma_kernel(AttnParams p) {
+// stage with NT threads cooperating (backward: 2 waves share the tiles)
+template <int NT>
+VC_DEV void am_stage_nt(vc_bf16* tile, const vc_bf16* g, long ld, int T, int tid) {
+    constexpr int N = AM_T * 8 / NT;
+    vc_u32x4 v[N];
+#pragma unroll
+    for (int it = 0; it < N; ++it) {
+        const int c = tid + NT * it, row = c >> 3, col = (c & 7) * 8;
+        v[it] = *reinterpret_cast<const vc_u32x4*>(g + (long)(row < T ? row : T - 1) * ld + col);
+    }
+#pragma unroll
+    for (int it = 0; it < N; ++it) {
+        const int c = tid + NT * it, row = c >> 3, col = (c & 7) * 8;
+        vc_u32x4 w = v[it];
+        if (row >= T) { w.x = 0u; w.y = 0u; w.z = 0u; w.w = 0u; }
+        *reinterpret_cast<vc_u32x4*>(tile + row * AM_S + col) = w;
+    }
+}
+
+// Backward: one 2-wave block per (frame, head).  Both waves share the staged Q/K/V/dO tiles; wave 0 owns the
+// "lane = query" orientation (D_i, dQ), wave 1 the "lane = key" orientation (dV, dK).  Wave 1 runs its two S / dP
+// MFMA grids while wave 0 produces D_i; the hand-off is the block barrier.  Halving the per-wave accumulator set
+// lifts occupancy from 1 to 2 waves per SIMD (8 waves per CU, LDS-limited at 37 KB per block).
+VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO
     VC_SHARED float lse_s[AM_T];
     VC_SHARED float del_s[AM_T];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
     const int T = p.Tq;
     const long rowq = n * T;
-    am_stage(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, lane);
-    am_stage(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, lane);
-    am_stage(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, lane);
-    am_stage(tiles[3], (const vc_bf16*)p.dout + rowq * p.lddo + h * AM_D, p.lddo, T, lane);
-    lse_s[lane] = (lane < T) ? p.lse[(n * p.H + h) * T + lane] : 0.f;
-    vc_wave_barrier();
+    am_stage_nt<128>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
+    am_stage_nt<128>(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
+    am_stage_nt<128>(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, tid);
+    am_stage_nt<128>(tiles[3], (const vc_bf16*)p.dout + rowq * p.lddo + h * AM_D, p.lddo, T, tid);
+    if (tid < AM_T) lse_s[tid] = (tid < T) ? p.lse[(n * p.H + h) * T + tid] : 0.f;
+    vc_sync();
     const vc_bf16 *Qs = tiles[0], *Ks = tiles[1], *Vs = tiles[2], *dOs = tiles[3];
 
-    {   // ---------------- lane = query:  dQ
+    if (wave == 0) {   // ---------------- lane = query:  D_i, dQ
         vc_f32x16 st[2][2], dpt[2][2];
         am_zero(st); am_zero(dpt);
         am_mm_nt(st, Ks, Qs, lane);          // S^T[key][query]
@@ -200,17 +223,17 @@ VC_KERNEL __launch_bounds__(64) void attn_vit_bwd_mfma_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) st[kt][qt][r] = st[kt][qt][r] * (dpt[kt][qt][r] - dsum);   // dS^T (scale folded into the store)
             if (lane < 32) del_s[query] = dsum;
         }
+        vc_sync();                           // publish D_i to wave 1
         vc_f32x16 dq[2][2];
         am_zero(dq);
         am_mm_tok(dq, st, Ks, lane);         // dQ[query][d] = sum_key dS[query][key] K[key][d]
         am_store((vc_bf16*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, T, lane, p.scale);
-    }
-    vc_wave_barrier();                       // del_s written by lanes < 32, read by all below
-    {   // ---------------- lane = key:  dV, dK
+    } else {           // ---------------- lane = key:  dV, dK
         vc_f32x16 sn[2][2], dp[2][2];
         am_zero(sn); am_zero(dp);
         am_mm_nt(sn, Qs, Ks, lane);          // S[query][key]   (grid [query tile][key tile], lane column = key)
         am_mm_nt(dp, dOs, Vs, lane);         // dP[query][key]
+        vc_sync();                           // D_i from wave 0
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int key = kt * 32 + (lane & 31);

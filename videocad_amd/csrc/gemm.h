@@ -141,7 +141,7 @@ template <> struct GemmCfg<float> {
 template <> struct GemmCfg<vc_bf16> {
     static constexpr int BK = 64, CHUNK = 8, STRIDE = 72, KSTEP = 16;
 };
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
+constexpr int GEMM_THREADS = 256;      // 4 waves as 2 x 2; each wave owns WT x WT MFMA 32x32 tiles => block tile = (64*WT)^2
 
 // LDS image of one operand tile:
 //   direct   (k contiguous in memory)       : [128 rows][BK + pad]           fragment = one ds_read_b128
@@ -149,12 +149,14 @@ constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_THREADS = 256;
 //            fragment = two ds_read_b64_tr_b16 (hardware transpose); the 64-byte row pad puts the 4 k-rows a
 //            transpose-read touches on disjoint banks
 //   f32  TR  : transposed on the way into LDS (scalar ds_write_b32), same image as direct
-constexpr int GEMM_TSTRIDE = 160;
-template <typename CT, bool TR> constexpr int gemm_tile_elems() {
-    return (sizeof(CT) == 2 && TR) ? GemmCfg<CT>::BK * GEMM_TSTRIDE : 128 * GemmCfg<CT>::STRIDE;
+template <int ROWS> constexpr int gemm_tstride() { return ROWS + 32; }
+template <typename CT, bool TR, int ROWS> constexpr int gemm_tile_elems() {
+    return (sizeof(CT) == 2 && TR) ? GemmCfg<CT>::BK * gemm_tstride<ROWS>() : ROWS * GemmCfg<CT>::STRIDE;
 }
-template <typename CT, bool TRA, bool TRB> constexpr size_t gemm_lds_bytes() {
-    return 2ul * (gemm_tile_elems<CT, TRA>() + gemm_tile_elems<CT, TRB>()) * sizeof(CT);
+template <typename CT, bool TRA, bool TRB, int WT> constexpr size_t gemm_lds_bytes() {
+    constexpr size_t stage = 2ul * (gemm_tile_elems<CT, TRA, 64 * WT>() + gemm_tile_elems<CT, TRB, 64 * WT>()) * sizeof(CT);
+    constexpr size_t epi = (size_t)(64 * WT) * (64 * WT + 4) * 4;          // fp32 staging tile of the row-wise epilogue
+    return stage > epi ? stage : epi;
 }
 
 // One staged chunk = CHUNK elements of CT = 16 bytes, kept as a raw 16-byte register quad (never repacked
@@ -167,11 +169,12 @@ VC_DEV vc_u32x4 gemm_pack_chunk(const float (&f)[GemmCfg<CT>::CHUNK]) {
     return r;
 }
 
-// Stage one 128 x BK operand tile.  LDS image is always [row][k] (k contiguous, padded stride).
-template <typename CT, typename ST, bool TR>
+// Stage one ROWS x BK operand tile.
+template <typename CT, typename ST, bool TR, int ROWS>
 struct GemmStager {
     static constexpr int BK = GemmCfg<CT>::BK, CH = GemmCfg<CT>::CHUNK, STRIDE = GemmCfg<CT>::STRIDE;
-    static constexpr int NCH = 128 * BK / CH / GEMM_THREADS;      // chunks per thread (= 4)
+    static constexpr int NCH = ROWS * BK / CH / GEMM_THREADS;     // chunks per thread (4 for 128 rows, 2 for 64)
+    static constexpr int TS = gemm_tstride<ROWS>();
     vc_u32x4 regs[NCH];
 
     // interior tile + 16-byte-aligned operand: straight-line vector loads (no per-chunk branch, so all loads of a
@@ -182,7 +185,7 @@ struct GemmStager {
             int c = tid + GEMM_THREADS * i;
             const ST* p;
             if constexpr (!TR) p = base + (long)(r0 + c / (BK / CH)) * ld + (k0 + (c % (BK / CH)) * CH);
-            else p = base + (long)(k0 + c / (128 / CH)) * ld + (r0 + (c % (128 / CH)) * CH);
+            else p = base + (long)(k0 + c / (ROWS / CH)) * ld + (r0 + (c % (ROWS / CH)) * CH);
             if constexpr (sizeof(ST) == sizeof(CT)) {
                 regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
             } else {   // fp32 source feeding bf16 MFMA
@@ -204,7 +207,7 @@ struct GemmStager {
                 nv = (r0 + row < R) ? (Kend - (k0 + kc)) : 0;
                 p = base + (long)(r0 + row) * ld + (k0 + kc);
             } else {
-                int k = c / (128 / CH), rc = (c % (128 / CH)) * CH;
+                int k = c / (ROWS / CH), rc = (c % (ROWS / CH)) * CH;
                 nv = (k0 + k < Kend) ? (R - (r0 + rc)) : 0;
                 p = base + (long)(k0 + k) * ld + (r0 + rc);
             }
@@ -229,9 +232,9 @@ struct GemmStager {
                     for (int j = 0; j < 4; ++j) d[j] = w[j];
                 }
             } else {
-                int k = c / (128 / CH), rc = (c % (128 / CH)) * CH;
+                int k = c / (ROWS / CH), rc = (c % (ROWS / CH)) * CH;
                 if constexpr (sizeof(CT) == 2) {
-                    *reinterpret_cast<vc_u32x4*>(lds + k * GEMM_TSTRIDE + rc) = regs[i];      // [k][row], 16 lanes = one 256-byte row
+                    *reinterpret_cast<vc_u32x4*>(lds + k * TS + rc) = regs[i];      // natural [k][row] image
                 } else {
                     uint32_t* d = reinterpret_cast<uint32_t*>(lds);
 #pragma unroll
@@ -243,8 +246,9 @@ struct GemmStager {
 };
 
 // bf16 MFMA fragment (8 k-values of one row) for k-step ks of the tile; row0 = first row of the wave's 32-row block
-template <bool TR>
+template <bool TR, int ROWS>
 VC_DEV vc_s16x8 gemm_frag_bf16(const vc_bf16* tile, int row0, int ks, int lane) {
+    constexpr int GEMM_TSTRIDE = gemm_tstride<ROWS>();
     if constexpr (!TR) {
         return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * GemmCfg<vc_bf16>::STRIDE + ks * 16 + (lane >> 5) * 8);
     } else {
@@ -257,13 +261,14 @@ VC_DEV vc_s16x8 gemm_frag_bf16(const vc_bf16* tile, int row0, int ks, int lane) 
     }
 }
 
-template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
 VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     constexpr int BK = GemmCfg<CT>::BK, STRIDE = GemmCfg<CT>::STRIDE;
+    constexpr int GEMM_BM = 64 * WT, GEMM_BN = 64 * WT, WS = 32 * WT;     // block tile, per-wave sub-tile
     VC_DYN_SHARED(CT, lds);
     // NB: buffers are addressed as base + integer offset.  Keeping the two tile pointers in an array makes hipcc
     // lose the LDS address space (flat_load/flat_store instead of ds_read_b128/ds_write_b128: ~10x slower).
-    constexpr int ATILE = gemm_tile_elems<CT, TRA>(), TILE = ATILE + gemm_tile_elems<CT, TRB>();
+    constexpr int ATILE = gemm_tile_elems<CT, TRA, GEMM_BM>(), TILE = ATILE + gemm_tile_elems<CT, TRB, GEMM_BN>();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -281,73 +286,80 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     const int kend = (kbeg + p.k_per_split < p.K) ? (kbeg + p.k_per_split) : p.K;
     const int nt = (kend - kbeg + BK - 1) / BK;
 
-    vc_f32x16 acc[2][2];
+    vc_f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    GemmStager<CT, SA, TRA> sa;
-    GemmStager<CT, SB, TRB> sb;
+    // Two-tile-deep register prefetch: tile t+2 is requested from HBM/L2 while tile t is on the matrix cores and tile t+1
+    // waits in the other staging set, so every global load has two MFMA phases + a barrier to land (one 512-cycle MFMA
+    // phase is shorter than an L2 round trip).  The loop is unrolled by two so both staging sets are statically indexed.
+    GemmStager<CT, SA, TRA, GEMM_BM> sa0, sa1;
+    GemmStager<CT, SB, TRB, GEMM_BN> sb0, sb1;
     const SA* Ag = (const SA*)p.A;
     const SB* Bg = (const SB*)p.B;
-
     const bool rowsA = p.vecA && (m0 + GEMM_BM <= p.M), rowsB = p.vecB && (n0 + GEMM_BN <= p.N);   // block-uniform
-    if (nt > 0) {
-        if (rowsA && kbeg + BK <= kend) sa.load_fast(Ag, p.lda, m0, kbeg, tid); else sa.load(Ag, p.lda, m0, kbeg, p.M, kend, tid);
-        if (rowsB && kbeg + BK <= kend) sb.load_fast(Bg, p.ldb, n0, kbeg, tid); else sb.load(Bg, p.ldb, n0, kbeg, p.N, kend, tid);
-        sa.store(lds, tid);
-        sb.store(lds + ATILE, tid);
-    }
-    vc_sync();
 
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) {
-            const int k1 = kbeg + (t + 1) * BK;
-            const bool kfull = k1 + BK <= kend;
-            if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid); else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
-            if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid); else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
-        }
+    auto fetch = [&](GemmStager<CT, SA, TRA, GEMM_BM>& sa, GemmStager<CT, SB, TRB, GEMM_BN>& sb, int t) {
+        const int k1 = kbeg + t * BK;
+        const bool kfull = k1 + BK <= kend;
+        if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid); else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
+        if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid); else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
+    };
+    auto compute = [&](int cur) {
         const CT* a_tile = lds + cur * TILE;
         const CT* b_tile = a_tile + ATILE;
-        const CT* a_base = a_tile + (wm * 64 + (lane & 31)) * STRIDE;
-        const CT* b_base = b_tile + (wn * 64 + (lane & 31)) * STRIDE;
         if constexpr (sizeof(CT) == 2) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                vc_s16x8 af[2], bf[2];
+                vc_s16x8 af[WT], bf[WT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = gemm_frag_bf16<TRA>(a_tile, wm * 64 + i * 32, ks, lane);
-                    bf[i] = gemm_frag_bf16<TRB>(b_tile, wn * 64 + i * 32, ks, lane);
+                for (int i = 0; i < WT; ++i) {
+                    af[i] = gemm_frag_bf16<TRA, GEMM_BM>(a_tile, wm * WS + i * 32, ks, lane);
+                    bf[i] = gemm_frag_bf16<TRB, GEMM_BN>(b_tile, wn * WS + i * 32, ks, lane);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = vc_mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < WT; ++j) acc[i][j] = vc_mfma_32x32x16_bf16(af[i], bf[j], acc[i][j]);
             }
         } else {
+            const CT* a_base = a_tile + (wm * WS + (lane & 31)) * STRIDE;
+            const CT* b_base = b_tile + (wn * WS + (lane & 31)) * STRIDE;
 #pragma unroll 4
             for (int ks = 0; ks < BK / 2; ++ks) {
-                float af[2], bf[2];
+                float af[WT], bf[WT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < WT; ++i) {
                     af[i] = a_base[i * 32 * STRIDE + ks * 2 + (lane >> 5)];
                     bf[i] = b_base[i * 32 * STRIDE + ks * 2 + (lane >> 5)];
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = vc_mfma_32x32x2_f32(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < WT; ++j) acc[i][j] = vc_mfma_32x32x2_f32(af[i], bf[j], acc[i][j]);
             }
         }
-        if (t + 1 < nt) {
-            sa.store(lds + (cur ^ 1) * TILE, tid);
-            sb.store(lds + (cur ^ 1) * TILE + ATILE, tid);
-        }
+    };
+
+    if (nt > 0) {
+        fetch(sa0, sb0, 0);
+        if (nt > 1) fetch(sa1, sb1, 1);
+        sa0.store(lds, tid); sb0.store(lds + ATILE, tid);
+    }
+    vc_sync();
+    for (int t = 0; t < nt; t += 2) {
+        if (t + 2 < nt) fetch(sa0, sb0, t + 2);                     // set 0 is free: tile t already sits in LDS buffer 0
+        compute(0);
+        if (t + 1 < nt) { sa1.store(lds + TILE, tid); sb1.store(lds + TILE + ATILE, tid); }
+        vc_sync();
+        if (t + 1 >= nt) break;
+        if (t + 3 < nt) fetch(sa1, sb1, t + 3);
+        compute(1);
+        if (t + 2 < nt) { sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
         vc_sync();
     }
 
@@ -357,22 +369,23 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
         // rows — residual / activation-source loads and the final stores are coalesced 16-byte (fp32) or 8-byte (bf16)
         // accesses of 512/256-byte row segments instead of 64 strided scalars per lane.
         constexpr int ES = GEMM_BN + 4;                              // fp32 row stride (pad: conflict-free column writes)
-        static_assert(GEMM_BM * ES * 4 <= gemm_lds_bytes<CT, TRA, TRB>(), "epilogue tile must fit the staging LDS");
+        constexpr int TPR = GEMM_BN / 4, RPP = GEMM_THREADS / TPR;   // threads per row, rows per pass
+        static_assert(GEMM_BM * ES * 4 <= gemm_lds_bytes<CT, TRA, TRB, WT>(), "epilogue tile must fit the staging LDS");
         float* et = reinterpret_cast<float*>(lds);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < WT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    et[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ES + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+                    et[(wm * WS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * ES + wn * WS + j * 32 + (lane & 31)] = acc[i][j][r];
         vc_sync();
-        const int c4 = (tid & 31) * 4, n = n0 + c4;
+        const int c4 = (tid % TPR) * 4, n = n0 + c4;
         float b4[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) quad_ld_f32(p.bias + n, b4);
 #pragma unroll 4
-        for (int pass = 0; pass < GEMM_BM / 8; ++pass) {
-            const int row = pass * 8 + (tid >> 5), m = m0 + row;
+        for (int pass = 0; pass < GEMM_BM / RPP; ++pass) {
+            const int row = pass * RPP + tid / TPR, m = m0 + row;
             float v[4];
             quad_ld_f32(et + row * ES + c4, v);
 #pragma unroll
@@ -404,23 +417,23 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     }
     if (!p.partial && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {        // interior block, unaligned tensors: batched scalar path
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < WT; ++j) {
+            const int n = n0 + wn * WS + j * 32 + (lane & 31);
             const float bias_n = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) gemm_epilogue_tile<TO>(p, m0 + wm * 64 + i * 32 + 4 * (lane >> 5), n, acc[i][j], bias_n);
+            for (int i = 0; i < WT; ++i) gemm_epilogue_tile<TO>(p, m0 + wm * WS + i * 32 + 4 * (lane >> 5), n, acc[i][j], bias_n);
         }
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < WT; ++j) {
+        const int n = n0 + wn * WS + j * 32 + (lane & 31);
         const float bias_n = (p.bias && !p.partial && n < p.N) ? p.bias[n] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + wm * WS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M && n < p.N) {
                     if (p.partial) p.partial[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
                     else gemm_epilogue_store<TO>(p, m, n, acc[i][j][r], bias_n);

@@ -179,7 +179,7 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     }
 }
 
-// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c].  Deterministic 32-way tree: every pass gives each block <= 32
+// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c].  Deterministic 128-way tree: every pass gives each block <= 32
 // rows of 256 columns (so there are always enough blocks in flight), partials are reduced by the next pass.
 struct ColsumParams {
     const void* x; long ld; long rows; int cols; long batch_stride_x;
@@ -194,7 +194,14 @@ VC_KERNEL __launch_bounds__(256) void colsum_pass_kernel(ColsumParams p) {
     long r0 = (long)blockIdx.y * p.rows_per_block, r1 = r0 + p.rows_per_block;
     if (r1 > p.rows) r1 = p.rows;
     float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += vc_ld(x + r * p.ld + c);
+    long r = r0;
+    for (; r + 8 <= r1; r += 8) {                 // 8 independent loads in flight per thread (a plain loop waits for each)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = vc_ld(x + (r + u) * p.ld + c);
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < r1; ++r) s += vc_ld(x + r * p.ld + c);
     float* o = p.out + (long)blockIdx.z * p.batch_stride_out + (long)blockIdx.y * p.ld_out_rows + c;
     *o = p.accumulate ? (*o + s) : s;
 }

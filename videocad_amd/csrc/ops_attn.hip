@@ -57,8 +57,14 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), 0, s);
+    if (p.Tq == 1 && !p.causal && p.Tk <= 64 && D == 64 && p.window >= p.Tk) {     // cls-only query (last ViT layer)
+        dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4));
+        if (t == VC_BF16) VC_LAUNCH((attn_bwd_single_query_kernel<vc_bf16, 1>), g, dim3(256), 0, s, p);
+        else VC_LAUNCH((attn_bwd_single_query_kernel<float, 1>), g, dim3(256), 0, s, p);
+        return VC_OK;
+    }
     if (mfma_ok(t, D, p, true)) {
-        VC_LAUNCH(attn_vit_bwd_mfma_kernel, dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
+        VC_LAUNCH(attn_vit_bwd_mfma_kernel, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);

@@ -40,13 +40,15 @@ extern "C" void vcad_profile_begin(void) {}
 extern "C" int vcad_profile_end(double*, double*, double*, int*) { return 0; }
 #endif
 
-template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
-static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
-    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB>();
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
+static int gemm_launch_wt(GemmCall c, int nsplit, vc_stream_t s) {
+    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB, WT>();
+    constexpr int GEMM_BM = 64 * WT, GEMM_BN = 64 * WT;
+    if (c.p.k_per_split < 0) c.p.k_per_split = -c.p.k_per_split;
 #ifndef VC_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<CT, SA, SB, TO, TRA, TRB>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
         attr_set = true;
@@ -55,13 +57,21 @@ static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
     ProfScope ps(TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD), 2.0 * c.p.M * c.p.N * c.p.K,
                  (double)c.p.M * c.p.K * sizeof(SA) + (double)c.p.N * c.p.K * sizeof(SB) + (double)c.p.M * c.p.N * sizeof(TO), s);
     dim3 grid(VC_CEIL_DIV(c.p.N, GEMM_BN), VC_CEIL_DIV(c.p.M, GEMM_BM), nsplit);
-    VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB>), grid, dim3(GEMM_THREADS), lds, s, c.p);
+    VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>), grid, dim3(GEMM_THREADS), lds, s, c.p);
     if (nsplit > 1) {
         long total = (long)c.p.M * c.p.N;
         VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total, 256)), dim3(256), 0, s, c.p, nsplit);
     }
     return VC_OK;
 }
+
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
+static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
+    return c.p.k_per_split < 0 ? gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 1>(c, nsplit, s) : gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 2>(c, nsplit, s);
+}
+
+static int g_force_tile = 0;     // 0 = automatic, 64 / 128 = forced (tests exercise both tile sizes on small problems)
+extern "C" void vcad_debug_force_gemm_tile(int tile) { g_force_tile = (tile == 64 || tile == 128) ? tile : 0; }
 
 static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
 
@@ -79,7 +89,13 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if (eo == 2) p.vecC = p.vecC && ((uintptr_t)p.C % 8 == 0);
     }
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
-    long tiles = (long)VC_CEIL_DIV(p.M, GEMM_BM) * VC_CEIL_DIV(p.N, GEMM_BN);
+    // tile size: 128x128 by default; 64x64 when that grid would leave most of the 256 CUs idle (the decoder's
+    // 2048-token GEMMs): 4x the blocks and no split-K pass.  Long token reductions still split K.
+    long tiles128 = (long)VC_CEIL_DIV(p.M, 128) * VC_CEIL_DIV(p.N, 128);
+    // (not for the long token reductions of wgrad: halving the tile doubles operand traffic per FLOP there; those split K instead)
+    const bool small = g_force_tile ? (g_force_tile == 64) : (tiles128 < 256 && p.K <= 4096);
+    const int BT = small ? 64 : 128;
+    long tiles = (long)VC_CEIL_DIV(p.M, BT) * VC_CEIL_DIV(p.N, BT);
     int nsplit = 1;
     if (scratch && tiles < 256 && p.K >= 8 * BK) {
         nsplit = (int)VC_CEIL_DIV(512, tiles);
@@ -92,6 +108,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     nsplit = VC_CEIL_DIV(p.K, kps);
     p.k_per_split = kps;
     p.partial = nsplit > 1 ? scratch : nullptr;
+    c.p.k_per_split = small ? -kps : kps;          // sign carries the tile-size choice to gemm_launch (restored there)
 
 #define G(CT_, SA_, SB_, TO_, TRA_, TRB_) return gemm_launch<CT_, SA_, SB_, TO_, TRA_, TRB_>(c, nsplit, s)
     const int lay = c.tra * 2 + c.trb;

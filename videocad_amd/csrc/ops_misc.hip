@@ -64,20 +64,20 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     return VC_OK;
 }
 
-long vc_colsum_chunks(long rows) { return VC_CEIL_DIV(rows, 32) + VC_CEIL_DIV(VC_CEIL_DIV(rows, 32), 32) + 2; }   // partial rows, both ping-pong levels
+long vc_colsum_chunks(long rows) { return VC_CEIL_DIV(rows, 128) + VC_CEIL_DIV(VC_CEIL_DIV(rows, 128), 128) + 2; }   // partial rows, both ping-pong levels
 
 int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
               int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s) {
     if (rows <= 0 || cols <= 0) return VC_OK;
     ProfScope ps(VC_CAT_OTHER, 0, (double)batch * rows * cols * (tx == VC_BF16 ? 2 : 4), s);
     const void* cur = x; long cur_ld = ld, cur_rows = rows, cur_bs = bstride_x; int cur_t = tx;
-    float* wsA = ws; float* wsB = ws + (long)batch * VC_CEIL_DIV(rows, 32) * cols;
+    float* wsA = ws; float* wsB = ws + (long)batch * VC_CEIL_DIV(rows, 128) * cols;
     bool useA = true;
     while (true) {
-        const bool last = cur_rows <= 32;
-        const long nblk = last ? 1 : VC_CEIL_DIV(cur_rows, 32);
+        const bool last = cur_rows <= 128;
+        const long nblk = last ? 1 : VC_CEIL_DIV(cur_rows, 128);
         ColsumParams p;
-        p.x = cur; p.ld = cur_ld; p.rows = cur_rows; p.cols = cols; p.batch_stride_x = cur_bs; p.rows_per_block = 32;
+        p.x = cur; p.ld = cur_ld; p.rows = cur_rows; p.cols = cols; p.batch_stride_x = cur_bs; p.rows_per_block = 128;
         float* dst = last ? out : (useA ? wsA : wsB);
         p.out = dst; p.ld_out_rows = last ? 0 : cols; p.batch_stride_out = last ? bstride_out : nblk * cols; p.accumulate = last ? accumulate : 0;
         dim3 g(VC_CEIL_DIV(cols, 256), (unsigned)nblk, batch);
