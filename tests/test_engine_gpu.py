@@ -133,3 +133,36 @@ def test_f32_causality_and_batch_independence():
     perm = torch.tensor([2, 0, 1], device=DEV)
     c2, p2 = eng.forward(fr[perm].contiguous(), an[perm].contiguous(), cad[perm].contiguous())
     assert U.relerr(p2, p0[perm]) < 1e-6
+
+
+def test_fused_loss_matches_reference_loss_cases(golden_dir):
+    """compute_loss on synthetic logits, use_mse True and False (class-weighted CE with the NaN-skip), incl. the
+    'all predictions inside the window -> constant 0' and 'no valid targets' branches (reference trainer.py:895-896, :961)."""
+    cases = json.load(open(os.path.join(golden_dir, "loss_cases.json")))
+    cw_json = json.load(open(os.path.join(golden_dir, "class_weights.json")))
+    names = ["x", "y", "Key Pressed", "Times Key Pressed", "Scroll Amount", "Typed Value"]
+    cw = torch.tensor([cw_json[k] for k in names], dtype=torch.float32, device=DEV).contiguous()
+    B, T = cases["B"], cases["T"]
+    eng = build(L.VCAD_F32)
+    b = synth.make_batch_torch(B, T, 1, DEV)
+    eng.forward(b["frames"][:, :-1], O.normalize_actions(b["actions"][:, :-1]), b["cad_image"])      # sizes the workspace for (B, T)
+    for name, c in cases["cases"].items():
+        seed, mode = c["seed"], c["mode"]
+        acts = torch.from_numpy(synth.make_actions(B, T + 1, seed, lengths=cases["lengths"]))[:, 1:].clone()
+        cm = torch.from_numpy(synth.hash_uniform(1000 + seed, B * T * 5).reshape(B, T, 5) * 3)
+        pm = torch.from_numpy(synth.hash_uniform(2000 + seed, B * T * 6000).reshape(B, T, 6, 1000) * 3)
+        if mode == "inside":
+            pm.scatter_(-1, acts[..., 1:].long().clamp(min=0).unsqueeze(-1), 50.0)
+        if mode == "empty":
+            acts[..., 5:] = -1
+        if mode == "edge":
+            m = acts[..., 1:] >= 0
+            acts[..., 1:][m] = torch.where(acts[..., 1:][m] > 500, torch.tensor(999.0), torch.tensor(998.0))
+        cm, pm, acts = cm.to(DEV), pm.to(DEV).contiguous(), acts.to(DEV)
+        from videocad_amd.trainer import metrics_from_counters
+        out, met = eng.loss(cm, pm, acts, use_mse=True)
+        assert abs(float(out[0]) - c["loss_use_mse"]) < 2e-5 * max(1.0, abs(c["loss_use_mse"])), (name, float(out[0]), c["loss_use_mse"])
+        assert metrics_from_counters(met.tolist()) == c["metrics_use_mse"], name
+        out, met = eng.loss(cm, pm, acts, use_mse=False, class_weights=cw)
+        assert abs(float(out[0]) - c["loss_no_mse"]) < 2e-5 * max(1.0, abs(c["loss_no_mse"])), (name, float(out[0]), c["loss_no_mse"])
+        assert metrics_from_counters(met.tolist()) == c["metrics_no_mse"], name

@@ -31,13 +31,60 @@ struct AttnParams {
     float* delta;                                                // [B][H][Tq]  D_i
 };
 
+// sum_d row[d] * bc[d]; bc: LDS, same address for all lanes (broadcast).  The row is walked in 16-byte chunks, four
+// chunks in flight per step (a scalar element loop makes hipcc wait for every load in turn).  Rows must be 16-byte aligned.
+template <typename T> VC_DEV float attn_dot_chunk(const vc_u32x4& c, const float* bc);
+template <> VC_DEV float attn_dot_chunk<float>(const vc_u32x4& c, const float* bc) {
+    return vc_bits_f32(c.x) * bc[0] + vc_bits_f32(c.y) * bc[1] + vc_bits_f32(c.z) * bc[2] + vc_bits_f32(c.w) * bc[3];
+}
+template <> VC_DEV float attn_dot_chunk<vc_bf16>(const vc_u32x4& c, const float* bc) {
+    return vc_bits_f32(c.x << 16) * bc[0] + vc_bits_f32(c.x & 0xFFFF0000u) * bc[1] + vc_bits_f32(c.y << 16) * bc[2] + vc_bits_f32(c.y & 0xFFFF0000u) * bc[3] +
+           vc_bits_f32(c.z << 16) * bc[4] + vc_bits_f32(c.z & 0xFFFF0000u) * bc[5] + vc_bits_f32(c.w << 16) * bc[6] + vc_bits_f32(c.w & 0xFFFF0000u) * bc[7];
+}
 template <typename T, int D>
-VC_DEV float attn_dot_row(const T* row, const float* bc) {      // sum_d row[d] * bc[d]; bc: LDS, same address for all lanes
-    float s = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < D; d += 4)
-        s += vc_ld(row + d) * bc[d] + vc_ld(row + d + 1) * bc[d + 1] + vc_ld(row + d + 2) * bc[d + 2] + vc_ld(row + d + 3) * bc[d + 3];
-    return s;
+VC_DEV float attn_dot_row(const T* row, const float* bc) {
+    constexpr int EPC = 16 / (int)sizeof(T);
+    static_assert(D % (4 * EPC) == 0, "head dim must be a multiple of four 16-byte chunks");
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 2
+    for (int d = 0; d < D; d += 4 * EPC) {
+        const vc_u32x4 c0 = *reinterpret_cast<const vc_u32x4*>(row + d), c1 = *reinterpret_cast<const vc_u32x4*>(row + d + EPC);
+        const vc_u32x4 c2 = *reinterpret_cast<const vc_u32x4*>(row + d + 2 * EPC), c3 = *reinterpret_cast<const vc_u32x4*>(row + d + 3 * EPC);
+        s0 += attn_dot_chunk<T>(c0, bc + d); s1 += attn_dot_chunk<T>(c1, bc + d + EPC);
+        s2 += attn_dot_chunk<T>(c2, bc + d + 2 * EPC); s3 += attn_dot_chunk<T>(c3, bc + d + 3 * EPC);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// DPL consecutive elements of a row as floats (one vector load for DPL = 4)
+template <typename T, int DPL> VC_DEV void attn_row_ld(const T* p, float (&v)[DPL]) {
+    if constexpr (DPL == 4 && sizeof(T) == 4) { const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p); v[0] = vc_bits_f32(q.x); v[1] = vc_bits_f32(q.y); v[2] = vc_bits_f32(q.z); v[3] = vc_bits_f32(q.w); }
+    else if constexpr (DPL == 4 && sizeof(T) == 2) { const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p); v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u); }
+    else {
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) v[j] = vc_ld(p + j);
+    }
+}
+// acc[j] += sum over rows r = 0..cnt-1 of w_r * row_r[j], w_r = lane r's `w` (broadcast), four rows in flight
+template <typename T, int DPL> VC_DEV void attn_accum_rows(float (&acc)[DPL], const T* base, long ld, int cnt, float w) {
+    int r = 0;
+    for (; r + 4 <= cnt; r += 4) {
+        float v[4][DPL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) attn_row_ld<T, DPL>(base + (long)(r + u) * ld, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wr = vc_shfl(w, r + u);
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) acc[j] += wr * v[u][j];
+        }
+    }
+    for (; r < cnt; ++r) {
+        float v[DPL]; attn_row_ld<T, DPL>(base + (long)r * ld, v);
+        const float wr = vc_shfl(w, r);
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) acc[j] += wr * v[j];
+    }
 }
 
 // NPASS = ceil(max visible keys / 64)
@@ -80,12 +127,7 @@ VC_KERNEL __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         int cnt = nk - ps * 64; cnt = cnt > 64 ? 64 : cnt;
-        for (int jj = 0; jj < cnt; ++jj) {
-            const float pj = vc_shfl(s[ps], jj);
-            const T* vrow = (const T*)p.v + ((long)b * p.Tk + lo + ps * 64 + jj) * p.ldv + h * D + lane * DPL;
-#pragma unroll
-            for (int j = 0; j < DPL; ++j) acc[j] += pj * vc_ld(vrow + j);
-        }
+        attn_accum_rows<T, DPL>(acc, (const T*)p.v + ((long)b * p.Tk + lo + ps * 64) * p.ldv + h * D + lane * DPL, p.ldv, cnt, s[ps]);
     }
     const float inv = 1.0f / l;
     T* orow = (T*)p.o + ((long)b * p.Tq + i) * p.ldo + h * D + lane * DPL;
@@ -138,12 +180,7 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
     for (int ps = 0; ps < NPASS; ++ps) {
         const float ds_mine = pr[ps] * (dp[ps] - dsum);
         int cnt = nk - ps * 64; cnt = cnt > 64 ? 64 : cnt;
-        for (int jj = 0; jj < cnt; ++jj) {
-            const float ds = vc_shfl(ds_mine, jj);
-            const T* krow = (const T*)p.k + ((long)b * p.Tk + lo + ps * 64 + jj) * p.ldk + h * D + lane * DPL;
-#pragma unroll
-            for (int j = 0; j < DPL; ++j) acc[j] += ds * vc_ld(krow + j);
-        }
+        attn_accum_rows<T, DPL>(acc, (const T*)p.k + ((long)b * p.Tk + lo + ps * 64) * p.ldk + h * D + lane * DPL, p.ldk, cnt, ds_mine);
     }
     T* dqrow = (T*)p.dq + ((long)b * p.Tq + i) * p.lddq + h * D + lane * DPL;
 #pragma unroll
@@ -193,14 +230,8 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         int cnt = nq - ps * 64; cnt = cnt > 64 ? 64 : cnt;
-        for (int ii = 0; ii < cnt; ++ii) {
-            const float pi = vc_shfl(pr[ps], ii), dsi = vc_shfl(ds[ps], ii);
-            const int i = i0 + ps * 64 + ii;
-            const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D + lane * DPL;
-            const T* dorow = (const T*)p.dout + ((long)b * p.Tq + i) * p.lddo + h * D + lane * DPL;
-#pragma unroll
-            for (int j = 0; j < DPL; ++j) { dv[j] += pi * vc_ld(dorow + j); dk[j] += dsi * vc_ld(qrow + j); }
-        }
+        attn_accum_rows<T, DPL>(dv, (const T*)p.dout + ((long)b * p.Tq + i0 + ps * 64) * p.lddo + h * D + lane * DPL, p.lddo, cnt, pr[ps]);
+        attn_accum_rows<T, DPL>(dk, (const T*)p.q + ((long)b * p.Tq + i0 + ps * 64) * p.ldq + h * D + lane * DPL, p.ldq, cnt, ds[ps]);
     }
     T* dkrow = (T*)p.dk + ((long)b * p.Tk + jk) * p.lddk + h * D + lane * DPL;
     T* dvrow = (T*)p.dv + ((long)b * p.Tk + jk) * p.lddv + h * D + lane * DPL;
@@ -218,6 +249,7 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_single_query_kernel(AttnParams p)
     VC_SHARED float qs[4][D];
     VC_SHARED float dos[4][D];
     VC_SHARED float dss[4][64];
+    VC_SHARED float pss[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wid = (long)blockIdx.x * 4 + wave;
     if (wid >= (long)p.B * p.H) return;
@@ -239,12 +271,20 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_single_query_kernel(AttnParams p)
     const float dsum = vc_wave_sum(pr * dp);
     const float ds = pr * (dp - dsum);
     dss[wave][lane] = ds;
-    if (on) {                                                               // dk_j = scale * dS_j * q ;  dv_j = P_j * dO
-        T* dk = (T*)p.dk + (b * p.Tk + lane) * p.lddk + h * D;
-        T* dv = (T*)p.dv + (b * p.Tk + lane) * p.lddv + h * D;
-        for (int d = 0; d < D; ++d) { vc_st(dk + d, ds * p.scale * qs[wave][d]); vc_st(dv + d, pr * dos[wave][d]); }
-    }
+    pss[wave][lane] = pr;
     vc_wave_barrier();
+    {   // dk_j = scale * dS_j * q ;  dv_j = P_j * dO   — lane = dims, so every key row is one coalesced store
+        float qv[DPL], dov[DPL];
+#pragma unroll
+        for (int j = 0; j < DPL; ++j) { qv[j] = qs[wave][lane * DPL + j] * p.scale; dov[j] = dos[wave][lane * DPL + j]; }
+        for (int jj = 0; jj < p.Tk; ++jj) {
+            const float dsj = dss[wave][jj], pj = pss[wave][jj];
+            T* dk = (T*)p.dk + (b * p.Tk + jj) * p.lddk + h * D + lane * DPL;
+            T* dv = (T*)p.dv + (b * p.Tk + jj) * p.lddv + h * D + lane * DPL;
+#pragma unroll
+            for (int j = 0; j < DPL; ++j) { vc_st(dk + j, dsj * qv[j]); vc_st(dv + j, pj * dov[j]); }
+        }
+    }
     float acc[DPL];
 #pragma unroll
     for (int j = 0; j < DPL; ++j) acc[j] = 0.f;

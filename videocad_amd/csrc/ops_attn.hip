@@ -45,8 +45,18 @@ static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
 }
+static int check_rows_aligned(int t, const AttnParams& p, bool bwd) {
+    const long e = (t == VC_BF16) ? 8 : 4;           // elements per 16 bytes
+    auto bad = [&](const void* q, long ld) { return q && (((uintptr_t)q % 16) || (ld % e)); };
+    if (bad(p.q, p.ldq) || bad(p.k, p.ldk) || bad(p.v, p.ldv) || (bwd && bad(p.dout, p.lddo))) {
+        vc_set_error("attention: q/k/v(/dout) head slices must be 16-byte aligned with leading dimensions multiple of %ld", e);
+        return VC_ERR_ARG;
+    }
+    return VC_OK;
+}
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
+    if (int rc = check_rows_aligned(t, p, false)) return rc;
     ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), 0, s);
     if (mfma_ok(t, D, p, false)) {
         VC_LAUNCH(attn_vit_fwd_mfma_kernel, dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
@@ -56,6 +66,7 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
 }
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
+    if (int rc = check_rows_aligned(t, p, true)) return rc;
     ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), 0, s);
     if (p.Tq == 1 && !p.causal && p.Tk <= 64 && D == 64 && p.window >= p.Tk) {     // cls-only query (last ViT layer)
         dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4));
