@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seq", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout probability (reference default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

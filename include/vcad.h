@@ -62,6 +62,14 @@ int vcad_sync_shadow(vcad_engine* e, void* stream);
 size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T);
 int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
 
+/* ---- dropout (nn.Dropout / attention dropout at the sites of the reference's train-mode forward: vit-pytorch emb /
+ * attention / to_out / feed-forward dropouts, TransformerDecoderLayer dropout, dropout1-3 and attention dropout).
+ * p = 0 disables (model.eval()).  Masks are a stateless hash of (seed, site, element index): set a fresh seed before every
+ * training forward; the backward of that forward regenerates the same masks.  No mask tensors are stored. */
+int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed);
+/* test hook: keep-multipliers of one site (module 1 = frame ViT, 2 = CAD ViT, 3 = decoder; kind ids in engine.hip) -> HOST buffer */
+int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out);
+
 /* ---- AutoRegressiveTransformer.forward (reference model/autoregressive_transformer.py:121-220)
  * frames: fp32, frame (b,t) at frames + b*frame_bstride + t*S*S  (so batch['frames'][:, :-1] needs no copy)
  * actions_norm: fp32 [B,T,7] already normalised (reference trainer.py:800-804); cad: fp32 [B,1,S,S]

@@ -115,7 +115,13 @@ def _ln(x: Tensor, P: dict, pre: str) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), P[pre + "weight"], P[pre + "bias"], 1e-5)
 
 
-def vit_forward(P: dict, pre: str, img: Tensor, cfg: dict = CANONICAL_CONFIG, taps: Optional[dict] = None) -> Tensor:
+def _m(masks: Optional[dict], key: str, x: Tensor) -> Tensor:
+    """explicit dropout: multiply by a supplied keep-multiplier tensor (0 or 1/(1-p)); no-op without masks (eval mode)."""
+    return x * masks[key] if masks is not None and key in masks else x
+
+
+def vit_forward(P: dict, pre: str, img: Tensor, cfg: dict = CANONICAL_CONFIG, taps: Optional[dict] = None,
+                masks: Optional[dict] = None) -> Tensor:
     """img [N,1,S,S] -> cls embedding [N,D] (mlp_head = Identity, trajectory_model.py:66)."""
     N = img.shape[0]
     p = cfg["patch_size"]; g = cfg["image_size"] // p
@@ -126,7 +132,7 @@ def vit_forward(P: dict, pre: str, img: Tensor, cfg: dict = CANONICAL_CONFIG, ta
     x = F.linear(x, P[pre + "to_patch_embedding.2.weight"], P[pre + "to_patch_embedding.2.bias"])
     x = _ln(x, P, pre + "to_patch_embedding.3.")
     x = torch.cat([P[pre + "cls_token"].expand(N, 1, -1), x], dim=1)
-    x = x + P[pre + "pos_embedding"][:, : g * g + 1]
+    x = _m(masks, pre + "emb", x + P[pre + "pos_embedding"][:, : g * g + 1])          # emb_dropout
     if taps is not None:
         taps[pre + "embed"] = x
     for L in range(cfg["vit_depth"]):
@@ -135,13 +141,13 @@ def vit_forward(P: dict, pre: str, img: Tensor, cfg: dict = CANONICAL_CONFIG, ta
         qkv = F.linear(h, P[a + "to_qkv.weight"])
         q, k, v = (t.reshape(N, -1, heads, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
         dots = torch.matmul(q, k.transpose(-1, -2)) * (dh ** -0.5)
-        attn = dots.softmax(dim=-1)
+        attn = _m(masks, f"{pre}L{L}.attn", dots.softmax(dim=-1))
         out = torch.matmul(attn, v).transpose(1, 2).reshape(N, -1, heads * dh)
-        x = F.linear(out, P[a + "to_out.0.weight"], P[a + "to_out.0.bias"]) + x
+        x = _m(masks, f"{pre}L{L}.out", F.linear(out, P[a + "to_out.0.weight"], P[a + "to_out.0.bias"])) + x
         f = f"{pre}transformer.layers.{L}.1.net."
         h = _ln(x, P, f + "0.")
-        h = F.gelu(F.linear(h, P[f + "1.weight"], P[f + "1.bias"]))
-        x = F.linear(h, P[f + "4.weight"], P[f + "4.bias"]) + x
+        h = _m(masks, f"{pre}L{L}.mlp_act", F.gelu(F.linear(h, P[f + "1.weight"], P[f + "1.bias"])))
+        x = _m(masks, f"{pre}L{L}.mlp_out", F.linear(h, P[f + "4.weight"], P[f + "4.bias"])) + x
         if taps is not None:
             taps[f"{pre}layer{L}"] = x
     x = _ln(x, P, pre + "transformer.norm.")
@@ -152,7 +158,7 @@ def vit_forward(P: dict, pre: str, img: Tensor, cfg: dict = CANONICAL_CONFIG, ta
 # decoder (torch.nn.TransformerDecoderLayer defaults: post-norm, ReLU, eps 1e-5, batch_first=False)
 # ----------------------------------------------------------------------------------------
 
-def _mha(xq: Tensor, xkv: Tensor, P: dict, pre: str, nhead: int, mask: Tensor) -> Tensor:
+def _mha(xq: Tensor, xkv: Tensor, P: dict, pre: str, nhead: int, mask: Tensor, masks: Optional[dict] = None, mkey: str = "") -> Tensor:
     """Batch-first [B,T,E] restatement of nn.MultiheadAttention with an additive [T,T] mask."""
     B, T, E = xq.shape
     d = E // nhead
@@ -161,7 +167,7 @@ def _mha(xq: Tensor, xkv: Tensor, P: dict, pre: str, nhead: int, mask: Tensor) -
     k = F.linear(xkv, w[E:2 * E], b[E:2 * E]).reshape(B, -1, nhead, d).transpose(1, 2)
     v = F.linear(xkv, w[2 * E:], b[2 * E:]).reshape(B, -1, nhead, d).transpose(1, 2)
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + mask
-    o = torch.matmul(s.softmax(dim=-1), v).transpose(1, 2).reshape(B, T, E)
+    o = torch.matmul(_m(masks, mkey, s.softmax(dim=-1)), v).transpose(1, 2).reshape(B, T, E)
     return F.linear(o, P[pre + "out_proj.weight"], P[pre + "out_proj.bias"])
 
 
@@ -174,18 +180,18 @@ def window_mask(T: int, window: int) -> Tensor:
     return m
 
 
-def decoder_forward(P: dict, tgt: Tensor, mem: Tensor, cfg: dict, taps: Optional[dict] = None) -> Tensor:
+def decoder_forward(P: dict, tgt: Tensor, mem: Tensor, cfg: dict, taps: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
     B, T, E = tgt.shape
     causal = window_mask(T, T)
     band = window_mask(T, cfg["window_size"])
     x = tgt
     for L in range(cfg["num_decoder_layers"]):
         p = f"transformer_decoder.layers.{L}."
-        x = _ln(x + _mha(x, x, P, p + "self_attn.", cfg["nhead"], causal), P, p + "norm1.")
-        x = _ln(x + _mha(x, mem, P, p + "multihead_attn.", cfg["nhead"], band), P, p + "norm2.")
-        ffn = F.linear(F.relu(F.linear(x, P[p + "linear1.weight"], P[p + "linear1.bias"])),
+        x = _ln(x + _m(masks, f"dec{L}.sa_out", _mha(x, x, P, p + "self_attn.", cfg["nhead"], causal, masks, f"dec{L}.sa")), P, p + "norm1.")
+        x = _ln(x + _m(masks, f"dec{L}.ca_out", _mha(x, mem, P, p + "multihead_attn.", cfg["nhead"], band, masks, f"dec{L}.ca")), P, p + "norm2.")
+        ffn = F.linear(_m(masks, f"dec{L}.ff_act", F.relu(F.linear(x, P[p + "linear1.weight"], P[p + "linear1.bias"]))),
                        P[p + "linear2.weight"], P[p + "linear2.bias"])
-        x = _ln(x + ffn, P, p + "norm3.")
+        x = _ln(x + _m(masks, f"dec{L}.ff_out", ffn), P, p + "norm3.")
         if taps is not None:
             taps[f"dec{L}"] = x
     return x
@@ -196,22 +202,22 @@ def decoder_forward(P: dict, tgt: Tensor, mem: Tensor, cfg: dict, taps: Optional
 # ----------------------------------------------------------------------------------------
 
 def model_forward(P: dict, frames: Tensor, actions_norm: Tensor, cad: Tensor,
-                  cfg: dict = CANONICAL_CONFIG, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+                  cfg: dict = CANONICAL_CONFIG, taps: Optional[dict] = None, masks: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
     """frames [B,T,1,S,S], actions_norm [B,T,7] (already normalised), cad [B,1,S,S]
     -> cmds [B,T,5], params [B,T,6,1000]   (autoregressive_transformer.py:121-220)."""
     B, T = actions_norm.shape[:2]
     H = cfg["hidden_size"]
     ts = P["timestep_embedding.weight"][:T]                                   # :144-146
-    e = vit_forward(P, "state_embedding_model.", frames.reshape(B * T, *frames.shape[2:]), cfg, taps)  # :153-154
+    e = vit_forward(P, "state_embedding_model.", frames.reshape(B * T, *frames.shape[2:]), cfg, taps, masks)  # :153-154
     ui = torch.tanh(F.linear(e, P["embed_state.weight"], P["embed_state.bias"]).reshape(B, T, H) + ts)  # :155-157
-    c = vit_forward(P, "cad_embedding_model.", cad, cfg, taps)                 # :162
+    c = vit_forward(P, "cad_embedding_model.", cad, cfg, taps, masks)                 # :162
     cadE = F.linear(c, P["embed_image.weight"], P["embed_image.bias"]).unsqueeze(1).repeat(1, T, 1)  # :163
     mem = torch.tanh(F.linear(torch.cat([ui, cadE], dim=-1),
                               P["image_projection.weight"], P["image_projection.bias"]))  # :172-175
     act = torch.tanh(F.linear(actions_norm, P["embed_action.weight"], P["embed_action.bias"]) + ts)  # :176-178
     if taps is not None:
         taps.update(cls_state=e, cls_cad=c, ui=ui, mem=mem, act=act)
-    h = decoder_forward(P, act, mem, cfg, taps)                                # :191-197
+    h = decoder_forward(P, act, mem, cfg, taps, masks)                                # :191-197
     cmds = F.linear(h, P["predict_action_class_0_4.weight"], P["predict_action_class_0_4.bias"])      # :217
     params = F.linear(h, P["predict_action_class_0_999.weight"], P["predict_action_class_0_999.bias"]
                       ).reshape(B, T, cfg["num_params"], cfg["num_params_values"])                   # :218
@@ -334,11 +340,13 @@ class OracleTrainer:
         self.t = 0
         self.lr, self.betas, self.eps, self.max_norm, self.use_mse = lr, betas, eps, max_norm, use_mse
 
+    masks: Optional[dict] = None            # explicit dropout keep-multipliers (train-mode checks); None = eval mode
+
     def forward(self, batch: dict, taps: Optional[dict] = None):
         frames = torch.as_tensor(batch["frames"], dtype=torch.float32)
         actions = torch.as_tensor(batch["actions"], dtype=torch.float32)
         cad = torch.as_tensor(batch["cad_image"], dtype=torch.float32)
-        cmds, params = model_forward(self.P, frames[:, :-1], normalize_actions(actions[:, :-1]), cad, self.cfg, taps)
+        cmds, params = model_forward(self.P, frames[:, :-1], normalize_actions(actions[:, :-1]), cad, self.cfg, taps, self.masks)
         return cmds, params, actions[:, 1:]
 
     def loss_and_grads(self, batch: dict):

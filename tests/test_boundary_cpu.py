@@ -76,6 +76,7 @@ def test_autograd_bridge_and_trainer_step_under_emulator(emu, tmp_path, monkeypa
     shapes = O.param_shapes(ocfg)
     weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
     model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    model.eval()                                   # parity with the (eval-mode) oracle; train-mode dropout is tested with explicit masks
     batch = synth.make_batch(1, 2, seed=4)
     tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
     pk = {"loader": [tb], "sampler": None}
@@ -110,6 +111,7 @@ def _ddp_worker(rank, world, port, tmp, q):
         model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
         shapes = O.param_shapes(ocfg)
         model.load_state_dict({k: torch.from_numpy(synth.make_param(k, s)) for k, s in shapes.items()}, strict=True)
+        model.eval()
         batch = synth.make_batch(1, 2, seed=10 + rank)
         tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
         pk = {"loader": [tb], "sampler": None}

@@ -28,6 +28,7 @@ def make(dtype, tmp_path):
     os.chdir(tmp_path)
     sd = {k: synth.make_param_torch(k, s, DEV) for k, s in O.param_shapes().items()}
     model, mtype = ModelFactory().create_model(CANON["model_name"], dict(CANON, compute_dtype=dtype), DEV, state_dict=sd)
+    model.eval()            # goldens were captured with dropout off (the reference's _process_batch does not switch modes)
     pk = {"loader": [], "sampler": None}
     tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, DEV, mtype, rank=0)
     return model, tr
@@ -73,6 +74,7 @@ def test_reference_style_loop_through_autograd_f32(golden_dir, tmp_path):
 
 def test_bf16_trainer_runs_and_sequential_inference(tmp_path):
     model, tr = make("bf16", tmp_path)
+    model.train()           # dropout 0.1 active: the train loop of the reference
     batch = synth.make_batch_torch(2, 6, 5, "cpu")
     l0, _ = tr._process_batch(batch)
     for _ in range(3):

@@ -88,3 +88,68 @@ def test_engine_forward_bf16_close(emu):
     cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
     assert U.relerr(pars, opars) < 3e-2, U.relerr(pars, opars)
     assert U.relerr(cmds, ocmds) < 3e-2
+
+
+def engine_masks(eng, cfg, B, T):
+    """Rebuild every dropout keep-multiplier tensor the engine uses (vcad_debug_dropout_mask) in the oracle's tensor shapes.
+    The last ViT layer computes the cls row only, so its site masks are indexed per frame: cls rows get them, the unused
+    rows get 1."""
+    M, P1, D, Hh = B * T, 50, cfg["vit_dim"], cfg["vit_heads"]
+    masks = {}
+    for v, (pre, N) in enumerate((("state_embedding_model.", M), ("cad_embedding_model.", B))):
+        mod = v + 1
+        masks[pre + "emb"] = eng.dropout_mask(mod, 0, 1, N * P1 * D).reshape(N, P1, D)
+        for L in range(cfg["vit_depth"]):
+            last = L == cfg["vit_depth"] - 1
+            if not last:
+                masks[f"{pre}L{L}.attn"] = eng.dropout_mask(mod, L, 2, N * Hh * P1 * P1).reshape(N, Hh, P1, P1)
+                for kind, name in ((3, "out"), (4, "mlp_act"), (5, "mlp_out")):
+                    masks[f"{pre}L{L}.{name}"] = eng.dropout_mask(mod, L, kind, N * P1 * D).reshape(N, P1, D)
+            else:
+                a = torch.ones(N, Hh, P1, P1); a[:, :, 0, :] = eng.dropout_mask(mod, L, 2, N * Hh * P1).reshape(N, Hh, P1)
+                masks[f"{pre}L{L}.attn"] = a
+                for kind, name in ((3, "out"), (4, "mlp_act"), (5, "mlp_out")):
+                    t = torch.ones(N, P1, D); t[:, 0, :] = eng.dropout_mask(mod, L, kind, N * D).reshape(N, D)
+                    masks[f"{pre}L{L}.{name}"] = t
+    H, nh = cfg["hidden_size"], cfg["nhead"]
+    for L in range(cfg["num_decoder_layers"]):
+        masks[f"dec{L}.sa"] = eng.dropout_mask(3, L, 6, B * nh * T * T).reshape(B, nh, T, T)
+        masks[f"dec{L}.sa_out"] = eng.dropout_mask(3, L, 7, M * H).reshape(B, T, H)
+        masks[f"dec{L}.ca"] = eng.dropout_mask(3, L, 8, B * nh * T * T).reshape(B, nh, T, T)
+        masks[f"dec{L}.ca_out"] = eng.dropout_mask(3, L, 9, M * H).reshape(B, T, H)
+        masks[f"dec{L}.ff_act"] = eng.dropout_mask(3, L, 10, M * cfg["dim_feedforward"]).reshape(B, T, cfg["dim_feedforward"])
+        masks[f"dec{L}.ff_out"] = eng.dropout_mask(3, L, 11, M * H).reshape(B, T, H)
+    return masks
+
+
+def test_engine_train_mode_dropout_matches_oracle_with_same_masks(emu):
+    """Train mode (p = 0.1 at every dropout site of the reference forward): the engine's counter-based masks are exported
+    and fed to the oracle as explicit multipliers; forward, loss and every gradient must still agree."""
+    cfg = small_cfg(vit_depth=2, num_decoder_layers=1)
+    eng, weights = build(cfg, L.VCAD_F32, emu)
+    B, T = 2, 3
+    eng.set_dropout(0.1, seed=1234)
+    batch = synth.make_batch(B, T, seed=6)
+    ot = O.OracleTrainer(weights, cfg)
+    ot.masks = engine_masks(eng, cfg, B, T)
+    kept = float(torch.cat([m.reshape(-1) for m in ot.masks.values()]).ne(0).float().mean())
+    assert 0.85 < kept < 0.95                                       # p = 0.1 (the cls-only sites are padded with ones)
+    oloss, ometrics, ocmds, opars = ot.loss_and_grads(batch)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    assert U.relerr(pars, opars) < 1e-5 and U.relerr(cmds, ocmds) < 1e-5, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
+    loss, met = eng.loss(cmds, pars, actions[:, 1:])
+    assert abs(float(loss[0]) - float(oloss)) < 2e-5 * max(1.0, abs(float(oloss)))
+    eng.backward()
+    worst = ("", 0.0)
+    for k in weights:
+        g = eng.view(k, eng.grads); og = ot.P[k].grad
+        denom = float(og.norm())
+        err = float((g - og).norm()) / (denom + 1e-12) if denom > 0 else float(g.abs().max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 2e-4, worst
+    # a different seed gives different masks; p = 0 restores the eval-mode forward
+    eng.set_dropout(0.1, seed=99)
+    c2, p2 = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    assert U.relerr(p2, pars) > 1e-3

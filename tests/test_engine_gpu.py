@@ -166,3 +166,47 @@ def test_fused_loss_matches_reference_loss_cases(golden_dir):
         out, met = eng.loss(cm, pm, acts, use_mse=False, class_weights=cw)
         assert abs(float(out[0]) - c["loss_no_mse"]) < 2e-5 * max(1.0, abs(c["loss_no_mse"])), (name, float(out[0]), c["loss_no_mse"])
         assert metrics_from_counters(met.tolist()) == c["metrics_no_mse"], name
+
+
+def _masks_for(eng, B, T):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("engine_emu_helpers", os.path.join(os.path.dirname(__file__), "test_engine_emu.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod.engine_masks(eng, O.CANONICAL_CONFIG, B, T)
+
+
+@pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(L.VCAD_F32, 1e-4, 2e-3), (L.VCAD_BF16, 3e-2, 6e-2)])
+def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol_grad):
+    """Canonical model, p = 0.1 at every site: the engine's masks are exported (vcad_debug_dropout_mask) and applied by the
+    oracle as explicit multipliers.  fp32 mode must agree tightly; bf16 mode (MFMA attention path with in-register masks)
+    within bf16 tolerance."""
+    eng = build(dtype)
+    B, T = 2, 4
+    eng.set_dropout(0.1, seed=77)
+    batch = synth.make_batch(B, T, seed=8)
+    weights = {k: eng.view(k).cpu().numpy() for k in eng.table}
+    ot = O.OracleTrainer(weights)
+    ot.masks = _masks_for(eng, B, T)
+    oloss, ometrics, ocmds, opars = ot.loss_and_grads(batch)
+    fr = torch.from_numpy(batch["frames"]).to(DEV); ac = torch.from_numpy(batch["actions"]).to(DEV); cad = torch.from_numpy(batch["cad_image"]).to(DEV)
+    cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
+    assert U.relerr(pars, opars) < tol_logit and U.relerr(cmds, ocmds) < tol_logit, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
+    loss, _ = eng.loss(cmds, pars, ac[:, 1:])
+    assert abs(float(loss[0]) - float(oloss)) < max(tol_logit, 1e-4) * abs(float(oloss))
+    eng.backward()
+    rels = []
+    for k in weights:
+        og = ot.P[k].grad
+        if float(og.norm()) > 1e-7:
+            rels.append((U.relerr(eng.view(k, eng.grads), og), k))
+    worst = max(rels)
+    med = float(np.median([r for r, _ in rels]))
+    print(f"\n[dropout, dtype={dtype}] grad rel err: median {med:.3e}, worst {worst}")
+    assert med < tol_grad and worst[0] < 40 * tol_grad, worst
+    # eval mode is unaffected by the armed seed once p = 0
+    eng.set_dropout(0.0, 0)
+    c0, p0 = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
+    ot.masks = None
+    with torch.no_grad():
+        oc, op, _ = ot.forward(batch)
+    assert U.relerr(p0, op) < tol_logit

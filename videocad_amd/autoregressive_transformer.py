@@ -11,7 +11,8 @@ Differences that are deliberate and documented in DESIGN.md:
     Adam and the RCCL all-reduce run over contiguous memory
   * wiring implemented natively: encoder="vit", enable_past_states and enable_past_actions both True (the configuration
     `main.py` and the README run); other wirings raise NotImplementedError instead of silently computing something else
-  * dropout: the native path currently runs with p = 0 (DESIGN.md "Known gaps")
+  * dropout is a stateless counter-based mask (hash of step seed, site, element index) regenerated in the backward:
+    statistically equivalent to nn.Dropout at the same sites, not bit-identical to torch's Philox stream
 There is no CPU fallback: calling forward on a non-CUDA module raises.
 """
 from __future__ import annotations
@@ -105,6 +106,7 @@ class AutoRegressiveTransformer(nn.Module):
             _attach(self, name, nn.Parameter(self._engine.view(name), requires_grad=True))
         self._plist = [dict(self.named_parameters())[n] for n in self._param_names]
         self._shadow_fresh = False
+        self._drop_step = 0
         self.reset_parameters()
         if not enable_timestep_embedding:                                     # reference :144-147: zeros instead of the table
             with torch.no_grad():
@@ -171,6 +173,16 @@ class AutoRegressiveTransformer(nn.Module):
         self._shadow_fresh = False
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
+    def _arm_dropout(self):
+        """train(): p = dropout with a fresh seed per forward (the backward reuses it); eval(): off."""
+        if self.training and self.dropout_p > 0:
+            self._drop_step += 1
+            self._engine.set_dropout(self.dropout_p, seed=(self._drop_seed_base << 20) + self._drop_step)
+        else:
+            self._engine.set_dropout(0.0, 0)
+
+    _drop_seed_base = 0x5EED
+
     def mark_shadow_fresh(self):
         """The native optimiser step rewrites the bf16 weight shadow itself; anything else (torch optimisers,
         load_state_dict, manual edits) leaves it stale, so forward re-casts it unless this was called."""
@@ -206,6 +218,7 @@ class AutoRegressiveTransformer(nn.Module):
         if not self._shadow_fresh:
             self._engine.sync_shadow()
         self._shadow_fresh = False
+        self._arm_dropout()
         frames = frames.float(); actions = actions.float(); cad = cad.float()
         if torch.is_grad_enabled():
             cmds, pars = _EngineFn.apply(self, frames, actions, cad, *self._plist)

@@ -53,8 +53,8 @@ def synthetic_batch(B, T, seed, device):
 class Stepper:
     """One optimiser step = BaseTrainer._process_batch (reference trainer.py:480-496) on the native engine."""
 
-    def __init__(self, eng: NativeEngine, world: int, rank: int):
-        self.eng, self.world, self.rank = eng, world, rank
+    def __init__(self, eng: NativeEngine, world: int, rank: int, dropout: float = 0.1):
+        self.eng, self.world, self.rank, self.dropout, self.nstep = eng, world, rank, dropout, 0
         self.comm_stream = torch.cuda.Stream(device=eng.device) if world > 1 else None
 
     def step(self, frames, actions, cad):
@@ -62,6 +62,8 @@ class Stepper:
         eng = self.eng
         an = actions[:, :-1].clone()
         an[:, :, 0] /= 4.0; an[:, :, 1:] /= 1000.0                               # reference trainer.py:800-804
+        self.nstep += 1
+        eng.set_dropout(self.dropout, seed=self.nstep)                            # train mode (reference: dropout 0.1 everywhere)
         cmds, pars = eng.forward(frames[:, :-1], an, cad)
         loss, met = eng.loss(cmds, pars, actions[:, 1:])
         if self.world == 1:
@@ -136,7 +138,7 @@ def run(args):
     eng = NativeEngine(make_config(dtype=dt, **CANONICAL), device)
     init_weights(eng, device)
     frames, actions, cad = synthetic_batch(B, T, 1000 * 2 + rank, device)
-    stepper = Stepper(eng, world, rank)
+    stepper = Stepper(eng, world, rank, dropout=args.dropout)
 
     for _ in range(args.warmup):
         stepper.step(frames, actions, cad)
@@ -186,7 +188,7 @@ def run(args):
                "dtype": args.dtype, "data": "synthetic (U[-1,1) frames in HBM, hash-init weights)",
                "config": {"workload": f"autoregressive_transformer bf16 seq_len={T} batch={B} per GPU, 1xMI355X (BASELINE configs[1])"
                           if (T, B) == (64, 32) else f"canonical model seq_len={T} batch={B} per GPU",
-                          "clips_per_gpu": B, "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "dropout": args.dropout, "clips_per_gpu": B, "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",
                           "loss": float(loss[0].item())},
                "roofline": roof, "kernel_breakdown": breakdown}
         if world == 1 and not args.no_cpu_baseline:

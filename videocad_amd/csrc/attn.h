@@ -29,6 +29,7 @@ struct AttnParams {
     const void* dout; long lddo;                                 // type T
     void* dq; void* dk; void* dv; long lddq, lddk, lddv;         // type T
     float* delta;                                                // [B][H][Tq]  D_i
+    vc_drop drop;                                                // attention-probability dropout, idx = ((b*H+h)*Tq+i)*Tk+j (key 0 = off)
 };
 
 // sum_d row[d] * bc[d]; bc: LDS, same address for all lanes (broadcast).  The row is walked in 16-byte chunks, four
@@ -121,6 +122,11 @@ VC_KERNEL __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) { s[ps] = (ps * 64 + lane < nk) ? expf(s[ps] - m) : 0.f; l += s[ps]; }
     l = vc_wave_sum(l);
+    if (p.drop.key) {                                            // dropout acts on the normalised probabilities, not on l
+        const long base = (((long)b * p.H + h) * p.Tq + i) * p.Tk + lo;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) if (ps * 64 + lane < nk) s[ps] *= vc_drop_mul(p.drop, base + ps * 64 + lane);
+    }
     float acc[DPL];
 #pragma unroll
     for (int j = 0; j < DPL; ++j) acc[j] = 0.f;
@@ -169,6 +175,7 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_q_kernel(AttnParams p) {
             const T* vrow = (const T*)p.v + ((long)b * p.Tk + lo + jj) * p.ldv + h * D;
             pr[ps] = expf(attn_dot_row<T, D>(krow, qs[wave]) * p.scale - lse);
             dp[ps] = attn_dot_row<T, D>(vrow, dos[wave]);
+            if (p.drop.key) dp[ps] *= vc_drop_mul(p.drop, (((long)b * p.H + h) * p.Tq + i) * p.Tk + lo + jj);   // dP = dP' * mask
         }
         dsum += pr[ps] * dp[ps];
     }
@@ -221,7 +228,9 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
             const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D;
             const T* dorow = (const T*)p.dout + ((long)b * p.Tq + i) * p.lddo + h * D;
             pr[ps] = expf(attn_dot_row<T, D>(qrow, ks[wave]) * p.scale - p.lse[sidx]);
-            ds[ps] = pr[ps] * (attn_dot_row<T, D>(dorow, vs[wave]) - p.delta[sidx]);
+            const float ms = p.drop.key ? vc_drop_mul(p.drop, (((long)b * p.H + h) * p.Tq + i) * p.Tk + jk) : 1.0f;
+            ds[ps] = pr[ps] * (attn_dot_row<T, D>(dorow, vs[wave]) * ms - p.delta[sidx]);
+            pr[ps] *= ms;                                        // dV uses the dropped probabilities
         }
     }
     float dk[DPL], dv[DPL];
@@ -268,10 +277,12 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_single_query_kernel(AttnParams p)
     const T* vrow = (const T*)p.v + (b * p.Tk + (on ? lane : 0)) * p.ldv + h * D;
     float pr = 0.f, dp = 0.f;
     if (on) { pr = expf(attn_dot_row<T, D>(krow, qs[wave]) * p.scale - lse); dp = attn_dot_row<T, D>(vrow, dos[wave]); }
+    const float ms = (p.drop.key && on) ? vc_drop_mul(p.drop, wid * p.Tk + lane) : 1.0f;       // Tq = 1: idx = (b*H+h)*Tk + j
+    dp *= ms;
     const float dsum = vc_wave_sum(pr * dp);
     const float ds = pr * (dp - dsum);
     dss[wave][lane] = ds;
-    pss[wave][lane] = pr;
+    pss[wave][lane] = pr * ms;
     vc_wave_barrier();
     {   // dk_j = scale * dS_j * q ;  dv_j = P_j * dO   — lane = dims, so every key row is one coalesced store
         float qv[DPL], dov[DPL];

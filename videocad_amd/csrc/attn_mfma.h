@@ -62,6 +62,16 @@ VC_DEV vc_s16x8 am_pack(const vc_f32x16& a, int s) {
     for (int j = 0; j < 8; ++j) r[j] = (short)vc_f32_to_bf16(a[8 * s + j]).bits;
     return r;
 }
+// same, with the dropout keep-multipliers of tile (ti, tj) applied while packing (P' = P * mask never materialised in fp32)
+VC_DEV vc_s16x8 am_pack_keep(const vc_f32x16& a, int s, uint64_t keep, int ti, int tj, float scale) {
+    vc_s16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float m = ((keep >> ((ti * 2 + tj) * 16 + 8 * s + j)) & 1) ? scale : 0.0f;
+        r[j] = (short)vc_f32_to_bf16(a[8 * s + j] * m).bits;
+    }
+    return r;
+}
 VC_DEV int am_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }   // row inside a 32x32 D tile
 
 VC_DEV void am_zero(vc_f32x16 (&a)[2][2]) {
@@ -101,6 +111,24 @@ VC_DEV void am_mm_tok(vc_f32x16 (&out)[2][2], const vc_f32x16 (&W)[2][2], const 
                 for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
         }
 }
+template <bool DROP>
+VC_DEV void am_mm_tok_keep(vc_f32x16 (&out)[2][2], const vc_f32x16 (&W)[2][2], const vc_bf16* Y, int lane, uint64_t keep, float scale) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            vc_s16x8 a[2], b[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                a[o] = DROP ? am_pack_keep(W[tt][o], s, keep, tt, o, scale) : am_pack(W[tt][o], s);
+                b[o] = am_frag_tr(Y, tt * 32 + 16 * s, o * 32, lane);
+            }
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
+        }
+}
 // store a [64 x 64] result grid (rows = tokens, lane column = d) as bf16, rows < T only
 VC_DEV void am_store(vc_bf16* g, long ld, const vc_f32x16 (&acc)[2][2], int T, int lane, float mul) {
 #pragma unroll
@@ -114,6 +142,31 @@ VC_DEV void am_store(vc_bf16* g, long ld, const vc_f32x16 (&acc)[2][2], int T, i
             }
 }
 
+// Keep-bits of the attention-probability dropout for this lane's 64 accumulator elements (2x2 tiles x 16 registers),
+// packed into one 64-bit word so the mask costs 2 registers instead of 64 live multipliers.
+// bit (ti*2 + tj)*16 + r  <->  element (row = ti*32 + am_row(r), lane column = tj*32 + (lane&31)) of a grid whose rows are
+// keys and columns queries when QCOL, else rows = queries and columns = keys.   idx = base + query*T + key.
+template <bool QCOL>
+VC_DEV uint64_t am_keep_bits(const vc_drop& d, uint32_t base, int T, int lane) {
+    uint32_t lo = 0, hi = 0;                  // tiles (0,0),(0,1) -> lo ; (1,0),(1,1) -> hi   (rolled loop: keeps register pressure flat)
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ti = t >> 1, tj = t & 1;
+            const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
+            const int query = QCOL ? col : row, key = QCOL ? row : col;
+            const uint32_t h = vc_hash32(((base + (uint32_t)(query * T + key)) * 0x9E3779B1u) ^ d.key);
+            const uint32_t bit = ((h >> 8) >= d.thr) ? 1u : 0u;
+            if (ti == 0) lo |= bit << (tj * 16 + r); else hi |= bit << (tj * 16 + r);
+        }
+    }
+    const uint64_t bits = (uint64_t)lo | ((uint64_t)hi << 32);
+    return bits;
+}
+VC_DEV float am_keep(uint64_t bits, int ti, int tj, int r, float scale) { return ((bits >> ((ti * 2 + tj) * 16 + r)) & 1) ? scale : 0.0f; }
+
+template <bool DROP>
 VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[3][AM_T * AM_S];
     const int lane = threadIdx.x;
@@ -124,6 +177,9 @@ VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
     am_stage(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, lane);
     am_stage(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, lane);
     vc_wave_barrier();
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    uint64_t keep = 0;
+    if (DROP) keep = am_keep_bits<true>(p.drop, dbase0, T, lane);
     vc_f32x16 st[2][2];                       // S^T: [key tile][query tile], lane column = query
     am_zero(st);
     am_mm_nt(st, tiles[1], tiles[0], lane);
@@ -146,11 +202,11 @@ VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
         l += vc_shfl_xor(l, 32);
         const float inv = 1.0f / l;
+        const int query = qt * 32 + (lane & 31);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kt][qt][r] *= inv;
-        const int query = qt * 32 + (lane & 31);
+            for (int r = 0; r < 16; ++r) st[kt][qt][r] *= DROP ? inv * am_keep(keep, kt, qt, r, p.drop.scale) : inv;
         if (p.lse && lane < 32 && query < T) p.lse[(n * p.H + h) * T + query] = m + logf(l);
     }
     vc_f32x16 o[2][2];
@@ -182,6 +238,7 @@ VC_DEV void am_stage_nt(vc_bf16* tile, const vc_bf16* g, long ld, int T, int tid
 // "lane = query" orientation (D_i, dQ), wave 1 the "lane = key" orientation (dV, dK).  Wave 1 runs its two S / dP
 // MFMA grids while wave 0 produces D_i; the hand-off is the block barrier.  Halving the per-wave accumulator set
 // lifts occupancy from 1 to 2 waves per SIMD (8 waves per CU, LDS-limited at 37 KB per block).
+template <bool DROP>
 VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO
     VC_SHARED float lse_s[AM_T];
@@ -198,7 +255,10 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) 
     vc_sync();
     const vc_bf16 *Qs = tiles[0], *Ks = tiles[1], *Vs = tiles[2], *dOs = tiles[3];
 
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
     if (wave == 0) {   // ---------------- lane = query:  D_i, dQ
+        uint64_t keep = 0;
+        if (DROP) keep = am_keep_bits<true>(p.drop, dbase0, T, lane);
         vc_f32x16 st[2][2], dpt[2][2];
         am_zero(st); am_zero(dpt);
         am_mm_nt(st, Ks, Qs, lane);          // S^T[key][query]
@@ -213,7 +273,9 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 32 + am_row(r, lane);
-                    const float pr = (key < T && query < T) ? expf(st[kt][qt][r] * p.scale - lse) : 0.f;
+                    const bool ok = key < T && query < T;
+                    const float pr = ok ? expf(st[kt][qt][r] * p.scale - lse) : 0.f;
+                    if (DROP) dpt[kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);                    // dP = dP' * mask
                     st[kt][qt][r] = pr; dsum += pr * dpt[kt][qt][r];
                 }
             dsum += vc_shfl_xor(dsum, 32);
@@ -229,11 +291,12 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) 
         am_mm_tok(dq, st, Ks, lane);         // dQ[query][d] = sum_key dS[query][key] K[key][d]
         am_store((vc_bf16*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, T, lane, p.scale);
     } else {           // ---------------- lane = key:  dV, dK
-        vc_f32x16 sn[2][2], dp[2][2];
-        am_zero(sn); am_zero(dp);
+        uint64_t keep = 0;
+        if (DROP) keep = am_keep_bits<false>(p.drop, dbase0, T, lane);
+        // ordered so that at most two 64-register grids are live: S -> P ; dV = P'^T dO ; dP ; dS ; dK = dS^T Q
+        vc_f32x16 sn[2][2];
+        am_zero(sn);
         am_mm_nt(sn, Qs, Ks, lane);          // S[query][key]   (grid [query tile][key tile], lane column = key)
-        am_mm_nt(dp, dOs, Vs, lane);         // dP[query][key]
-        vc_sync();                           // D_i from wave 0
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int key = kt * 32 + (lane & 31);
@@ -242,15 +305,30 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int query = qt * 32 + am_row(r, lane);
-                    const float pr = (key < T && query < T) ? expf(sn[qt][kt][r] * p.scale - lse_s[query]) : 0.f;
-                    sn[qt][kt][r] = pr;
-                    dp[qt][kt][r] = pr * (dp[qt][kt][r] - del_s[query]);
+                    sn[qt][kt][r] = (key < T && query < T) ? expf(sn[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
                 }
         }
+        {
+            vc_f32x16 acc[2][2];
+            am_zero(acc);
+            am_mm_tok_keep<DROP>(acc, sn, dOs, lane, keep, p.drop.scale);     // dV[key][d] = sum_query P'[query][key] dO[query][d]
+            am_store((vc_bf16*)p.dv + rowq * p.lddv + h * AM_D, p.lddv, acc, T, lane, 1.0f);
+        }
+        vc_f32x16 dp[2][2];
+        am_zero(dp);
+        am_mm_nt(dp, dOs, Vs, lane);         // dP'[query][key]
+        vc_sync();                           // D_i from wave 0
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + am_row(r, lane);
+                    const float ms = DROP ? am_keep(keep, qt, kt, r, p.drop.scale) : 1.0f;
+                    dp[qt][kt][r] = sn[qt][kt][r] * (dp[qt][kt][r] * ms - del_s[query]);                          // dS
+                }
         vc_f32x16 acc[2][2];
-        am_zero(acc);
-        am_mm_tok(acc, sn, dOs, lane);       // dV[key][d] = sum_query P[query][key] dO[query][d]
-        am_store((vc_bf16*)p.dv + rowq * p.lddv + h * AM_D, p.lddv, acc, T, lane, 1.0f);
         am_zero(acc);
         am_mm_tok(acc, dp, Qs, lane);        // dK[key][d] = sum_query dS[query][key] Q[query][d]
         am_store((vc_bf16*)p.dk + rowq * p.lddk + h * AM_D, p.lddk, acc, T, lane, p.scale);

@@ -31,6 +31,7 @@ struct Epi {
     const float* rowadd = nullptr; int rdiv = 1, rmod = 0; long ldrow = 0;
     void* aux = nullptr; long ldaux = 0;
     const void* dact = nullptr; long lddact = 0; int dkind = 0;
+    vc_drop drop = {0u, 0u, 1.0f};
 };
 
 struct VitW {       // float offsets into the flat buffer
@@ -71,6 +72,8 @@ struct vcad_engine {
     float *scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
     float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
+    // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
+    float drop_p = 0.f; uint64_t drop_seed = 0; void* t_dum = nullptr;
 };
 
 namespace {
@@ -203,6 +206,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     e->t_dx = b.take<float>(R * D * 4); e->t_dpe = b.take<float>(Rp * D * 4); e->t_dz = b.take<void>(R * c.vit_mlp * es);
     e->t_dh = b.take<void>(R * D * es); e->t_dao = b.take<void>(R * inner * es); e->t_dqkv = b.take<void>(R * 3 * inner * es);
     e->t_dpn = b.take<void>(Rp * pd * es);
+    e->t_dum = b.take<void>((R * D > M * H ? R * D : M * H) * 4);
     long dmax = (long)B * c.nhead * T; long vmax = M * c.vit_heads * (P + 1);
     e->t_delta = b.take<float>((dmax > vmax ? dmax : vmax) * 4);
     e->t_dmem = b.take<float>(M * H * 4); e->t_dcur = b.take<float>(M * H * 4); e->t_dui = b.take<float>(M * H * 4); e->t_dpre = b.take<float>(M * H * 4);
@@ -236,6 +240,22 @@ struct Ctx {
     Mat A32(const float* p, long ld) const { return Mat{p, VC_F32, ld}; }
     Mat AT(const void* p, long ld) const { return Mat{p, e->dt, ld}; }
 
+    // dropout site ids: (module << 16) | (layer << 8) | kind; module 1 = frame ViT, 2 = CAD ViT, 3 = decoder
+    enum { K_EMB = 1, K_ATTN = 2, K_OUT = 3, K_MLP_ACT = 4, K_MLP_OUT = 5, K_SA = 6, K_SA_OUT = 7, K_CA = 8, K_CA_OUT = 9, K_FF_ACT = 10, K_FF_OUT = 11 };
+    vc_drop site(int module, int layer, int kind) const {
+        vc_drop d = {0u, 0u, 1.0f};
+        if (e->drop_p > 0.f) {
+            d.key = vc_drop_key(e->drop_seed, ((uint32_t)module << 16) | ((uint32_t)layer << 8) | (uint32_t)kind);
+            d.thr = (uint32_t)(e->drop_p * 16777216.0f); d.scale = 1.0f / (1.0f - e->drop_p);
+        }
+        return d;
+    }
+    // masked copy of a residual-stream gradient: du = dx * mask (type T, compact [rows, cols]); returns the matrix to feed wgrad / dgrad
+    int masked(const float* dx, long ldx, long rows, int cols, vc_drop d, Mat* out) const {
+        if (!d.key) { *out = A32(dx, ldx); return 0; }
+        *out = AT(e->t_dum, cols);
+        return vc_dropout_mul(e->dt, dx, ldx, e->t_dum, cols, rows, cols, d, s);
+    }
     int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep) const {
         GemmCall c; memset(&c, 0, sizeof(c));
         c.ct = e->dt; c.sa = A.dt; c.sb = B.dt; c.to = C.dt; c.tra = tra; c.trb = trb;
@@ -243,7 +263,7 @@ struct Ctx {
         p.A = A.p; p.B = B.p; p.C = (void*)C.p; p.M = M; p.N = N; p.K = K; p.lda = A.ld; p.ldb = B.ld; p.ldc = C.ld;
         p.alpha = 1.0f; p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr;
         p.rowadd = ep.rowadd; p.rowadd_div = ep.rdiv; p.rowadd_mod = ep.rmod; p.ld_rowadd = ep.ldrow;
-        p.aux = ep.aux; p.ldaux = ep.ldaux; p.dact_src = ep.dact; p.lddact = ep.lddact; p.dact_kind = ep.dkind;
+        p.aux = ep.aux; p.ldaux = ep.ldaux; p.dact_src = ep.dact; p.lddact = ep.lddact; p.dact_kind = ep.dkind; p.drop = ep.drop;
         return vc_gemm(c, e->scr_splitk, e->scr_splitk_bytes, s);
     }
     // Y[M,N] = X[M,K] W[N,K]^T (+ epilogue)
@@ -292,7 +312,7 @@ int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bst
     {   // LN(512) + cls + pos  -> x0
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = a.pe; p.ldx = D; p.gamma = cx.Pf(w.ln2w); p.beta = cx.Pf(w.ln2b); p.y32 = a.x0; p.ldy32 = D; p.stats = a.stat2;
-        p.rows = R; p.eps = 1e-5f; p.pos = cx.Pf(w.pos); p.cls = cx.Pf(w.cls); p.P = P;
+        p.rows = R; p.eps = 1e-5f; p.pos = cx.Pf(w.pos); p.cls = cx.Pf(w.cls); p.P = P; p.drop = cx.site(v + 1, 0, Ctx::K_EMB);
         CK(vc_ln_fwd(VC_F32, VC_F32, D, 2, p, cx.s));
     }
     const float* x = a.x0;
@@ -309,25 +329,27 @@ int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bst
         ap.q = q; ap.k = q + (size_t)inner * e->esz; ap.v = q + (size_t)2 * inner * e->esz; ap.o = l.ao;
         ap.ldq = ap.ldk = ap.ldv = 3 * inner; ap.ldo = inner; ap.lse = l.lse;
         ap.B = (int)N; ap.H = c.vit_heads; ap.Tq = ap.Tk = P + 1; ap.window = P + 1; ap.causal = 0; ap.scale = scale;
+        ap.drop = cx.site(v + 1, L, Ctx::K_ATTN);
+        const vc_drop d_out = cx.site(v + 1, L, Ctx::K_OUT), d_act = cx.site(v + 1, L, Ctx::K_MLP_ACT), d_mlp = cx.site(v + 1, L, Ctx::K_MLP_OUT);
         if (!cls_only) {
             CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
-            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
+            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; ep.drop = d_out; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
             CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
-            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp;
+            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
               CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
-            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D;
+            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
               CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
         } else {
             CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv + (long)inner * D, D), cx.AT(q + (size_t)inner * e->esz, 3 * inner), (int)R, 2 * inner, D, Epi()));   // K, V: all tokens
             CK(cx.lin_fwd(cx.AT(l.h_a, TD), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * TI), (int)N, inner, D, Epi()));                                       // Q: cls rows
             ap.Tq = 1; ap.ldq = 3 * TI; ap.ldo = TI;                                   // query row b -> cls row of frame b
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
-            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = TD; CK(cx.lin_fwd(cx.AT(l.ao, TI), cx.W(wl.ow, inner), cx.A32(l.xm, TD), (int)N, D, inner, ep)); }
+            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = TD; ep.drop = d_out; CK(cx.lin_fwd(cx.AT(l.ao, TI), cx.W(wl.ow, inner), cx.A32(l.xm, TD), (int)N, D, inner, ep)); }
             CK(cx.ln_fwd(VC_F32, l.xm, TD, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, N, D));                   // h_f, z, g: compact [N, .]
-            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp;
+            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
               CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)N, c.vit_mlp, D, ep)); }
-            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = TD;
+            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = TD; ep.drop = d_mlp;
               CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, TD), (int)N, D, c.vit_mlp, ep)); }
         }
         x = l.xo;
@@ -359,16 +381,19 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         const bool cls_only = (L == c.vit_depth - 1);          // see vit_forward: dx is non-zero on cls rows only here
         const long Rm = cls_only ? N : R;                       // rows the MLP / out-proj backward runs over
         const long ldx = cls_only ? TD : D, ldao = cls_only ? TI : inner;
-        // MLP
-        CK(cx.lin_wgrad(cx.A32(dx, ldx), cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
-        { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU;
-          CK(cx.lin_dgrad(cx.A32(dx, ldx), cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
+        // MLP (x' = xm + drop(W4 drop(gelu(z)) + b4)): the gradient entering W4 is dx * mask_out
+        Mat du;
+        CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));
+        CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
+        { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
+          CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
         CK(cx.lin_wgrad(cx.AT(e->t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
         CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         CK(cx.ln_bwd(e->dt, e->t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D));
-        // attention block
-        CK(cx.lin_wgrad(cx.A32(dx, ldx), cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
-        CK(cx.lin_dgrad(cx.A32(dx, ldx), cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
+        // attention block (xm = x + drop(Wo ao + bo))
+        CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du));
+        CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
+        CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
         {
             AttnParams p; memset(&p, 0, sizeof(p));
             const char* q = (const char*)l.qkv; char* dq = (char*)e->t_dqkv;
@@ -377,6 +402,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             p.dout = e->t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
             p.lddq = p.lddk = p.lddv = 3 * inner;
             p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
+            p.drop = cx.site(v + 1, L, Ctx::K_ATTN);
             if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero
                 CK(vc_memset_async(e->t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
                 p.Tq = 1; p.ldq = 3 * TI; p.lddq = 3 * TI;
@@ -388,6 +414,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.ln_bwd(e->dt, e->t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
     }
     if (part != 1) {
+        { const vc_drop d = cx.site(v + 1, 0, Ctx::K_EMB);      // emb_dropout: everything below sees dx * mask
+          if (d.key) CK(vc_dropout_mul(VC_F32, dx, D, dx, D, R, D, d, cx.s)); }
         // pos / cls gradients: column sums over frames of dx viewed as [N, (P+1)*D]
         CK(cx.colsum(cx.A32(dx, (long)(P + 1) * D), N, (P + 1) * D, cx.Gf(w.pos), 0));
         CK(vc_memcpy_d2d_async(cx.Gf(w.cls), cx.Gf(w.pos), (size_t)D * 4, cx.s));
@@ -410,11 +438,11 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
 }
 
 int dec_attn(const Ctx& cx, bool bwd, const void* q, long ldq, const void* k, const void* v, long ldkv, void* o, float* lse,
-             int window, const void* dout, void* dq, void* dk, void* dv, long lddq, long lddkv) {
+             int window, const void* dout, void* dq, void* dk, void* dv, long lddq, long lddkv, vc_drop drop) {
     vcad_engine* e = cx.e; const vcad_config& c = e->c;
     AttnParams p; memset(&p, 0, sizeof(p));
     p.q = q; p.k = k; p.v = v; p.o = o; p.ldq = ldq; p.ldk = p.ldv = ldkv; p.ldo = c.hidden_size; p.lse = lse;
-    p.B = e->B; p.H = c.nhead; p.Tq = p.Tk = e->T; p.window = window; p.causal = 1;
+    p.B = e->B; p.H = c.nhead; p.Tq = p.Tk = e->T; p.window = window; p.causal = 1; p.drop = drop;
     const int hd = c.hidden_size / c.nhead;
     p.scale = 1.0f / sqrtf((float)hd);
     if (!bwd) return vc_attn_fwd(e->dt, hd, p, cx.s);
@@ -444,17 +472,17 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
         { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, 3 * H), (int)M, 3 * H, H, ep)); }
         { const char* q = (const char*)d.qkv_s;
-          CK(dec_attn(cx, false, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, T, nullptr, nullptr, nullptr, nullptr, 0, 0)); }
-        { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), (int)M, H, H, ep)); }
+          CK(dec_attn(cx, false, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, T, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_SA))); }
+        { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_SA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), (int)M, H, H, ep)); }
         CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, nullptr, 0, d.st1, M, H));
         { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), (int)M, H, H, ep)); }
         { Epi ep; ep.bias = cx.Pf(w.ca_b + H); CK(cx.lin_fwd(cx.A32(e->mem, H), cx.W(w.ca_w + (long)H * H, H), cx.AT(d.kv_c, 2 * H), (int)M, 2 * H, H, ep)); }
         { const char* kv = (const char*)d.kv_c;
-          CK(dec_attn(cx, false, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, d.ao_c, d.lse_c, c.window_size, nullptr, nullptr, nullptr, nullptr, 0, 0)); }
-        { Epi ep; ep.bias = cx.Pf(w.ca_ob); ep.residual = d.x1; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.ao_c, H), cx.W(w.ca_ow, H), cx.A32(d.s2, H), (int)M, H, H, ep)); }
+          CK(dec_attn(cx, false, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, d.ao_c, d.lse_c, c.window_size, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_CA))); }
+        { Epi ep; ep.bias = cx.Pf(w.ca_ob); ep.residual = d.x1; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_CA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_c, H), cx.W(w.ca_ow, H), cx.A32(d.s2, H), (int)M, H, H, ep)); }
         CK(cx.ln_fwd(VC_F32, d.s2, H, w.n2w, w.n2b, d.x2, H, nullptr, 0, d.st2, M, H));
-        { Epi ep; ep.bias = cx.Pf(w.b1); ep.act = VC_ACT_RELU; CK(cx.lin_fwd(cx.A32(d.x2, H), cx.W(w.w1, H), cx.AT(d.f1, c.dim_feedforward), (int)M, c.dim_feedforward, H, ep)); }
-        { Epi ep; ep.bias = cx.Pf(w.b2); ep.residual = d.x2; ep.ldr = H;
+        { Epi ep; ep.bias = cx.Pf(w.b1); ep.act = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT); CK(cx.lin_fwd(cx.A32(d.x2, H), cx.W(w.w1, H), cx.AT(d.f1, c.dim_feedforward), (int)M, c.dim_feedforward, H, ep)); }
+        { Epi ep; ep.bias = cx.Pf(w.b2); ep.residual = d.x2; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_FF_OUT);
           CK(cx.lin_fwd(cx.AT(d.f1, c.dim_feedforward), cx.W(w.w2, c.dim_feedforward), cx.A32(d.s3, H), (int)M, H, c.dim_feedforward, ep)); }
         CK(cx.ln_fwd(VC_F32, d.s3, H, w.n3w, w.n3b, d.x3, H, nullptr, 0, d.st3, M, H));
         x = d.x3;
@@ -481,19 +509,23 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     for (int L = c.num_decoder_layers - 1; L >= 0; --L) {
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
         const float* xin = L == 0 ? e->act : e->da[L - 1].x3;
-        // ---- FFN
+        // ---- FFN   x3 = LN3(x2 + drop(W2 drop(relu(W1 x2 + b1)) + b2))
+        Mat du;
         CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H));
-        CK(cx.lin_wgrad(cx.A32(dx, H), cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
-        { Epi ep; ep.dact = d.f1; ep.lddact = ff; ep.dkind = VC_ACT_RELU;
-          CK(cx.lin_dgrad(cx.A32(dx, H), cx.W(w.w2, ff), cx.AT(e->t_df1, ff), (int)M, H, ff, ep)); }
+        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du));
+        CK(cx.lin_wgrad(du, cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
+        { Epi ep; ep.dact = d.f1; ep.lddact = ff; ep.dkind = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT);   // f1 > 0 <=> z > 0 and kept
+          CK(cx.lin_dgrad(du, cx.W(w.w2, ff), cx.AT(e->t_df1, ff), (int)M, H, ff, ep)); }
         CK(cx.lin_wgrad(cx.AT(e->t_df1, ff), cx.A32(d.x2, H), cx.Gf(w.w1), H, cx.Gf(w.b1), (int)M, ff, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_df1, ff), cx.W(w.w1, H), cx.A32(dx, H), (int)M, ff, H, ep)); }
         // ---- cross attention
         CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H));
-        CK(cx.lin_wgrad(cx.A32(dx, H), cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
-        CK(cx.lin_dgrad(cx.A32(dx, H), cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
+        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du));
+        CK(cx.lin_wgrad(du, cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
+        CK(cx.lin_dgrad(du, cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* kv = (const char*)d.kv_c; char* dkv = (char*)e->t_dkv;
-          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, nullptr, d.lse_c, c.window_size, e->t_dao_d, e->t_dq, dkv, dkv + (size_t)H * es, H, 2 * H)); }
+          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, nullptr, d.lse_c, c.window_size, e->t_dao_d, e->t_dq, dkv, dkv + (size_t)H * es, H, 2 * H,
+                      cx.site(3, L, Ctx::K_CA))); }
         CK(cx.lin_wgrad(cx.AT(e->t_dq, H), cx.A32(d.x1, H), cx.Gf(w.ca_w), H, cx.Gf(w.ca_b), (int)M, H, H));
         CK(cx.lin_wgrad(cx.AT(e->t_dkv, 2 * H), cx.A32(e->mem, H), cx.Gf(w.ca_w + (long)H * H), H, cx.Gf(w.ca_b + H), (int)M, 2 * H, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dq, H), cx.W(w.ca_w, H), cx.A32(dx, H), (int)M, H, H, ep)); }
@@ -501,11 +533,12 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
           CK(cx.lin_dgrad(cx.AT(e->t_dkv, 2 * H), cx.W(w.ca_w + (long)H * H, H), cx.A32(e->t_dmem, H), (int)M, 2 * H, H, ep)); }
         // ---- self attention
         CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H));
-        CK(cx.lin_wgrad(cx.A32(dx, H), cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
-        CK(cx.lin_dgrad(cx.A32(dx, H), cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
+        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du));
+        CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
+        CK(cx.lin_dgrad(du, cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* q = (const char*)d.qkv_s; char* dq = (char*)e->t_dqkv_d;
           CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, nullptr, d.lse_s, T, e->t_dao_d,
-                      dq, dq + (size_t)H * es, dq + (size_t)2 * H * es, 3 * H, 3 * H)); }
+                      dq, dq + (size_t)H * es, dq + (size_t)2 * H * es, 3 * H, 3 * H, cx.site(3, L, Ctx::K_SA))); }
         CK(cx.lin_wgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.A32(xin, H), cx.Gf(w.sa_w), H, cx.Gf(w.sa_b), (int)M, 3 * H, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }
     }
@@ -590,11 +623,25 @@ size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
 }
 int vcad_set_workspace(vcad_engine* e, void* ws, size_t bytes) { e->ws = (char*)ws; e->ws_bytes = bytes; e->fwd_valid = false; e->B = e->T = 0; return 0; }
 
+int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed) {
+    if (!(p >= 0.f && p < 1.f)) { vc_set_error("vcad_set_dropout: p must be in [0, 1)"); return VC_ERR_ARG; }
+    e->drop_p = p; e->drop_seed = seed;
+    return 0;
+}
+// debug / test hook: the keep-multipliers (0 or 1/(1-p)) a site applies to elements 0..n-1, written to a HOST buffer
+int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out) {
+    Ctx cx{const_cast<vcad_engine*>(e), nullptr};
+    const vc_drop d = cx.site(module, layer, kind);
+    for (int64_t i = 0; i < n; ++i) host_out[i] = d.key ? vc_drop_mul(d, (uint32_t)i) : 1.0f;
+    return 0;
+}
+
 int vcad_forward(vcad_engine* e, const float* frames, int64_t fbstride, const float* actions, const float* cad, int B, int T,
                  float* cmds_out, float* pars_out, void* stream) {
     if (!e->P) { vc_set_error("vcad_forward: parameters not bound"); return VC_ERR_ARG; }
     if (B < 1 || T < 1 || T > e->c.max_ep_len) { vc_set_error("vcad_forward: bad B=%d T=%d", B, T); return VC_ERR_ARG; }
     if (T > 192) { vc_set_error("vcad_forward: T=%d exceeds the attention kernels' 192-key limit", T); return VC_ERR_UNSUPPORTED; }
+    if ((double)B * T * 50.0 * 3072.0 >= 4294967296.0) { vc_set_error("vcad_forward: B*T=%d too large for 32-bit dropout indices", B * T); return VC_ERR_UNSUPPORTED; }
     if (!e->ws) { vc_set_error("vcad_forward: no workspace"); return VC_ERR_WORKSPACE; }
     size_t need = plan(e, B, T, e->ws);
     if (need > e->ws_bytes) { vc_set_error("vcad_forward: workspace %zu < %zu bytes", e->ws_bytes, need); return VC_ERR_WORKSPACE; }

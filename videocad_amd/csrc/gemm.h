@@ -29,7 +29,7 @@ struct GemmParams {
     int vecC;                       // every epilogue tensor (C, residual, aux, dact_src, rowadd) allows 4-column vector rows
     // split-K: gridDim.z slices of k_per_split; partials (fp32, [z][M][N]) go to `partial`, epilogue runs in the reducer
     int k_per_split; float* partial;
-    // epilogue (applied in this order): v = alpha*acc (+bias[n]) (+rowadd[row(m)][n]); aux[m,n]=v; v=act(v); v*=dact(src[m,n]); v+=residual[m,n]
+    // epilogue (applied in this order): v = alpha*acc (+bias[n]) (+rowadd[row(m)][n]); aux[m,n]=v; v=act(v); v*=dropmask(m*N+n); v*=dact(src[m,n]); v+=residual[m,n]
     float alpha;
     const float* bias;
     const float* rowadd; int rowadd_div; int rowadd_mod; long ld_rowadd;   // row = rowadd_mod ? m % div : m / div
@@ -37,6 +37,7 @@ struct GemmParams {
     int act;
     const void* dact_src; long lddact; int dact_kind;                     // type TO
     const float* residual; long ldr;                                      // fp32, may alias C
+    vc_drop drop;                                                         // applied after act, before dact / residual (key 0 = off)
 };
 
 VC_DEV float vc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -67,6 +68,7 @@ VC_DEV void gemm_epilogue_store(const GemmParams& p, int m, int n, float acc, fl
     }
     if (p.aux) vc_st(((TO*)p.aux) + (long)m * p.ldaux + n, v);
     v = vc_apply_act(v, p.act);
+    if (p.drop.key) v *= vc_drop_mul(p.drop, (long)m * p.N + n);
     if (p.dact_src) v = vc_apply_dact(v, vc_ld(((const TO*)p.dact_src) + (long)m * p.lddact + n), p.dact_kind);
     if (p.residual) v += p.residual[(long)m * p.ldr + n];
     vc_st(((TO*)p.C) + (long)m * p.ldc + n, v);
@@ -94,6 +96,10 @@ VC_DEV void gemm_epilogue_tile(const GemmParams& p, int mbase, int n, const vc_f
     if (p.act) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = vc_apply_act(v[r], p.act);
+    }
+    if (p.drop.key) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= vc_drop_mul(p.drop, (long)(mbase + (r & 3) + 8 * (r >> 2)) * p.N + n);
     }
     if (p.dact_src) {
         float sv[16];
@@ -400,6 +406,10 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
             if (p.act) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = vc_apply_act(v[k], p.act);
+            }
+            if (p.drop.key) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= vc_drop_mul(p.drop, (long)m * p.N + n + k);
             }
             if (p.dact_src) {
                 float s4[4]; quad_ld<TO>(((const TO*)p.dact_src) + (long)m * p.lddact + n, s4);

@@ -74,6 +74,7 @@ struct LnFwdParams {
     int img, patch;                   // PATCH mode
     // EMBED mode: input row r = n*P + p  ->  output row n*(P+1) + p + 1, plus pos[p+1]; extra rows write cls+pos[0]
     const float* pos; const float* cls; int P;
+    vc_drop drop;                     // EMBED mode: emb_dropout on the finished token rows (idx = out_row * C + col)
 };
 
 // MODE 0 plain, 1 PATCH (x = frames), 2 EMBED (see above; grid covers N*(P+1) output rows)
@@ -92,6 +93,10 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
             row_load<float, VPL>(p.cls, c, lane); row_load<float, VPL>(p.pos, q, lane);
 #pragma unroll
             for (int i = 0; i < VPL; ++i) c[i] += q[i];
+            if (p.drop.key) {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) c[i] *= vc_drop_mul(p.drop, row * C + (i / 4) * 256 + lane * 4 + (i % 4));
+            }
             row_store<float, VPL>(p.y32 + row * p.ldy32, c, lane);
             return;
         }
@@ -110,6 +115,10 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
         row_load<float, VPL>(p.pos + (long)(row % (p.P + 1)) * C, q, lane);
 #pragma unroll
         for (int i = 0; i < VPL; ++i) v[i] += q[i];
+        if (p.drop.key) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) v[i] *= vc_drop_mul(p.drop, row * C + (i / 4) * 256 + lane * 4 + (i % 4));
+        }
     }
     if (p.y32) row_store<float, VPL>(p.y32 + out_row * p.ldy32, v, lane);
     if (p.yt) row_store<TY, VPL>((TY*)p.yt + out_row * p.ldyt, v, lane);
@@ -215,6 +224,19 @@ VC_KERNEL __launch_bounds__(256) void dtanh_kernel(const float* d, const float* 
     float v = d[i] * (1.0f - yy * yy);
     if (out32) out32[i] = v;
     if (outt) vc_st(outt + i, v);
+}
+
+// ---- out[r][c] = in[r][c] * dropmask(r * cols + c): the masked gradient that feeds a dropped GEMM output's wgrad / dgrad
+template <typename TY>
+VC_KERNEL __launch_bounds__(256) void dropout_mul_kernel(const float* in, long ld_in, TY* out, long ld_out, long rows, int cols, vc_drop d) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= rows * cols) return;
+    const long r = i / cols; const int c = (int)(i % cols);
+    float v[4];
+    quad_load<float>(in + r * ld_in + c, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] *= vc_drop_mul(d, i + k);
+    quad_store<TY>(out + r * ld_out + c, v);
 }
 
 // ---- act = tanh(a W^T + b + ts[t])  with K = act_dim (7): too skinny for MFMA, one thread per output

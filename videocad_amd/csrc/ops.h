@@ -41,6 +41,8 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
 long vc_colsum_chunks(long rows);
 int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
               int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s);
+// out (fp32 or T) = in (fp32) * dropout mask; cols % 4 == 0, 16-byte-aligned rows
+int vc_dropout_mul(int ty, const float* in, long ld_in, void* out, long ld_out, long rows, int cols, vc_drop d, vc_stream_t s);
 int vc_dtanh(int ty, const float* d, const float* y, float* out32, void* outt, long n, vc_stream_t s);
 int vc_embed_action(int ty, const float* a, const float* W, const float* b, const float* ts, float* y32, void* yt,
                     long M, int H, int K, int T, vc_stream_t s);

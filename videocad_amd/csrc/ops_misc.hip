@@ -89,6 +89,15 @@ int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, i
     return VC_OK;
 }
 
+int vc_dropout_mul(int ty, const float* in, long ld_in, void* out, long ld_out, long rows, int cols, vc_drop d, vc_stream_t s) {
+    if (rows <= 0) return VC_OK;
+    if (cols % 4) { vc_set_error("dropout_mul: cols %% 4 != 0"); return VC_ERR_ARG; }
+    ProfScope ps(VC_CAT_OTHER, 0, (double)rows * cols * (4 + (ty == VC_BF16 ? 2 : 4)), s);
+    dim3 g((unsigned)VC_CEIL_DIV(rows * cols / 4, 256));
+    if (ty == VC_BF16) VC_LAUNCH((dropout_mul_kernel<vc_bf16>), g, dim3(256), 0, s, in, ld_in, (vc_bf16*)out, ld_out, rows, cols, d);
+    else VC_LAUNCH((dropout_mul_kernel<float>), g, dim3(256), 0, s, in, ld_in, (float*)out, ld_out, rows, cols, d);
+    return VC_OK;
+}
 int vc_dtanh(int ty, const float* d, const float* y, float* out32, void* outt, long n, vc_stream_t s) {
     dim3 g((unsigned)VC_CEIL_DIV(n, 256));
     if (ty == VC_BF16) VC_LAUNCH((dtanh_kernel<vc_bf16>), g, dim3(256), 0, s, d, y, out32, (vc_bf16*)outt, n);

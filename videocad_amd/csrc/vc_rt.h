@@ -174,4 +174,19 @@ VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_b
 VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
+// ---- dropout: counter-based, stateless.  keep-multiplier of element `idx` at a site = (hash(key, idx) >= thr) ? scale : 0,
+// so the backward regenerates exactly the forward's mask from (key, idx) — no mask tensors in HBM.
+// key = vc_drop_key(step seed, site id) (0 = disabled), thr = p * 2^24, scale = 1 / (1 - p).
+struct vc_drop { uint32_t key, thr; float scale; };
+VC_HD uint32_t vc_hash32(uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
+VC_HD uint32_t vc_drop_key(uint64_t seed, uint32_t site) {
+    uint32_t k = vc_hash32((uint32_t)seed ^ vc_hash32((uint32_t)(seed >> 32) + 0x9E3779B9u * (site + 1u)));
+    return k | 1u;
+}
+// element indices are 32-bit: every site has < 2^32 elements (checked on the host when the workspace is planned)
+VC_HD float vc_drop_mul(const vc_drop& d, uint32_t idx) {
+    const uint32_t h = vc_hash32((idx * 0x9E3779B1u) ^ d.key);
+    return ((h >> 8) >= d.thr) ? d.scale : 0.0f;
+}
+
 #define VC_CEIL_DIV(a, b) (((a) + (b) - 1) / (b))

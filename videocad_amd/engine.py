@@ -84,6 +84,15 @@ class NativeEngine:
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             L.check(self.lib, self.lib.vcad_set_workspace(self.h, _ptr(self.ws), need), "set_workspace")
 
+    def set_dropout(self, p: float, seed: int = 0):
+        """p = 0 disables; call with a fresh seed before every training forward (masks = hash(seed, site, index))."""
+        L.check(self.lib, self.lib.vcad_set_dropout(self.h, float(p), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF)), "set_dropout")
+
+    def dropout_mask(self, module: int, layer: int, kind: int, n: int) -> torch.Tensor:
+        out = torch.empty(n, dtype=torch.float32)
+        L.check(self.lib, self.lib.vcad_debug_dropout_mask(self.h, module, layer, kind, n, C.c_void_p(out.data_ptr())), "dropout_mask")
+        return out
+
     # ------------------------------------------------------------------ hot path
     def forward(self, frames: torch.Tensor, actions_norm: torch.Tensor, cad: torch.Tensor):
         """frames [B,T,1,S,S] fp32 (any batch stride, frames contiguous within a clip), actions_norm [B,T,7], cad [B,1,S,S]."""

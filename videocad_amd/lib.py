@@ -42,6 +42,8 @@ PROTOTYPES = {
     "vcad_sync_shadow": (_i, [_vp, _vp]),
     "vcad_workspace_bytes": (_sz, [_vp, _i, _i]),
     "vcad_set_workspace": (_i, [_vp, _vp, _sz]),
+    "vcad_set_dropout": (_i, [_vp, _f, C.c_uint64]),
+    "vcad_debug_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "vcad_dlogits_offsets": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),

@@ -149,6 +149,7 @@ class BaseTrainer:
         inputs = self._prepare_model_inputs(bd, False)
         if not self.native._shadow_fresh:
             eng.sync_shadow()
+        self.native._arm_dropout()                               # model.train() -> dropout active, like the reference's train loop
         cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"])
         out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], use_mse=self.use_mse, class_weights=self._class_w())
         self.gradsync.backward()
