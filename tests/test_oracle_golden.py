@@ -1,0 +1,82 @@
+"""The oracle restatement (oracle/restatement.py) against the golden vectors captured from the IMPORTED reference
+(tests/golden/make_goldens.py).  This is what pins the oracle; everything else is checked against the oracle or the goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as O
+from videocad_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return {k: synth.make_param(k, s) for k, s in O.param_shapes().items()}
+
+
+def sl(t, n=64):
+    f = t.detach().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return f[idx].numpy()
+
+
+@pytest.mark.parametrize("case", ["c1_full", "c1_ragged"])
+def test_oracle_step_matches_reference_goldens(weights, case):
+    meta = json.load(open(os.path.join(GOLD, "meta.json")))["cases"][case]
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    batch = synth.make_batch(meta["B"], meta["T"], meta["seed"], meta["lengths"])
+    ot = O.OracleTrainer(weights)
+    loss, metrics, total, cmds, params = ot.step(batch)
+    ref_p = torch.from_numpy(g["params"])
+    got_p = params if case == "c1_full" else params[:, :, :, ::8]
+    assert float((got_p - ref_p).norm() / ref_p.norm()) < 5e-6
+    assert float((cmds - torch.from_numpy(g["cmds"])).norm() / torch.from_numpy(g["cmds"]).norm()) < 5e-6
+    assert np.array_equal(params.argmax(-1).numpy(), g["params_argmax"]) and np.array_equal(cmds.argmax(-1).numpy(), g["cmds_argmax"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert metrics == json.loads(str(g["metrics_json"]))
+    assert abs(total - float(g["total_grad_norm"])) < 1e-4 * float(g["total_grad_norm"])
+    for n, gn in zip([str(x) for x in g["grad_names"]], g["grad_norms"]):
+        mine = float(ot.P[n].grad.double().norm())
+        assert abs(mine - gn) <= 1e-4 * gn + 1e-10, (n, mine, gn)
+    for k in g.files:
+        if k.startswith("pslice:"):
+            n = k[len("pslice:"):]
+            assert np.abs(sl(ot.P[n]) - g[k]).max() < 1e-6, n
+        if k.startswith("gslice:"):
+            n = k[len("gslice:"):]
+            assert np.abs(sl(ot.P[n].grad) - g[k]).max() <= 1e-4 * np.abs(g[k]).max() + 1e-10, n
+
+
+def test_oracle_window1_and_loss_cases(weights):
+    g = np.load(os.path.join(GOLD, "win1.npz"))
+    cfg = dict(O.CANONICAL_CONFIG); cfg["window_size"] = 1
+    ot = O.OracleTrainer(weights, cfg)
+    with torch.no_grad():
+        cmds, params, tgt = ot.forward(synth.make_batch(2, 8, 3))
+        loss, metrics = O.compute_loss(cmds, params, tgt)
+    assert float((params[:, :, :, ::8] - torch.from_numpy(g["params"])).norm() / torch.from_numpy(g["params"]).norm()) < 5e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"])) and metrics == json.loads(str(g["metrics_json"]))
+    cases = json.load(open(os.path.join(GOLD, "loss_cases.json")))
+    cw = json.load(open(os.path.join(GOLD, "class_weights.json")))
+    B, T = cases["B"], cases["T"]
+    for name, c in cases["cases"].items():
+        seed, mode = c["seed"], c["mode"]
+        acts = torch.from_numpy(synth.make_actions(B, T + 1, seed, lengths=cases["lengths"]))[:, 1:].clone()
+        cm = torch.from_numpy(synth.hash_uniform(1000 + seed, B * T * 5).reshape(B, T, 5) * 3)
+        pm = torch.from_numpy(synth.hash_uniform(2000 + seed, B * T * 6000).reshape(B, T, 6, 1000) * 3)
+        if mode == "inside":
+            pm.scatter_(-1, acts[..., 1:].long().clamp(min=0).unsqueeze(-1), 50.0)
+        if mode == "empty":
+            acts[..., 5:] = -1
+        if mode == "edge":
+            m = acts[..., 1:] >= 0
+            acts[..., 1:][m] = torch.where(acts[..., 1:][m] > 500, torch.tensor(999.0), torch.tensor(998.0))
+        l1, m1 = O.compute_loss(cm, pm, acts, True)
+        l0, m0 = O.compute_loss(cm, pm, acts, False, cw)
+        assert abs(float(l1) - c["loss_use_mse"]) < 2e-6 * max(1, abs(c["loss_use_mse"])) and m1 == c["metrics_use_mse"], name
+        assert abs(float(l0) - c["loss_no_mse"]) < 2e-5 * max(1, abs(c["loss_no_mse"])) and m0 == c["metrics_no_mse"], name

@@ -175,8 +175,21 @@ def run(args):
     gemm_ms = pms[0] + pms[1] + pms[2]; gemm_fl = pfl[0] + pfl[1] + pfl[2]; gemm_n = pln[0] + pln[1] + pln[2]
     peak = PEAK_TFLOPS[args.dtype]
     ach = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read inside this process; they come from the committed
+    # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/<round>_pmc.json), bf16 C2 workload only.
+    traffic, traffic_src = None, None
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        cands = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.endswith("_pmc.json"))
+        if cands and args.dtype == "bf16" and (B, T) == (32, 64):
+            pj = json.load(open(os.path.join(root, "profiles", cands[-1])))
+            traffic = round(pj["gemm_hbm_bytes_per_launch"]); traffic_src = "profiles/" + cands[-1]
+    except Exception:
+        pass
     roof = {"bound": "mfma", "kernel": "gemm_kernel (all Linear fwd/dgrad/wgrad launches of one step)",
-            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+            "alg_bytes_per_launch": round((pby[0] + pby[1] + pby[2]) / max(gemm_n, 1)),
             "launches_per_step": gemm_n, "avg_launch_us": round(gemm_ms * 1e3 / max(gemm_n, 1), 1),
             "alg_tflop_per_step": round(gemm_fl / 1e12, 3),
             "step_level_frac": round(fps / world * train_gf_per_frame(T) * 1e9 / (peak * 1e12), 4)}

@@ -38,6 +38,8 @@ struct GemmParams {
     const void* dact_src; long lddact; int dact_kind;                     // type TO
     const float* residual; long ldr;                                      // fp32, may alias C
     vc_drop drop;                                                         // applied after act, before dact / residual (key 0 = off)
+    int stagger;                                                          // first-wave start offset in units of s_sleep(127) (~3.4 us); 0 = off
+    int debug_skip;                                                       // ablation only (tools/gemm_ablate.py): 1 = no global loads in the loop, 2 = no LDS stores, 4 = no MFMA
 };
 
 VC_DEV float vc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -288,6 +290,16 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
         tile_m = t / nx; tile_n = t - tile_m * nx;
     }
     const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
+#ifndef VC_EMU
+    // De-phase co-resident workgroups: every block of a launch takes the same time, so the two blocks sharing a CU would
+    // run their (MFMA-bound) K-loops and their (HBM-bound) epilogues in lockstep forever.  Half of the FIRST wave of blocks
+    // starts ~half a tile late; the offset then persists for the rest of the launch because successors start when
+    // predecessors retire.  (Pure scheduling hint: no effect on results.)
+    if (p.stagger > 0 && blockIdx.z == 0) {
+        const int bid0 = blockIdx.y * gridDim.x + blockIdx.x;
+        if (bid0 < 2 * 256 && ((bid0 >> 3) & 1)) for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? (kbeg + p.k_per_split) : p.K;
     const int nt = (kend - kbeg + BK - 1) / BK;
@@ -357,18 +369,20 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
         sa0.store(lds, tid); sb0.store(lds + ATILE, tid);
     }
     vc_sync();
+    const int dbg = p.debug_skip;
     for (int t = 0; t < nt; t += 2) {
-        if (t + 2 < nt) fetch(sa0, sb0, t + 2);                     // set 0 is free: tile t already sits in LDS buffer 0
-        compute(0);
-        if (t + 1 < nt) { sa1.store(lds + TILE, tid); sb1.store(lds + TILE + ATILE, tid); }
+        if (t + 2 < nt && !(dbg & 1)) fetch(sa0, sb0, t + 2);       // set 0 is free: tile t already sits in LDS buffer 0
+        if (!(dbg & 4)) compute(0);
+        if (t + 1 < nt && !(dbg & 2)) { sa1.store(lds + TILE, tid); sb1.store(lds + TILE + ATILE, tid); }
         vc_sync();
         if (t + 1 >= nt) break;
-        if (t + 3 < nt) fetch(sa1, sb1, t + 3);
-        compute(1);
-        if (t + 2 < nt) { sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
+        if (t + 3 < nt && !(dbg & 1)) fetch(sa1, sb1, t + 3);
+        if (!(dbg & 4)) compute(1);
+        if (t + 2 < nt && !(dbg & 2)) { sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
         vc_sync();
     }
 
+    if (dbg & 8) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = 1.f; return; }   // ablation: no epilogue
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!p.partial && p.vecC && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {
         // Interior block: stage the fp32 tile through LDS (free after the last barrier) and run the epilogue on whole

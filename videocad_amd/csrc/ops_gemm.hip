@@ -70,6 +70,10 @@ static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
     return c.p.k_per_split < 0 ? gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 1>(c, nsplit, s) : gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 2>(c, nsplit, s);
 }
 
+static int g_stagger = -1;      // -1 = automatic
+extern "C" void vcad_debug_gemm_stagger(int n) { g_stagger = n; }
+static int g_debug_skip = 0;
+extern "C" void vcad_debug_gemm_skip(int mask) { g_debug_skip = mask; }
 static int g_force_tile = 0;     // 0 = automatic, 64 / 128 = forced (tests exercise both tile sizes on small problems)
 extern "C" void vcad_debug_force_gemm_tile(int tile) { g_force_tile = (tile == 64 || tile == 128) ? tile : 0; }
 
@@ -79,6 +83,8 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     GemmParams& p = c.p;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
     if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
+    p.debug_skip = g_debug_skip;
+    p.stagger = g_stagger >= 0 ? g_stagger : 0;
     p.vecA = (((uintptr_t)p.A) % 16 == 0) && ((p.lda * dsize(c.sa)) % 16 == 0);
     p.vecB = (((uintptr_t)p.B) % 16 == 0) && ((p.ldb * dsize(c.sb)) % 16 == 0);
     {   // row-wise vector epilogue: every tensor it touches must allow aligned 4-column accesses
@@ -88,6 +94,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
                  ok(p.dact_src, p.lddact, eo) && ok(p.rowadd, p.ld_rowadd, 4) && ok(p.bias, 4, 4);
         if (eo == 2) p.vecC = p.vecC && ((uintptr_t)p.C % 8 == 0);
     }
+    if (g_debug_skip & 16) p.vecC = 0;          // ablation: register-direct epilogue
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
     // tile size: 128x128 by default; 64x64 when that grid would leave most of the 256 CUs idle (the decoder's
     // 2048-token GEMMs): 4x the blocks and no split-K pass.  Long token reductions still split K.
