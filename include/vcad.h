@@ -32,6 +32,8 @@ typedef struct vcad_config {
     /* vit_pytorch.ViT(...) constructor call at reference model/trajectory_model.py:54-65 */
     int vit_dim, vit_depth, vit_heads, vit_dim_head, vit_mlp, image_size, patch_size;
     int dtype;                     /* VCAD_F32 | VCAD_BF16 */
+    /* wiring flags of forward (reference model/autoregressive_transformer.py:149-213) */
+    int enable_past_actions, enable_past_states, enable_timestep_embedding;
 } vcad_config;
 
 typedef struct vcad_engine vcad_engine;

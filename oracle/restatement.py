@@ -84,9 +84,11 @@ def param_shapes(cfg: dict = CANONICAL_CONFIG) -> Dict[str, Tuple[int, ...]]:
         s[pre + "transformer.norm.bias"] = (D,)
     s["embed_state.weight"] = (H, D); s["embed_state.bias"] = (H,)
     s["embed_image.weight"] = (H, D); s["embed_image.bias"] = (H,)
-    s["image_projection.weight"] = (H, 2 * H); s["image_projection.bias"] = (H,)
+    num_inputs = 1 + (1 if cfg.get("enable_past_states", True) else 0)       # autoregressive_transformer.py:68-76
+    s["image_projection.weight"] = (H, num_inputs * H); s["image_projection.bias"] = (H,)
     s["embed_action.weight"] = (H, cfg["act_dim"]); s["embed_action.bias"] = (H,)
-    s["timestep_embedding.weight"] = (cfg["max_ep_len"], H)
+    if cfg.get("enable_timestep_embedding", True):
+        s["timestep_embedding.weight"] = (cfg["max_ep_len"], H)
     ff = cfg["dim_feedforward"]
     for L in range(cfg["num_decoder_layers"]):
         p = f"transformer_decoder.layers.{L}."
@@ -180,10 +182,11 @@ def window_mask(T: int, window: int) -> Tensor:
     return m
 
 
-def decoder_forward(P: dict, tgt: Tensor, mem: Tensor, cfg: dict, taps: Optional[dict] = None, masks: Optional[dict] = None) -> Tensor:
+def decoder_forward(P: dict, tgt: Tensor, mem: Tensor, cfg: dict, taps: Optional[dict] = None, masks: Optional[dict] = None,
+                    tgt_band: bool = False) -> Tensor:
     B, T, E = tgt.shape
-    causal = window_mask(T, T)
     band = window_mask(T, cfg["window_size"])
+    causal = band if tgt_band else window_mask(T, T)
     x = tgt
     for L in range(cfg["num_decoder_layers"]):
         p = f"transformer_decoder.layers.{L}."
@@ -207,17 +210,29 @@ def model_forward(P: dict, frames: Tensor, actions_norm: Tensor, cad: Tensor,
     -> cmds [B,T,5], params [B,T,6,1000]   (autoregressive_transformer.py:121-220)."""
     B, T = actions_norm.shape[:2]
     H = cfg["hidden_size"]
-    ts = P["timestep_embedding.weight"][:T]                                   # :144-146
-    e = vit_forward(P, "state_embedding_model.", frames.reshape(B * T, *frames.shape[2:]), cfg, taps, masks)  # :153-154
-    ui = torch.tanh(F.linear(e, P["embed_state.weight"], P["embed_state.bias"]).reshape(B, T, H) + ts)  # :155-157
-    c = vit_forward(P, "cad_embedding_model.", cad, cfg, taps, masks)                 # :162
-    cadE = F.linear(c, P["embed_image.weight"], P["embed_image.bias"]).unsqueeze(1).repeat(1, T, 1)  # :163
-    mem = torch.tanh(F.linear(torch.cat([ui, cadE], dim=-1),
-                              P["image_projection.weight"], P["image_projection.bias"]))  # :172-175
-    act = torch.tanh(F.linear(actions_norm, P["embed_action.weight"], P["embed_action.bias"]) + ts)  # :176-178
+    pa, ps = cfg.get("enable_past_actions", True), cfg.get("enable_past_states", True)
+    ts = P["timestep_embedding.weight"][:T] if cfg.get("enable_timestep_embedding", True) else torch.zeros(T, H)   # :144-147
+    images, ui, e = [], None, None
+    if ps:                                                                                                  # :152-159
+        e = vit_forward(P, "state_embedding_model.", frames.reshape(B * T, *frames.shape[2:]), cfg, taps, masks)
+        ui = torch.tanh(F.linear(e, P["embed_state.weight"], P["embed_state.bias"]).reshape(B, T, H) + ts)
+        if pa:
+            images.append(ui)
+    c = vit_forward(P, "cad_embedding_model.", cad, cfg, taps, masks)                                        # :162
+    images.append(F.linear(c, P["embed_image.weight"], P["embed_image.bias"]).unsqueeze(1).repeat(1, T, 1))  # :163-164
+    mem = torch.cat(images, dim=-1)
+    if len(images) > 1:
+        mem = F.linear(mem, P["image_projection.weight"], P["image_projection.bias"])                       # :172-174
+    mem = torch.tanh(mem)                                                                                    # :175
+    act = torch.tanh(F.linear(actions_norm, P["embed_action.weight"], P["embed_action.bias"]) + ts)          # :176-178
     if taps is not None:
         taps.update(cls_state=e, cls_cad=c, ui=ui, mem=mem, act=act)
-    h = decoder_forward(P, act, mem, cfg, taps, masks)                                # :191-197
+    if pa:
+        h = decoder_forward(P, act, mem, cfg, taps, masks)                                                   # :190-197
+    elif ps:
+        h = decoder_forward(P, ui, mem, cfg, taps, masks, tgt_band=True)                                     # :198-205
+    else:
+        h = decoder_forward(P, mem, mem, cfg, taps, masks, tgt_band=True)                                    # :206-213
     cmds = F.linear(h, P["predict_action_class_0_4.weight"], P["predict_action_class_0_4.bias"])      # :217
     params = F.linear(h, P["predict_action_class_0_999.weight"], P["predict_action_class_0_999.bias"]
                       ).reshape(B, T, cfg["num_params"], cfg["num_params_values"])                   # :218

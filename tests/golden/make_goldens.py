@@ -194,6 +194,51 @@ def main():
                         metrics_json=np.array(json.dumps(metrics1)))
     meta["cases"]["win1"] = {"config": "cad_3_actions_and_states", "B": 2, "T": 8, "seed": 3, "oracle_vs_reference": dev}
 
+    # ------------------------------------------------------------------ other wirings of forward (:190-213)
+    for case, cfg_name, seed in [("states_only", "cad_and_past_10_states", 5), ("actions_only", "cad_and_past_5_actions", 6)]:
+        rcfg = json.load(open(os.path.join(HERE, "model_configs.json")))[cfg_name]
+        ocfg = dict(O.CANONICAL_CONFIG)
+        ocfg.update(window_size=rcfg["window_size"], enable_past_actions=rcfg.get("enable_past_actions", False),
+                    enable_past_states=rcfg.get("enable_past_states", False),
+                    enable_timestep_embedding=rcfg.get("enable_timestep_embedding", False))
+        wts = {k: synth.make_param(k, s) for k, s in O.param_shapes(ocfg).items()}
+        modelx, mkx, _ = build_reference(cfg_name, wts, scratch)
+        trx = mkx(True)
+        batch_np = synth.make_batch(2, 8, seed)
+        batch = tbatch(batch_np)
+        modelx.eval()
+        with torch.no_grad():
+            bd = trx.prepare_batch(batch)
+            cmds, params = modelx(trx._prepare_model_inputs(bd, False))
+        gradsx = {}
+        orig_clip = torch.nn.utils.clip_grad_norm_
+        def spyx(parameters, max_norm, *a, **k):
+            for n, p in modelx.named_parameters():
+                if p.grad is not None and n in wts:
+                    gradsx[n] = p.grad.detach().clone()
+            out = orig_clip(modelx.parameters(), max_norm, *a, **k)
+            gradsx["__total_norm__"] = out.detach().clone()
+            return out
+        torch.nn.utils.clip_grad_norm_ = spyx
+        loss_s, metrics = trx._process_batch(batch)
+        torch.nn.utils.clip_grad_norm_ = orig_clip
+        ot = O.OracleTrainer(wts, ocfg)
+        oloss, ometrics, ocmds, oparams = ot.loss_and_grads(batch_np)
+        live = sorted(k for k in gradsx if k != "__total_norm__")
+        olive = sorted(k for k, p in ot.P.items() if p.grad is not None)
+        dev = {"cmds_rel": rel(ocmds, cmds), "params_rel": rel(oparams, params), "loss_abs": abs(float(oloss) - float(loss_s)),
+               "live_sets_equal": live == olive, "metrics_equal": ometrics == metrics,
+               "grad_rel_max": max(rel(ot.P[k].grad, gradsx[k]) for k in live if gradsx[k].norm() > 0)}
+        print(case, json.dumps(dev))
+        assert dev["cmds_rel"] < 1e-5 and dev["params_rel"] < 1e-5 and dev["live_sets_equal"] and dev["grad_rel_max"] < 1e-3, dev
+        np.savez_compressed(os.path.join(HERE, case + ".npz"), cmds=cmds.numpy(), params=params[:, :, :, ::8].numpy().copy(),
+                            params_argmax=params.argmax(-1).numpy(), loss=np.float32(loss_s.item()),
+                            total_grad_norm=np.float32(gradsx["__total_norm__"].item()), grad_names=np.array(live),
+                            grad_norms=np.array([float(gradsx[k].double().norm()) for k in live], dtype=np.float64),
+                            metrics_json=np.array(json.dumps(metrics)))
+        meta["cases"][case] = {"config": cfg_name, "B": 2, "T": 8, "seed": seed, "oracle_vs_reference": dev,
+                               "dead_parameters": sorted(set(wts) - set(live))}
+
     # ------------------------------------------------------------------ loss-only cases on synthetic logits
     tr = mk(True); trn = mk(False)
     loss_cases = {}

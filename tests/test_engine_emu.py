@@ -153,3 +153,38 @@ def test_engine_train_mode_dropout_matches_oracle_with_same_masks(emu):
     eng.set_dropout(0.1, seed=99)
     c2, p2 = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
     assert U.relerr(p2, pars) > 1e-3
+
+
+@pytest.mark.parametrize("pa,ps,tse", [(False, True, True), (True, False, False), (False, False, True)])
+def test_engine_other_wirings_match_oracle(emu, pa, ps, tse):
+    """The other branches of AutoRegressiveTransformer.forward (reference :198-213): tgt = UI embeddings / memory, band-limited
+    self-attention, memory = tanh(CAD embedding); untouched parameters must keep zero gradients and stay put under Adam."""
+    cfg = small_cfg(vit_depth=1, num_decoder_layers=1, enable_past_actions=pa, enable_past_states=ps, enable_timestep_embedding=tse)
+    shapes = O.param_shapes(cfg)
+    weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
+    keys = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
+            "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size",
+            "enable_past_actions", "enable_past_states", "enable_timestep_embedding")
+    eng = NativeEngine(make_config(dtype=L.VCAD_F32, **{k: cfg[k] for k in keys}), "cpu", lib=emu)
+    assert set(eng.table) == set(shapes) and all(eng.table[k][2] == tuple(shapes[k]) for k in shapes)
+    for k, w in weights.items():
+        eng.view(k).copy_(torch.from_numpy(w))
+    batch = synth.make_batch(2, 3, seed=12)
+    ot = O.OracleTrainer(weights, cfg)
+    oloss, ometrics, ocmds, opars = ot.loss_and_grads(batch)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    assert U.relerr(pars, opars) < 1e-5 and U.relerr(cmds, ocmds) < 1e-5
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:])
+    assert abs(float(loss[0]) - float(oloss)) < 2e-5 * max(1.0, abs(float(oloss)))
+    eng.backward()
+    for k in weights:
+        g = eng.view(k, eng.grads); og = ot.P[k].grad
+        if og is None:
+            assert float(g.abs().max()) == 0.0, ("dead parameter received a gradient", k)
+        else:
+            assert U.relerr(g, og) < 2e-4 or float(og.norm()) < 1e-9, (k, U.relerr(g, og))
+    ot.apply_grads({k: p.grad for k, p in ot.P.items() if p.grad is not None})
+    eng.optimizer_step(lr=1e-5)
+    for k in weights:
+        assert float((eng.view(k) - ot.P[k].detach()).abs().max()) < 2e-6, k

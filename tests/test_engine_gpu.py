@@ -210,3 +210,38 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol
     with torch.no_grad():
         oc, op, _ = ot.forward(batch)
     assert U.relerr(p0, op) < tol_logit
+
+
+@pytest.mark.parametrize("case", ["states_only", "actions_only"])
+def test_f32_other_wirings_match_reference_goldens(golden_dir, case):
+    """cad_and_past_10_states (tgt = UI embeddings, band self-attention) and cad_and_past_5_actions (no frame encoder, no
+    timestep embedding, memory = tanh(CAD embedding)) — reference forward branches :198-213 — against goldens from the
+    imported reference: logits, arg-max, loss, metrics, the set of live parameters and their gradient norms."""
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["cases"][case]
+    gold = np.load(os.path.join(golden_dir, case + ".npz"))
+    rcfg = json.load(open(os.path.join(golden_dir, "model_configs.json")))[meta["config"]]
+    cfg = dict(O.CANONICAL_CONFIG)
+    cfg.update(window_size=rcfg["window_size"], enable_past_actions=rcfg.get("enable_past_actions", False),
+               enable_past_states=rcfg.get("enable_past_states", False), enable_timestep_embedding=rcfg.get("enable_timestep_embedding", False))
+    keys = CFG_KEYS + ("enable_past_actions", "enable_past_states", "enable_timestep_embedding")
+    eng = NativeEngine(make_config(dtype=L.VCAD_F32, **{k: cfg[k] for k in keys}), DEV)
+    shapes = O.param_shapes(cfg)
+    assert set(eng.table) == set(shapes)
+    for k, s in shapes.items():
+        eng.view(k).copy_(synth.make_param_torch(k, s, DEV))
+    batch, cmds, pars, gc, gp, pcmp = run_case(eng, gold, meta["B"], meta["T"], meta["seed"], None, False)
+    assert U.relerr(cmds, gc) < 1e-4 and U.relerr(pcmp, gp) < 1e-4
+    assert np.array_equal(pars.argmax(-1).cpu().numpy(), gold["params_argmax"])
+    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:])
+    assert abs(float(loss[0]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+    from videocad_amd.trainer import metrics_from_counters
+    assert metrics_from_counters(met.tolist()) == json.loads(str(gold["metrics_json"]))
+    eng.backward()
+    live = [str(n) for n in gold["grad_names"]]
+    for n, gn in zip(live, gold["grad_norms"]):
+        mine = float(eng.view(n, eng.grads).double().norm())
+        assert abs(mine - gn) <= 2e-3 * gn + 1e-9, (n, mine, float(gn))
+    for n in set(shapes) - set(live):                       # parameters the wiring never touches
+        assert float(eng.view(n, eng.grads).abs().max()) == 0.0, n
+    norm = eng.optimizer_step(lr=1e-5)
+    assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < 1e-3 * float(gold["total_grad_norm"])

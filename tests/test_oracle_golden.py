@@ -80,3 +80,22 @@ def test_oracle_window1_and_loss_cases(weights):
         l0, m0 = O.compute_loss(cm, pm, acts, False, cw)
         assert abs(float(l1) - c["loss_use_mse"]) < 2e-6 * max(1, abs(c["loss_use_mse"])) and m1 == c["metrics_use_mse"], name
         assert abs(float(l0) - c["loss_no_mse"]) < 2e-5 * max(1, abs(c["loss_no_mse"])) and m0 == c["metrics_no_mse"], name
+
+
+@pytest.mark.parametrize("case", ["states_only", "actions_only"])
+def test_oracle_other_wirings_match_reference_goldens(case):
+    meta = json.load(open(os.path.join(GOLD, "meta.json")))["cases"][case]
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    rcfg = json.load(open(os.path.join(GOLD, "model_configs.json")))[meta["config"]]
+    cfg = dict(O.CANONICAL_CONFIG)
+    cfg.update(window_size=rcfg["window_size"], enable_past_actions=rcfg.get("enable_past_actions", False),
+               enable_past_states=rcfg.get("enable_past_states", False), enable_timestep_embedding=rcfg.get("enable_timestep_embedding", False))
+    ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in O.param_shapes(cfg).items()}, cfg)
+    loss, metrics, cmds, params = ot.loss_and_grads(synth.make_batch(meta["B"], meta["T"], meta["seed"]))
+    ref = torch.from_numpy(g["params"])
+    assert float((params[:, :, :, ::8] - ref).norm() / ref.norm()) < 5e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"])) and metrics == json.loads(str(g["metrics_json"]))
+    live = sorted(k for k, p in ot.P.items() if p.grad is not None)
+    assert live == [str(n) for n in g["grad_names"]] and sorted(set(ot.P) - set(live)) == meta["dead_parameters"]
+    for n, gn in zip(live, g["grad_norms"]):
+        assert abs(float(ot.P[n].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-10, n

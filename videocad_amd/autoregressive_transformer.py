@@ -9,8 +9,9 @@ Differences that are deliberate and documented in DESIGN.md:
     strict=False (model/model_factory.py:35) so both directions interoperate
   * parameters are views into ONE flat fp32 buffer (and `.grad` views into one flat gradient buffer) so that clipping,
     Adam and the RCCL all-reduce run over contiguous memory
-  * wiring implemented natively: encoder="vit", enable_past_states and enable_past_actions both True (the configuration
-    `main.py` and the README run); other wirings raise NotImplementedError instead of silently computing something else
+  * every wiring of forward (:149-213) is native: past actions and/or past states, with or without the timestep embedding;
+    parameters a wiring never touches (e.g. image_projection without both flags) keep a zero gradient and are left unchanged
+    by the optimiser, as in the reference where their .grad stays None; encoder != "vit" and the multiview branch raise
   * dropout is a stateless counter-based mask (hash of step seed, site, element index) regenerated in the backward:
     statistically equivalent to nn.Dropout at the same sites, not bit-identical to torch's Philox stream
 There is no CPU fallback: calling forward on a non-CUDA module raises.
@@ -80,9 +81,6 @@ class AutoRegressiveTransformer(nn.Module):
         if encoder != "vit" or use_pretrained_cad_model:
             raise NotImplementedError(f"encoder={encoder!r}/gencad is out of scope of the MI355X path (needs torchvision weights; "
                                       "reference model/trajectory_model.py:68-74)")
-        if not (enable_past_actions and enable_past_states):
-            raise NotImplementedError("native wiring covers enable_past_actions=True & enable_past_states=True "
-                                      "(reference :190-197); other branches are listed under 'next' in DESIGN.md")
         if num_views:
             raise NotImplementedError("multiview branch (reference :167-170) is not on the hot path (SURVEY §8 f4)")
         self.state_dim, self.act_dim, self.hidden_size = state_dim, act_dim, hidden_size
@@ -91,7 +89,7 @@ class AutoRegressiveTransformer(nn.Module):
         self.enable_timestep_embedding = enable_timestep_embedding
         self.window_size, self.normalize, self.num_views = window_size, normalize, num_views
         self.use_pretrained_cad_model = use_pretrained_cad_model
-        self.num_inputs = 2
+        self.num_inputs = 1 + (1 if enable_past_states else 0)              # reference :67-76
         self.state_embedding_model_size = self.cad_embedding_model_size = 512
         self.dropout_p = dropout
         self.compute_dtype = compute_dtype
@@ -99,6 +97,8 @@ class AutoRegressiveTransformer(nn.Module):
         cfg = make_config(hidden_size=hidden_size, nhead=nhead, num_decoder_layers=num_decoder_layers,
                           dim_feedforward=dim_feedforward, window_size=window_size, act_dim=act_dim, num_classes=num_classes,
                           num_params=num_params, num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dt,
+                          enable_past_actions=enable_past_actions, enable_past_states=enable_past_states,
+                          enable_timestep_embedding=enable_timestep_embedding,
                           **{k: kwargs[k] for k in ("vit_depth",) if k in kwargs})    # extension (tests): shallower ViT
         self._engine = NativeEngine(cfg, "cpu", lib=_lib)
         self._param_names = list(self._engine.table.keys())
@@ -108,10 +108,6 @@ class AutoRegressiveTransformer(nn.Module):
         self._shadow_fresh = False
         self._drop_step = 0
         self.reset_parameters()
-        if not enable_timestep_embedding:                                     # reference :144-147: zeros instead of the table
-            with torch.no_grad():
-                self.timestep_embedding.weight.zero_()
-            self.timestep_embedding.weight.requires_grad_(False)
         self.action_mask = torch.tensor([[1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 1, 0],
                                          [0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0]]).float()   # reference :83-89 (plain attribute)
         if device is not None:

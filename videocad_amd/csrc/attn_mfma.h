@@ -239,7 +239,7 @@ VC_DEV void am_stage_nt(vc_bf16* tile, const vc_bf16* g, long ld, int T, int tid
 // MFMA grids while wave 0 produces D_i; the hand-off is the block barrier.  Halving the per-wave accumulator set
 // lifts occupancy from 1 to 2 waves per SIMD (8 waves per CU, LDS-limited at 37 KB per block).
 template <bool DROP>
-VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) {
+VC_DEV void attn_vit_bwd_mfma_body(const AttnParams& p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO
     VC_SHARED float lse_s[AM_T];
     VC_SHARED float del_s[AM_T];
@@ -334,3 +334,11 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel(AttnParams p) 
         am_store((vc_bf16*)p.dk + rowq * p.lddk + h * AM_D, p.lddk, acc, T, lane, p.scale);
     }
 }
+
+// eval / p = 0: capped at 256 registers -> 2 waves per SIMD.  Train mode (mask bits + masked packing) does not fit the cap
+// without spilling; ATTN_BWD_DROP_WAVES selects its register budget.
+#ifndef ATTN_BWD_DROP_WAVES
+#define ATTN_BWD_DROP_WAVES 1
+#endif
+VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel_eval(AttnParams p) { attn_vit_bwd_mfma_body<false>(p); }
+VC_KERNEL __launch_bounds__(128, ATTN_BWD_DROP_WAVES) void attn_vit_bwd_mfma_kernel_drop(AttnParams p) { attn_vit_bwd_mfma_body<true>(p); }

@@ -140,8 +140,8 @@ void build_params(vcad_engine* e) {
         w.sa_w = add_param(e, p + "self_attn.in_proj_weight", {3 * H, H}); w.sa_b = add_param(e, p + "self_attn.in_proj_bias", {3 * H});
     }
     e->o_ea_w = add_param(e, "embed_action.weight", {H, (long)c.act_dim}); e->o_ea_b = add_param(e, "embed_action.bias", {H});
-    e->o_ts = add_param(e, "timestep_embedding.weight", {(long)c.max_ep_len, H});
-    e->o_ip_w = add_param(e, "image_projection.weight", {H, 2 * H}); e->o_ip_b = add_param(e, "image_projection.bias", {H});
+    e->o_ts = c.enable_timestep_embedding ? add_param(e, "timestep_embedding.weight", {(long)c.max_ep_len, H}) : -1;
+    e->o_ip_w = add_param(e, "image_projection.weight", {H, (c.enable_past_states ? 2 : 1) * H}); e->o_ip_b = add_param(e, "image_projection.bias", {H});
     e->o_ei_w = add_param(e, "embed_image.weight", {H, (long)c.vit_dim}); e->o_ei_b = add_param(e, "embed_image.bias", {H});
     e->o_es_w = add_param(e, "embed_state.weight", {H, (long)c.vit_dim}); e->o_es_b = add_param(e, "embed_state.bias", {H});
     e->buckets.push_back({b0, e->ptotal});
@@ -455,24 +455,36 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     const int B = e->B, T = e->T, H = c.hidden_size, D = c.vit_dim; const long M = (long)B * T;
     const size_t es = e->esz;
     if (H != 1024) { vc_set_error("engine: hidden_size %d unsupported (LN kernels: 1024)", H); return VC_ERR_UNSUPPORTED; }
-    CK(vit_forward(cx, 0, e->in_frames, T, e->in_fbstride));
+    // wiring (reference model/autoregressive_transformer.py:149-213): past_actions -> tgt = action embeddings, causal self-attention;
+    // else past_states -> tgt = UI embeddings; else tgt = memory; in the last two cases self-attention is band-limited too.
+    // memory = tanh(image_projection([ui, cad])) only when BOTH flags are set, otherwise tanh(cad embedding) repeated over time.
+    const bool pa = c.enable_past_actions, ps = c.enable_past_states;
+    const float* ts = c.enable_timestep_embedding ? cx.Pf(e->o_ts) : nullptr;
+    if (ps) {
+        CK(vit_forward(cx, 0, e->in_frames, T, e->in_fbstride));
+        Epi ep; ep.bias = cx.Pf(e->o_es_b); ep.rowadd = ts; ep.rdiv = T; ep.rmod = 1; ep.ldrow = H; ep.act = VC_ACT_TANH;
+        CK(cx.lin_fwd(cx.AT(e->va[0].e, D), cx.W(e->o_es_w, D), cx.A32(e->ui, H), (int)M, H, D, ep));
+    }
     CK(vit_forward(cx, 1, e->in_cad, 1, (long)c.image_size * c.image_size));
-    const float* ts = cx.Pf(e->o_ts);
-    { Epi ep; ep.bias = cx.Pf(e->o_es_b); ep.rowadd = ts; ep.rdiv = T; ep.rmod = 1; ep.ldrow = H; ep.act = VC_ACT_TANH;
-      CK(cx.lin_fwd(cx.AT(e->va[0].e, D), cx.W(e->o_es_w, D), cx.A32(e->ui, H), (int)M, H, D, ep)); }
     { Epi ep; ep.bias = cx.Pf(e->o_ei_b); CK(cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep)); }
-    { Epi ep; ep.bias = cx.Pf(e->o_ip_b);
-      Mat w2 = cx.W(e->o_ip_w + H, 2 * H);
-      CK(cx.lin_fwd(cx.AT(e->cadE, H), w2, cx.A32(e->cadterm, H), B, H, H, ep)); }
-    { Epi ep; ep.rowadd = e->cadterm; ep.rdiv = T; ep.rmod = 0; ep.ldrow = H; ep.act = VC_ACT_TANH;
-      CK(cx.lin_fwd(cx.A32(e->ui, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->mem, H), (int)M, H, H, ep)); }
-    CK(vc_embed_action(VC_F32, e->in_actions, cx.Pf(e->o_ea_w), cx.Pf(e->o_ea_b), ts, e->act, nullptr, M, H, c.act_dim, T, s));
-    const float* x = e->act;
+    if (pa && ps) {
+        { Epi ep; ep.bias = cx.Pf(e->o_ip_b);
+          Mat w2 = cx.W(e->o_ip_w + H, 2 * H);
+          CK(cx.lin_fwd(cx.AT(e->cadE, H), w2, cx.A32(e->cadterm, H), B, H, H, ep)); }
+        { Epi ep; ep.rowadd = e->cadterm; ep.rdiv = T; ep.rmod = 0; ep.ldrow = H; ep.act = VC_ACT_TANH;
+          CK(cx.lin_fwd(cx.A32(e->ui, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->mem, H), (int)M, H, H, ep)); }
+    } else {
+        CK(vc_bcast_tanh(e->dt, e->cadE, e->mem, M, H, T, s));
+    }
+    if (pa) CK(vc_embed_action(VC_F32, e->in_actions, cx.Pf(e->o_ea_w), cx.Pf(e->o_ea_b), ts, e->act, nullptr, M, H, c.act_dim, T, s));
+    const float* tgt = pa ? e->act : (ps ? e->ui : e->mem);
+    const int sa_window = pa ? T : c.window_size;
+    const float* x = tgt;
     for (int L = 0; L < c.num_decoder_layers; ++L) {
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
         { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, 3 * H), (int)M, 3 * H, H, ep)); }
         { const char* q = (const char*)d.qkv_s;
-          CK(dec_attn(cx, false, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, T, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_SA))); }
+          CK(dec_attn(cx, false, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, sa_window, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_SA))); }
         { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_SA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), (int)M, H, H, ep)); }
         CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, nullptr, 0, d.st1, M, H));
         { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), (int)M, H, H, ep)); }
@@ -502,13 +514,16 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     const int n5 = c.num_classes, n6 = c.num_params * c.num_params_values;
     float* dx = e->t_dcur;
     const float* xf = e->xfinal;
+    const bool pa = c.enable_past_actions, ps = c.enable_past_states, tsE = c.enable_timestep_embedding;
+    const float* tgt0 = pa ? e->act : (ps ? e->ui : e->mem);
+    const int sa_window = pa ? T : c.window_size;
     CK(cx.lin_wgrad(cx.A32(dcmds, n5), cx.A32(xf, H), cx.Gf(e->o_h5_w), H, cx.Gf(e->o_h5_b), (int)M, n5, H));
     CK(cx.lin_wgrad(cx.A32(dpars, n6), cx.A32(xf, H), cx.Gf(e->o_h6_w), H, cx.Gf(e->o_h6_b), (int)M, n6, H));
     CK(cx.lin_dgrad(cx.A32(dpars, n6), cx.W(e->o_h6_w, H), cx.A32(dx, H), (int)M, n6, H, Epi()));
     { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.A32(dcmds, n5), cx.W(e->o_h5_w, H), cx.A32(dx, H), (int)M, n5, H, ep)); }
     for (int L = c.num_decoder_layers - 1; L >= 0; --L) {
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
-        const float* xin = L == 0 ? e->act : e->da[L - 1].x3;
+        const float* xin = L == 0 ? tgt0 : e->da[L - 1].x3;
         // ---- FFN   x3 = LN3(x2 + drop(W2 drop(relu(W1 x2 + b1)) + b2))
         Mat du;
         CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H));
@@ -537,30 +552,43 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* q = (const char*)d.qkv_s; char* dq = (char*)e->t_dqkv_d;
-          CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, nullptr, d.lse_s, T, e->t_dao_d,
+          CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, nullptr, d.lse_s, sa_window, e->t_dao_d,
                       dq, dq + (size_t)H * es, dq + (size_t)2 * H * es, 3 * H, 3 * H, cx.site(3, L, Ctx::K_SA))); }
         CK(cx.lin_wgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.A32(xin, H), cx.Gf(w.sa_w), H, cx.Gf(w.sa_b), (int)M, 3 * H, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }
     }
-    // ---- stem (reference model/autoregressive_transformer.py:144-178)
+    // ---- stem (reference model/autoregressive_transformer.py:144-178); dx = gradient of the decoder's tgt input
     float* dpre = e->t_dpre;
-    CK(vc_memset_async(cx.Gf(e->o_ts), 0, (size_t)c.max_ep_len * H * 4, s));       // rows >= T receive no gradient
-    CK(vc_dtanh(VC_F32, dx, e->act, dpre, nullptr, M * H, s));                     // d pre-tanh of the action embedding
-    CK(cx.lin_wgrad(cx.A32(dpre, H), cx.A32(e->in_actions, c.act_dim), cx.Gf(e->o_ea_w), c.act_dim, cx.Gf(e->o_ea_b), (int)M, H, c.act_dim));
-    CK(cx.colsum(cx.A32(dpre, (long)T * H), B, T * H, cx.Gf(e->o_ts), 0));
-    CK(vc_dtanh(VC_F32, e->t_dmem, e->mem, dpre, nullptr, M * H, s));              // d pre-tanh of the image projection
-    CK(cx.gemm(cx.A32(dpre, H), 1, cx.A32(e->ui, H), 1, Mat{cx.Gf(e->o_ip_w), VC_F32, 2L * H}, H, H, (int)M, Epi()));
-    CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadterm, 0, B, (long)T * H, H));    // sum over t -> [B, H]
-    CK(cx.colsum(cx.A32(e->t_dcadterm, H), B, H, cx.Gf(e->o_ip_b), 0));
-    CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->cadE, H), 1, Mat{cx.Gf(e->o_ip_w + H), VC_F32, 2L * H}, H, H, B, Epi()));
-    CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + H, 2 * H), cx.A32(e->t_dcadE, H), B, H, H, Epi()));
+    if (tsE) CK(vc_memset_async(cx.Gf(e->o_ts), 0, (size_t)c.max_ep_len * H * 4, s));   // rows >= T receive no gradient
+    if (pa) {                                                                          // tgt = tanh(embed_action(a) + ts)
+        CK(vc_dtanh(VC_F32, dx, e->act, dpre, nullptr, M * H, s));
+        CK(cx.lin_wgrad(cx.A32(dpre, H), cx.A32(e->in_actions, c.act_dim), cx.Gf(e->o_ea_w), c.act_dim, cx.Gf(e->o_ea_b), (int)M, H, c.act_dim));
+        if (tsE) CK(cx.colsum(cx.A32(dpre, (long)T * H), B, T * H, cx.Gf(e->o_ts), 1));
+    } else if (!ps) {
+        CK(vc_add_inplace(e->t_dmem, dx, M * H, s));                                   // tgt = memory
+    }
+    const float* dui = nullptr;                                                        // gradient w.r.t. ui (post-tanh)
+    CK(vc_dtanh(VC_F32, e->t_dmem, e->mem, dpre, nullptr, M * H, s));                  // d pre-tanh of the memory
+    if (pa && ps) {
+        CK(cx.gemm(cx.A32(dpre, H), 1, cx.A32(e->ui, H), 1, Mat{cx.Gf(e->o_ip_w), VC_F32, 2L * H}, H, H, (int)M, Epi()));
+        CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadterm, 0, B, (long)T * H, H));    // sum over t -> [B, H]
+        CK(cx.colsum(cx.A32(e->t_dcadterm, H), B, H, cx.Gf(e->o_ip_b), 0));
+        CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->cadE, H), 1, Mat{cx.Gf(e->o_ip_w + H), VC_F32, 2L * H}, H, H, B, Epi()));
+        CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + H, 2 * H), cx.A32(e->t_dcadE, H), B, H, H, Epi()));
+        CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->t_dui, H), (int)M, H, H, Epi()));
+        dui = e->t_dui;
+    } else {
+        CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadE, 0, B, (long)T * H, H));       // memory = tanh(cadE[b]): sum over t
+        if (ps) dui = dx;                                                              // tgt = ui
+    }
     CK(cx.lin_wgrad(cx.A32(e->t_dcadE, H), cx.AT(e->va[1].e, D), cx.Gf(e->o_ei_w), D, cx.Gf(e->o_ei_b), B, H, D));
     CK(cx.lin_dgrad(cx.A32(e->t_dcadE, H), cx.W(e->o_ei_w, D), cx.A32(e->t_dec, D), B, H, D, Epi()));
-    CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->t_dui, H), (int)M, H, H, Epi()));
-    CK(vc_dtanh(VC_F32, e->t_dui, e->ui, dpre, nullptr, M * H, s));                // d pre-tanh of the state embedding
-    CK(cx.lin_wgrad(cx.A32(dpre, H), cx.AT(e->va[0].e, D), cx.Gf(e->o_es_w), D, cx.Gf(e->o_es_b), (int)M, H, D));
-    CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_es_w, D), cx.A32(e->t_des, D), (int)M, H, D, Epi()));
-    CK(cx.colsum(cx.A32(dpre, (long)T * H), B, T * H, cx.Gf(e->o_ts), 1));
+    if (ps) {
+        CK(vc_dtanh(VC_F32, dui, e->ui, dpre, nullptr, M * H, s));                     // d pre-tanh of the state embedding
+        CK(cx.lin_wgrad(cx.A32(dpre, H), cx.AT(e->va[0].e, D), cx.Gf(e->o_es_w), D, cx.Gf(e->o_es_b), (int)M, H, D));
+        CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_es_w, D), cx.A32(e->t_des, D), (int)M, H, D, Epi()));
+        if (tsE) CK(cx.colsum(cx.A32(dpre, (long)T * H), B, T * H, cx.Gf(e->o_ts), 1));
+    }
     return 0;
 }
 
@@ -702,8 +730,8 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
     switch (stage) {
         case 0: rc = backward_stage0(e, dcmds ? dcmds : e->dl_cmds, dpars ? dpars : e->dl_pars, s); break;
         case 1: rc = vit_backward(cx, 1, e->t_dec, 0, e->in_cad, 1, img2); break;
-        case 2: rc = vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride); break;
-        case 3: rc = vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride); break;
+        case 2: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride) : 0; break;
+        case 3: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride) : 0; break;
         default: vc_set_error("vcad_backward_stage: stage %d out of range", stage); return VC_ERR_ARG;
     }
     if (rc) return rc;

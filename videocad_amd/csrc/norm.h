@@ -247,11 +247,23 @@ VC_KERNEL __launch_bounds__(256) void embed_action_kernel(const float* a, const 
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * H) return;
     long m = i / H; int n = (int)(i % H);
-    float s = b[n] + ts[(m % T) * (long)H + n];
+    float s = b[n] + (ts ? ts[(m % T) * (long)H + n] : 0.0f);
     for (int k = 0; k < K; ++k) s += a[m * K + k] * W[n * K + k];
     s = tanhf(s);
     y32[i] = s;
     if (yt) vc_st(yt + i, s);
+}
+
+// ---- mem[m][n] = tanh(src[m / T][n])   (memory = tanh(CAD embedding) repeated over time, reference :163,175 when no projection)
+template <typename TS>
+VC_KERNEL __launch_bounds__(256) void bcast_tanh_kernel(const TS* src, float* out, long M, int H, int T) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * H) return;
+    out[i] = tanhf(vc_ld(src + (i / H / T) * (long)H + (i % H)));
+}
+VC_KERNEL __launch_bounds__(256) void add_inplace_kernel(float* a, const float* b, long n) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] += b[i];
 }
 
 // ---- fp32 -> T cast (weight shadows) and generic fill

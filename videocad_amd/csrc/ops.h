@@ -46,6 +46,8 @@ int vc_dropout_mul(int ty, const float* in, long ld_in, void* out, long ld_out, 
 int vc_dtanh(int ty, const float* d, const float* y, float* out32, void* outt, long n, vc_stream_t s);
 int vc_embed_action(int ty, const float* a, const float* W, const float* b, const float* ts, float* y32, void* yt,
                     long M, int H, int K, int T, vc_stream_t s);
+int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s);
+int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s);
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
 
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s);

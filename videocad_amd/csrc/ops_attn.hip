@@ -76,8 +76,8 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         return VC_OK;
     }
     if (mfma_ok(t, D, p, true)) {
-        if (p.drop.key) VC_LAUNCH((attn_vit_bwd_mfma_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
-        else VC_LAUNCH((attn_vit_bwd_mfma_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        if (p.drop.key) VC_LAUNCH(attn_vit_bwd_mfma_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        else VC_LAUNCH(attn_vit_bwd_mfma_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);

@@ -111,6 +111,16 @@ int vc_embed_action(int ty, const float* a, const float* W, const float* b, cons
     else VC_LAUNCH((embed_action_kernel<float>), g, dim3(256), 0, s, a, W, b, ts, y32, (float*)yt, M, H, K, T);
     return VC_OK;
 }
+int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s) {
+    dim3 g((unsigned)VC_CEIL_DIV(M * H, 256));
+    if (ts == VC_BF16) VC_LAUNCH((bcast_tanh_kernel<vc_bf16>), g, dim3(256), 0, s, (const vc_bf16*)src, out, M, H, T);
+    else VC_LAUNCH((bcast_tanh_kernel<float>), g, dim3(256), 0, s, (const float*)src, out, M, H, T);
+    return VC_OK;
+}
+int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s) {
+    VC_LAUNCH(add_inplace_kernel, dim3((unsigned)VC_CEIL_DIV(n, 256)), dim3(256), 0, s, a, b, n);
+    return VC_OK;
+}
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
     dim3 g((unsigned)VC_CEIL_DIV(n, 1024));
     if (ty == VC_BF16) VC_LAUNCH((cast_kernel<vc_bf16>), g, dim3(256), 0, s, x, (vc_bf16*)y, n);

@@ -15,11 +15,14 @@ VIT_DEFAULTS = dict(vit_dim=512, vit_depth=6, vit_heads=16, vit_dim_head=64, vit
 
 
 def make_config(hidden_size, nhead=4, num_decoder_layers=8, dim_feedforward=512, window_size=1, act_dim=7, num_classes=5,
-                num_params=6, num_params_values=1000, max_ep_len=1000, dtype=L.VCAD_F32, **vit) -> L.Config:
+                num_params=6, num_params_values=1000, max_ep_len=1000, dtype=L.VCAD_F32, enable_past_actions=True,
+                enable_past_states=True, enable_timestep_embedding=True, **vit) -> L.Config:
     v = dict(VIT_DEFAULTS); v.update({k: vit[k] for k in vit if k in VIT_DEFAULTS})
     return L.Config(hidden_size=hidden_size, nhead=nhead, num_decoder_layers=num_decoder_layers, dim_feedforward=dim_feedforward,
                     window_size=window_size, act_dim=act_dim, num_classes=num_classes, num_params=num_params,
-                    num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dtype, **v)
+                    num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dtype,
+                    enable_past_actions=int(bool(enable_past_actions)), enable_past_states=int(bool(enable_past_states)),
+                    enable_timestep_embedding=int(bool(enable_timestep_embedding)), **v)
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -23,7 +23,8 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim",
         "num_classes", "num_params", "num_params_values", "max_ep_len",
-        "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size", "dtype")]
+        "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size", "dtype",
+        "enable_past_actions", "enable_past_states", "enable_timestep_embedding")]
 
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
