@@ -108,6 +108,9 @@ int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launche
 
 /* test hook: force the GEMM block tile (64 or 128; 0 = automatic choice by problem size) */
 void vcad_debug_force_gemm_tile(int tile);
+/* -1 automatic, 0 never, 1 whenever legal: routes bf16 GEMMs through the persistent DMA-fed kernel (tests) */
+void vcad_debug_gemm_dma(int mode);
+long vcad_debug_gemm_dma_launches(void);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,

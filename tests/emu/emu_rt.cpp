@@ -181,6 +181,11 @@ void ds_read_tr16(const void* p, short* out4) {      // semantics measured on gf
     wave_sync();
 }
 
+void dma16(const void* gsrc, void* lds_piece) {      // global_load_lds_dwordx4: lane-linear 1 KiB piece (the emulator copies at once)
+    BlockState* bs = g_bs;
+    memcpy((char*)lds_piece + 16 * (bs->cur & 63), gsrc, 16);
+}
+
 void mfma_32x32x2_f32(float a, float b, float* c16) {
     BlockState* bs = g_bs;
     WaveState& w = bs->waves[bs->cur / 64];

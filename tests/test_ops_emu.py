@@ -52,6 +52,22 @@ def test_gemm_bf16_unaligned_tail(emu):
     U.check_gemm(emu, "cpu", 33, 7, 100, BF16, sa=F32, to=F32, tra=1, trb=1, pad=1, splitk=False)
 
 
+@pytest.mark.parametrize("tra,trb,to", [(0, 0, BF16), (0, 0, F32), (0, 1, BF16), (0, 1, F32), (1, 1, F32)])
+def test_gemm_dma_kernel(emu, gemm_tile, tra, trb, to):
+    """the persistent DMA-fed kernel (gemm_dma.h): M tail, several tiles per workgroup stream, fused epilogue, k-slices"""
+    if gemm_tile != 128:
+        pytest.skip("tile-size fixture does not apply to the DMA kernel")
+    emu.vcad_debug_gemm_dma(1)
+    n0 = emu.vcad_debug_gemm_dma_launches()
+    try:
+        M = 264 if tra else 300                       # row-contiguous A needs M % 8 == 0; 300 leaves a ragged last tile
+        U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, act=(0 if tra else 1),
+                     residual=(to == F32), splitk=bool(tra))
+        assert emu.vcad_debug_gemm_dma_launches() == n0 + 1, "the GEMM did not take the DMA kernel"
+    finally:
+        emu.vcad_debug_gemm_dma(-1)
+
+
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16)])
 def test_layernorm(emu, C_, dt):
     U.check_layernorm(emu, "cpu", 11, C_, dt)

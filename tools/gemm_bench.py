@@ -40,7 +40,27 @@ def run(name, M, N, K, sa=BF, sb=BF, to=BF, tra=0, trb=0, bias=False, res=False,
     print(f"{name:34s} M={M:6d} N={N:5d} K={K:6d} tra={tra} trb={trb} {str(sa)[6:]:>8s}->{str(to)[6:]:<8s} {ms*1e3:8.1f} us  {tf:7.1f} TF/s", flush=True)
 
 
+def both(name, *a, **k):
+    """old register-staged kernel vs automatic choice (persistent DMA-fed kernel where legal)"""
+    lib.vcad_debug_gemm_dma(0); run(name + " [reg]", *a, **k)
+    lib.vcad_debug_gemm_dma(-1); run(name + " [auto]", *a, **k)
+
+
 R = 104000
+if len(sys.argv) > 1 and sys.argv[1] == "dma":
+    both("vit qkv fwd", R, 3072, 512, bias=True)
+    both("vit out fwd (+res, f32 out)", R, 512, 1024, to=F32, bias=True, res=True)
+    both("vit mlp1 fwd", R, 512, 512, bias=True)
+    both("vit mlp2 fwd (+res, f32 out)", R, 512, 512, to=F32, bias=True, res=True)
+    both("vit dqkv dgrad", R, 512, 3072, trb=1)
+    both("vit dao dgrad", R, 1024, 512, trb=1)
+    both("vit dz dgrad", R, 512, 512, trb=1)
+    both("vit qkv wgrad", 3072, 512, R, to=F32, tra=1, trb=1)
+    both("vit out wgrad", 512, 1024, R, to=F32, tra=1, trb=1)
+    both("vit mlp wgrad", 512, 512, R, to=F32, tra=1, trb=1)
+    both("square 4096", 4096, 4096, 4096)
+    both("square 8192", 8192, 8192, 8192)
+    sys.exit(0)
 run("vit qkv fwd", R, 3072, 512)
 run("vit out fwd (+res, f32 out)", R, 512, 1024, to=F32, bias=True, res=True)
 run("vit mlp1 fwd", R, 512, 512, bias=True)

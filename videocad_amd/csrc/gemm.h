@@ -142,6 +142,40 @@ template <> VC_DEV void quad_st<vc_bf16>(vc_bf16* p, const float* v) {
     *reinterpret_cast<vc_u32x2*>(p) = q;
 }
 
+// The fused epilogue on four consecutive columns n..n+3 of row m (16-byte / 8-byte accesses): alpha, bias, row-broadcast add,
+// pre-activation side output, activation, dropout, activation-derivative, residual, store.
+template <typename TO>
+VC_DEV void gemm_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], const float (&b4)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = p.alpha * v[k] + b4[k];
+    if (p.rowadd) {
+        const int rr = p.rowadd_mod ? (m % p.rowadd_div) : (m / p.rowadd_div);
+        float a4[4]; quad_ld_f32(p.rowadd + (long)rr * p.ld_rowadd + n, a4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += a4[k];
+    }
+    if (p.aux) quad_st<TO>(((TO*)p.aux) + (long)m * p.ldaux + n, v);
+    if (p.act) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = vc_apply_act(v[k], p.act);
+    }
+    if (p.drop.key) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= vc_drop_mul(p.drop, (long)m * p.N + n + k);
+    }
+    if (p.dact_src) {
+        float s4[4]; quad_ld<TO>(((const TO*)p.dact_src) + (long)m * p.lddact + n, s4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = vc_apply_dact(v[k], s4[k], p.dact_kind);
+    }
+    if (p.residual) {
+        float q4[4]; quad_ld_f32(p.residual + (long)m * p.ldr + n, q4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += q4[k];
+    }
+    quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
+}
+
 template <typename CT> struct GemmCfg;
 template <> struct GemmCfg<float> {
     static constexpr int BK = 32, CHUNK = 4, STRIDE = 33, KSTEP = 2;
@@ -408,34 +442,7 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
             const int row = pass * RPP + tid / TPR, m = m0 + row;
             float v[4];
             quad_ld_f32(et + row * ES + c4, v);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = p.alpha * v[k] + b4[k];
-            if (p.rowadd) {
-                const int rr = p.rowadd_mod ? (m % p.rowadd_div) : (m / p.rowadd_div);
-                float a4[4]; quad_ld_f32(p.rowadd + (long)rr * p.ld_rowadd + n, a4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += a4[k];
-            }
-            if (p.aux) quad_st<TO>(((TO*)p.aux) + (long)m * p.ldaux + n, v);
-            if (p.act) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = vc_apply_act(v[k], p.act);
-            }
-            if (p.drop.key) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] *= vc_drop_mul(p.drop, (long)m * p.N + n + k);
-            }
-            if (p.dact_src) {
-                float s4[4]; quad_ld<TO>(((const TO*)p.dact_src) + (long)m * p.lddact + n, s4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = vc_apply_dact(v[k], s4[k], p.dact_kind);
-            }
-            if (p.residual) {
-                float q4[4]; quad_ld_f32(p.residual + (long)m * p.ldr + n, q4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += q4[k];
-            }
-            quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
+            gemm_epilogue_quad<TO>(p, m, n, v, b4);
         }
         return;
     }

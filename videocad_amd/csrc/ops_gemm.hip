@@ -1,6 +1,7 @@
 // ops_gemm.hip — GEMM dispatch: picks the template instantiation, the 16-byte-load legality flags and the
 // split-K factor (small tile counts with a long reduction, e.g. every wgrad: K = number of tokens).
 #include "ops.h"
+#include "gemm_dma.h"
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -70,6 +71,34 @@ static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
     return c.p.k_per_split < 0 ? gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 1>(c, nsplit, s) : gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 2>(c, nsplit, s);
 }
 
+static long g_dma_launches = 0;
+extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
+// persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
+template <typename TO, bool TRA, bool TRB>
+static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
+#ifndef VC_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD_LDS_BYTES);
+        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+        attr_set = true;
+    }
+#endif
+    ProfScope ps(TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD), 2.0 * c.p.M * c.p.N * c.p.K,
+                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s);
+    const int tiles_n = c.p.N / GD_BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
+    ++g_dma_launches;
+    const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GD_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
+    if (nsplit > 1) {
+        long tot = (long)c.p.M * c.p.N;
+        VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot, 256)), dim3(256), 0, s, c.p, nsplit);
+    }
+    return VC_OK;
+}
+
+static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal (tests run small problems through it)
+extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
 static int g_stagger = -1;      // -1 = automatic
 extern "C" void vcad_debug_gemm_stagger(int n) { g_stagger = n; }
 static int g_debug_skip = 0;
@@ -95,6 +124,32 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if (eo == 2) p.vecC = p.vecC && ((uintptr_t)p.C % 8 == 0);
     }
     if (g_debug_skip & 16) p.vecC = 0;          // ablation: register-direct epilogue
+    const int lay = c.tra * 2 + c.trb;
+    // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad)
+    if (c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && lay != 2 && g_dma_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
+        p.N % GD_BN == 0 && p.K % GD_BK == 0 && (!c.tra || p.M % 8 == 0) && (lay != 3 || c.to == VC_F32) && p.M >= 8 && !p.rowadd) {
+        const long tiles = (long)VC_CEIL_DIV(p.M, GD_BM) * (p.N / GD_BN);
+        const int ktiles = p.K / GD_BK;
+        // k-slices: model time as (rounds over the 256 CUs) x (k-tiles per item) + the fp32 slab round trip of a split
+        int best = 1; double bestc = 1e30;
+        const size_t per = (size_t)p.M * p.N * sizeof(float);
+        for (int ns = 1; ns <= 64 && ns <= ktiles / 4 + 1; ++ns) {
+            if (ns > 1 && (!scratch || (size_t)ns * per > scratch_bytes)) break;
+            const int nt = VC_CEIL_DIV(ktiles, ns);
+            if (VC_CEIL_DIV(ktiles, nt) != ns) continue;
+            const double rounds = (double)VC_CEIL_DIV(tiles * ns, 256);
+            const double cost = rounds * (nt * 0.25 + 1.5) + (ns > 1 ? ns * (double)per * 2 / 3.0e6 + 3.0 : 0.0);   // microseconds
+            if (cost < bestc) { bestc = cost; best = ns; }
+        }
+        const int nt = VC_CEIL_DIV(ktiles, best);
+        if (g_dma_mode == 1 || tiles * best >= 200) {
+            p.k_per_split = nt * GD_BK;
+            p.partial = best > 1 ? scratch : nullptr;
+            if (lay == 3) return gemm_launch_dma<float, true, true>(c, best, s);
+            if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false>(c, best, s) : gemm_launch_dma<vc_bf16, false, false>(c, best, s);
+            return c.to == VC_F32 ? gemm_launch_dma<float, false, true>(c, best, s) : gemm_launch_dma<vc_bf16, false, true>(c, best, s);
+        }
+    }
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
     // tile size: 128x128 by default; 64x64 when that grid would leave most of the 256 CUs idle (the decoder's
     // 2048-token GEMMs): 4x the blocks and no split-K pass.  Long token reductions still split K.
@@ -118,7 +173,6 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     c.p.k_per_split = small ? -kps : kps;          // sign carries the tile-size choice to gemm_launch (restored there)
 
 #define G(CT_, SA_, SB_, TO_, TRA_, TRB_) return gemm_launch<CT_, SA_, SB_, TO_, TRA_, TRB_>(c, nsplit, s)
-    const int lay = c.tra * 2 + c.trb;
     if (c.ct == VC_F32) {
         switch (lay) { case 0: G(float, float, float, float, false, false); case 1: G(float, float, float, float, false, true);
                        case 2: G(float, float, float, float, true, false); case 3: G(float, float, float, float, true, true); }

@@ -53,6 +53,18 @@ typedef short vc_s16x4 __attribute__((ext_vector_type(4)));
 VC_DEV vc_s16x4 vc_ds_read_tr16(const void* lds_ptr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((vc_s16x4 __attribute__((address_space(3)))*)lds_ptr);
 }
+// Direct-to-LDS DMA (global_load_lds_dwordx4): each lane supplies its own 16-byte global source; the 64 lanes' data lands
+// at lds_piece (wave-uniform) + lane*16, i.e. one contiguous 1 KiB piece.  Tracked by vmcnt like any VMEM load.
+VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+template <int N> VC_DEV void vc_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that does NOT drain vmcnt (DMA stays in flight across it); LDS reads/writes are ordered around it
+VC_DEV void vc_barrier_raw() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 // D(32x32) += A(32x2) * B(2x32), exact f32.  lane l: A[i=l&31][k=l>>5], B[k=l>>5][n=l&31]; D as above.
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -74,6 +86,7 @@ void* dyn_shared();
 void mfma_32x32x16_bf16(const short* a8, const short* b8, float* c16);   // in-place on c16
 void mfma_32x32x2_f32(float a, float b, float* c16);
 void ds_read_tr16(const void* p, short* out4);
+void dma16(const void* gsrc, void* lds_piece);
 void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem);
 }  // namespace vcemu
 using vcemu::dim3;
@@ -122,6 +135,9 @@ VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) { vc
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) { vcemu::mfma_32x32x2_f32(a, b, c.v); return c; }
 struct vc_s16x4 { short v[4]; short& operator[](int i) { return v[i]; } const short& operator[](int i) const { return v[i]; } };
 VC_DEV vc_s16x4 vc_ds_read_tr16(const void* p) { vc_s16x4 r; vcemu::ds_read_tr16(p, r.v); return r; }
+VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) { vcemu::dma16(gsrc, lds_piece); }
+template <int N> VC_DEV void vc_wait_vmcnt() {}
+VC_DEV void vc_barrier_raw() { vcemu::sync_block(); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #endif
 

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "vcad_profile_begin": (None, []),
     "vcad_profile_end": (_i, [C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_int * 8)]),
     "vcad_debug_force_gemm_tile": (None, [_i]),
+    "vcad_debug_gemm_dma": (None, [_i]),
+    "vcad_debug_gemm_dma_launches": (C.c_long, []),
     "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, _vp]),
     "vcad_op_layernorm_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
     "vcad_op_layernorm_bwd": (_i, [_i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
