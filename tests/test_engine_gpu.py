@@ -96,7 +96,20 @@ def test_f32_window1_forward(golden_dir):
     assert abs(float(loss[0]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
 
 
-def test_bf16_step_close_to_goldens(golden_dir):
+@pytest.fixture(params=[-1, 1], ids=["gemm-auto", "gemm-dma-forced"])
+def gemm_dma_mode(request):
+    """bf16 tests run twice: automatic kernel choice (these small batches stay on the register-staged GEMM) and with every
+    legal bf16 GEMM forced through the persistent DMA-fed kernel (the one the C2 bench shapes take)."""
+    lib = L.load()
+    lib.vcad_debug_gemm_dma(request.param)
+    n0 = lib.vcad_debug_gemm_dma_launches()
+    yield request.param
+    lib.vcad_debug_gemm_dma(-1)
+    if request.param == 1:
+        assert lib.vcad_debug_gemm_dma_launches() > n0 + 20, "forced mode did not reach the DMA kernel"
+
+
+def test_bf16_step_close_to_goldens(golden_dir, gemm_dma_mode):
     """Throughput mode: bf16 MFMA / fp32 accumulate.  Reported (not gated at 1e-3): logit MAE, norm-wise error, argmax agreement."""
     gold = np.load(os.path.join(golden_dir, "c1_full.npz"))
     eng = build(L.VCAD_BF16)
@@ -176,10 +189,12 @@ def _masks_for(eng, B, T):
 
 
 @pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(L.VCAD_F32, 1e-4, 2e-3), (L.VCAD_BF16, 3e-2, 6e-2)])
-def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol_grad):
+def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol_grad, gemm_dma_mode):
     """Canonical model, p = 0.1 at every site: the engine's masks are exported (vcad_debug_dropout_mask) and applied by the
     oracle as explicit multipliers.  fp32 mode must agree tightly; bf16 mode (MFMA attention path with in-register masks)
     within bf16 tolerance."""
+    if dtype == L.VCAD_F32 and gemm_dma_mode == 1:
+        pytest.skip("the DMA kernel is bf16 only")
     eng = build(dtype)
     B, T = 2, 4
     eng.set_dropout(0.1, seed=77)

@@ -32,27 +32,31 @@ constexpr int GD_PIECES_A = GD_A_ELEMS * 2 / 1024, GD_PIECES_B = GD_B_ELEMS * 2 
 constexpr int GD_PW = (GD_PIECES_A + GD_PIECES_B) / 8;                          // DMA instructions per wave per stage (6)
 constexpr int GD_NS = 16;                                                       // epilogue store instructions per wave per tile (2x2x4 quads)
 
-// issue this wave's share of one operand tile: NP pieces starting at piece `p0`
+// Per-lane byte offsets of this wave's NP pieces of one operand tile (computed once per item; the k position of a stage is a
+// wave-uniform base added by the scalar unit, so issuing a stage costs ~3 instructions per piece).
 template <bool TR, int EXT, int NP>
-VC_DEV void gd_issue(const vc_bf16* base, long ld, int r0, int k1, int R, vc_bf16* tile, int p0, int lane) {
+VC_DEV void gd_offsets(uint32_t (&off)[NP], long ld, int r0, int R, int p0, int lane) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int pc = p0 + i;
-        const vc_bf16* src;
         if constexpr (!TR) {                       // piece = 8 rows x 128 B
             const int row = pc * 8 + (lane >> 3);
             const int slot = (lane & 7) ^ ((row >> 1) & 7);
             int rg = r0 + row; rg = rg < R ? rg : R - 1;                       // tail rows: re-read the last row (never stored)
-            src = base + (long)rg * ld + k1 + slot * 8;
+            off[i] = (uint32_t)(((long)rg * ld + slot * 8) * 2);
         } else {                                   // piece = 1024/(2*EXT) k-rows of EXT elements
             constexpr int SPR = EXT / 8, KPP = 64 / SPR;                        // slots per k-row, k-rows per piece
             const int k = pc * KPP + lane / SPR;
             const int slot = (lane % SPR) ^ ((k & 3) << 2);
             int c = r0 + slot * 8; c = c + 8 <= R ? c : R - 8;
-            src = base + (long)(k1 + k) * ld + c;
+            off[i] = (uint32_t)(((long)k * ld + c) * 2);
         }
-        vc_dma16(src, tile + pc * 512);
     }
+}
+template <int NP>
+VC_DEV void gd_issue(const unsigned char* ubase, const uint32_t (&off)[NP], vc_bf16* tile, int p0) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) vc_dma16(ubase + off[i], tile + (p0 + i) * 512);
 }
 
 // 8 k-values of one operand row for k-step ks (16 k) of the stage
@@ -74,7 +78,7 @@ VC_DEV vc_s16x8 gd_frag(const vc_bf16* tile, int row0, int ks, int lane) {
     }
 }
 
-struct GdCursor { int item, kt, ntc, seq; };      // item index, k-tile within it, k-tiles of that item, items started so far
+struct GdCursor { int item, kt, ntc, seq, z, tm, tn; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile row, tile column)
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
 VC_DEV void gd_wait_le(int n) {
@@ -121,10 +125,10 @@ template <typename TO, bool TRA, bool TRB>
 VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total) {
     VC_DYN_SHARED(vc_bf16, lds);
     float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + GD_RING_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const vc_bf16* Ag = (const vc_bf16*)p.A;
-    const vc_bf16* Bg = (const vc_bf16*)p.B;
+    const unsigned char* Ag = (const unsigned char*)p.A;
+    const unsigned char* Bg = (const unsigned char*)p.B;
 
     // this workgroup's items: XCD x (= block id & 7, the hardware's round-robin) owns one contiguous chunk of the item list
     // (items ordered k-slice major, then tile_m, tile_n fastest), and its workgroups sweep that chunk interleaved — at any
@@ -138,69 +142,70 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     const int nt = p.k_per_split / GD_BK, ktiles = p.K / GD_BK;  // k-tiles per slice (the last slice may be shorter)
     const bool use_bias = p.bias && !p.partial;
     const bool use_side = (p.residual || p.dact_src) && !p.partial;
+    constexpr int NPA = GD_PIECES_A / 8, NPB = GD_PIECES_B / 8;
+    // bytes one k-tile advances the (wave-uniform) operand base
+    const long kstepA = TRA ? (long)GD_BK * p.lda * 2 : (long)GD_BK * 2, kstepB = TRB ? (long)GD_BK * p.ldb * 2 : (long)GD_BK * 2;
 
+    auto locate = [&](GdCursor& c) {            // integer divisions: once per item, never per k-tile
+        c.z = c.item / tiles_mn; const int rem = c.item - c.z * tiles_mn;
+        c.tm = rem / tiles_n; c.tn = rem - c.tm * tiles_n;
+        const int rest = ktiles - c.z * nt; c.ntc = rest < nt ? rest : nt;
+    };
+    auto advance = [&](GdCursor& c) -> bool {   // true when the cursor moved on to a new item
+        if (++c.kt < c.ntc) return false;
+        c.kt = 0; c.item += nbx; ++c.seq;
+        if (c.item < last) locate(c);
+        return true;
+    };
+    uint32_t offA[NPA], offB[NPB];
+    auto retarget = [&](const GdCursor& c) {
+        gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.tm * GD_BM, p.M, wave * NPA, lane);
+        gd_offsets<TRB, GD_BN, NPB>(offB, p.ldb, c.tn * GD_BN, p.N, wave * NPB, lane);
+    };
     auto issue = [&](const GdCursor& c, int slot) {
-        const int z = c.item / tiles_mn, rem = c.item - z * tiles_mn;
-        const int tm = rem / tiles_n, tn = rem - tm * tiles_n;
-        const int k1 = z * p.k_per_split + c.kt * GD_BK;
+        const long kt_abs = (long)c.z * nt + c.kt;
         vc_bf16* st = lds + slot * GD_STAGE_ELEMS;
         // the tile's 128 bias values: issued AHEAD of the item's first stage, so the wait that retires that stage covers them
-        if (use_bias && c.kt == 0 && wave == 0 && lane < GD_BN / 4) vc_dma16(p.bias + tn * GD_BN + lane * 4, bias_lds + (c.seq & 1) * GD_BN);
-        gd_issue<TRA, GD_BM, GD_PIECES_A / 8>(Ag, p.lda, tm * GD_BM, k1, p.M, st, wave * (GD_PIECES_A / 8), lane);
-        gd_issue<TRB, GD_BN, GD_PIECES_B / 8>(Bg, p.ldb, tn * GD_BN, k1, p.N, st + GD_A_ELEMS, wave * (GD_PIECES_B / 8), lane);
-    };
-    auto slice_tiles = [&](int item) { const int rest = ktiles - (item / tiles_mn) * nt; return rest < nt ? rest : nt; };
-    auto advance = [&](GdCursor& c) {
-        if (++c.kt == c.ntc) { c.kt = 0; c.item += nbx; ++c.seq; if (c.item < last) c.ntc = slice_tiles(c.item); }
+        if (use_bias && c.kt == 0 && wave == 0 && lane < GD_BN / 4) vc_dma16(p.bias + c.tn * GD_BN + lane * 4, bias_lds + (c.seq & 1) * GD_BN);
+        gd_issue<NPA>(Ag + kt_abs * kstepA, offA, st, wave * NPA);
+        gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS, wave * NPB);
     };
 
-    GdCursor pf{first, 0, first < last ? slice_tiles(first) : 1, 0}, cp = pf;
+    GdCursor pf{first, 0, 1, 0, 0, 0, 0};
+    if (first < last) { locate(pf); retarget(pf); }
+    GdCursor cp = pf;
     int ahead = 0;                                               // stages issued and not yet consumed
-    for (; ahead < GD_STAGES - 1 && pf.item < last; ++ahead) { issue(pf, ahead); advance(pf); }
+    for (; ahead < GD_STAGES - 1 && pf.item < last; ++ahead) { issue(pf, ahead); if (advance(pf) && pf.item < last) retarget(pf); }
 
     vc_f32x16 acc[2][2];
-    vc_u32x4 side[2][2][4];
     int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
-    while (cp.item < last) {
+    const int dbg = p.debug_skip;
+
+    // One k-tile: retire stage `slot`, re-arm the slot freed by the previous k-tile, feed the matrix cores.
+    // Every instruction here is paid 300+ times per launch by every wave (a wave issues one instruction per ~4 cycles, a
+    // taken branch costs ~5 of those), so the body is kept to: wait, barrier, 6 DMA issues, 16 ds_read, 16 MFMA.
+    auto ktile_begin = [&]() {
         // stage `slot` must have landed.  VMEM retires in issue order on gfx9, so "at most N outstanding" with N = the number
         // of operations issued AFTER this stage's DMA — the younger stage's pieces and the epilogue stores of the last two
-        // iterations — is exact: neither the prefetch nor the stores are waited for.  N must never over-count (that would let
-        // the stage itself still be in flight), so only guaranteed stores (interior tile, the C quads) are counted.
-        gd_wait_le((ahead >= 2 ? GD_PW : 0) + young_prev + young_cur);
-        vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
+        // k-tiles — is exact: neither the prefetch nor the stores are waited for.  N must never over-count (the stage itself
+        // could still be in flight), so only guaranteed stores (interior tile, the C quads) are counted.
+        const int young = young_prev + young_cur;
+        if (young == 0) { if (ahead >= 2) vc_wait_vmcnt<GD_PW>(); else vc_wait_vmcnt<0>(); }
+        else gd_wait_le((ahead >= 2 ? GD_PW : 0) + young);
         young_prev = young_cur; young_cur = 0;
-
-        const bool fin = cp.kt == cp.ntc - 1;
-        const int z = cp.item / tiles_mn, rem = cp.item - z * tiles_mn;
-        const int tm = rem / tiles_n, tn = rem - tm * tiles_n;
-        if (fin && use_side) {
-            // side input of the fused epilogue: requested now, consumed after this phase's 16 MFMAs
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31); m = m < p.M ? m : p.M - 1;
-#pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = tn * GD_BN + wn * 64 + jn * 32 + 8 * q + 4 * (lane >> 5);
-                        if (p.residual) side[i][jn][q] = *reinterpret_cast<const vc_u32x4*>(p.residual + (long)m * p.ldr + n);
-                        else if constexpr (sizeof(TO) == 2) {
-                            const vc_u32x2 t = *reinterpret_cast<const vc_u32x2*>(((const TO*)p.dact_src) + (long)m * p.lddact + n);
-                            side[i][jn][q].x = t.x; side[i][jn][q].y = t.y;
-                        } else side[i][jn][q] = *reinterpret_cast<const vc_u32x4*>(((const TO*)p.dact_src) + (long)m * p.lddact + n);
-                    }
-            }
-        }
-        if (pf.item < last) { issue(pf, slot == 0 ? GD_STAGES - 1 : slot - 1); advance(pf); } else --ahead;
-
-        if (cp.kt == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-        }
+        vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
+    };
+    // (Issuing the next stage's pieces BETWEEN the MFMAs instead of in one burst after the barrier was measured: +1-3 % on the
+    // k-contiguous layout, -25..-40 % on the ds_read_b64_tr_b16 layouts, whose 32 LDS reads per k-tile then collide with the
+    // DMA's LDS writes.  The LDS port — 48 KiB of DMA writes at 64-85 B/clk plus 128 KiB of fragment reads at 256 B/clk per
+    // 1024-cycle MFMA phase — is what this tile shape saturates first; see DESIGN.md.)
+    auto ktile_prefetch = [&]() {
+        if (pf.item < last) {
+            issue(pf, slot == 0 ? GD_STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
+            if (advance(pf) && pf.item < last) retarget(pf);
+        } else --ahead;
+    };
+    auto ktile_mfma = [&]() {
         const vc_bf16* a_tile = lds + slot * GD_STAGE_ELEMS;
         const vc_bf16* b_tile = a_tile + GD_A_ELEMS;
 #pragma unroll
@@ -216,33 +221,93 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);   // swapped: D[n][m]
         }
+        slot = slot == GD_STAGES - 1 ? 0 : slot + 1;
+    };
 
-        if (fin) {
-            // epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3
-            const float* brow = bias_lds + (cp.seq & 1) * GD_BN + wn * 64 + 4 * (lane >> 5);
+
+    // plain epilogue = scale-free, bias at most: the QKV / dgrad / split-K launches (most of the FLOPs) skip the generic code
+    const bool plain = !p.partial && !p.aux && !p.act && !p.drop.key && !p.dact_src && !p.residual && p.alpha == 1.0f;
+
+    for (; cp.item < last; cp.item += nbx, ++cp.seq) {
+        if (cp.seq) locate(cp);
+        const int z = cp.z, tm = cp.tm, tn = cp.tn;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31);
-                if (m < p.M) {
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+        for (int kt = 0; kt < cp.ntc - 1; ++kt) { ktile_begin(); ktile_prefetch(); ktile_mfma(); }
+
+        // ---- last k-tile of the item: the epilogue's side input is requested before the MFMA phase that hides its latency
+        ktile_begin();
+        vc_u32x4 side[2][2][4];
+        if (use_side) {
+            // the residual / dact choice is hoisted around the whole unrolled batch (a per-load select makes hipcc branch and
+            // drain around every load)
+            int mrow[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31); mrow[i] = m < p.M ? m : p.M - 1; }
+            const int ncol = tn * GD_BN + wn * 64 + 4 * (lane >> 5);
+            if (p.residual) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            side[i][jn][q] = *reinterpret_cast<const vc_u32x4*>(p.residual + (long)mrow[i] * p.ldr + ncol + jn * 32 + 8 * q);
+            } else if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int n = tn * GD_BN + wn * 64 + jn * 32 + 8 * q + 4 * (lane >> 5);
-                            float v[4] = {acc[i][jn][4 * q], acc[i][jn][4 * q + 1], acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]};
-                            if (p.partial) {
-                                quad_st<float>(p.partial + ((long)z * p.M + m) * p.N + n, v);
-                            } else {
-                                float b4[4] = {0.f, 0.f, 0.f, 0.f};
-                                if (use_bias) quad_ld_f32(brow + jn * 32 + 8 * q, b4);
-                                gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
-                            }
+                            const vc_u32x2 t = *reinterpret_cast<const vc_u32x2*>(((const TO*)p.dact_src) + (long)mrow[i] * p.lddact + ncol + jn * 32 + 8 * q);
+                            side[i][jn][q].x = t.x; side[i][jn][q].y = t.y;
                         }
-                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            side[i][jn][q] = *reinterpret_cast<const vc_u32x4*>(((const TO*)p.dact_src) + (long)mrow[i] * p.lddact + ncol + jn * 32 + 8 * q);
             }
-            if ((tm + 1) * GD_BM <= p.M && !(p.debug_skip & 32)) young_cur = GD_NS;
         }
-        advance(cp);
-        slot = slot == GD_STAGES - 1 ? 0 : slot + 1;
+        ktile_prefetch();
+        const float* brow = bias_lds + (cp.seq & 1) * GD_BN + wn * 64 + 4 * (lane >> 5);
+        ktile_mfma();
+
+        // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3
+        if (dbg & 64) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31);
+            if (m < p.M) {
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = tn * GD_BN + wn * 64 + jn * 32 + 8 * q + 4 * (lane >> 5);
+                        float v[4] = {acc[i][jn][4 * q], acc[i][jn][4 * q + 1], acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]};
+                        if (p.partial) {
+                            quad_st<float>(p.partial + ((long)z * p.M + m) * p.N + n, v);
+                        } else {
+                            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (use_bias) quad_ld_f32(brow + jn * 32 + 8 * q, b4);
+                            if (plain) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] += b4[k];
+                                quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
+                            } else gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
+                        }
+                    }
+            }
+        }
+        if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = GD_NS;
     }
+    vc_wait_vmcnt<0>();            // no DMA may still be writing this workgroup's LDS when it is handed to the next one
 }

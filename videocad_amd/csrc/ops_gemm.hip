@@ -127,7 +127,8 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     const int lay = c.tra * 2 + c.trb;
     // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad)
     if (c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && lay != 2 && g_dma_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
-        p.N % GD_BN == 0 && p.K % GD_BK == 0 && (!c.tra || p.M % 8 == 0) && (lay != 3 || c.to == VC_F32) && p.M >= 8 && !p.rowadd) {
+        p.N % GD_BN == 0 && p.K % GD_BK == 0 && (!c.tra || p.M % 8 == 0) && (lay != 3 || c.to == VC_F32) && p.M >= 8 && !p.rowadd &&
+        (double)p.lda * (c.tra ? p.K : p.M) * 2 < 2.0e9 && (double)p.ldb * (c.trb ? p.K : p.N) * 2 < 2.0e9) {
         const long tiles = (long)VC_CEIL_DIV(p.M, GD_BM) * (p.N / GD_BN);
         const int ktiles = p.K / GD_BK;
         // k-slices: model time as (rounds over the 256 CUs) x (k-tiles per item) + the fp32 slab round trip of a split
