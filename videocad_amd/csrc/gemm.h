@@ -19,7 +19,7 @@
 #pragma once
 #include "vc_rt.h"
 
-enum { VC_ACT_NONE = 0, VC_ACT_GELU = 1, VC_ACT_RELU = 2, VC_ACT_TANH = 3 };
+enum { VC_ACT_NONE = 0, VC_ACT_GELU = 1, VC_ACT_RELU = 2, VC_ACT_TANH = 3, VC_ACT_GELU_FAST = 4 /* internal: bf16-mode GELU */ };
 
 struct GemmParams {
     const void* A; const void* B; void* C;
@@ -46,14 +46,31 @@ VC_DEV float vc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118
 VC_DEV float vc_dgelu(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
+// bf16-mode GELU: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 + fp32 rounding — three orders below the bf16 rounding of
+// the value it feeds) — one exp, one reciprocal, five FMAs instead of libm's erff; the fp32 parity mode keeps erff.
+// e = exp(-x^2/2) is shared by erf(x/sqrt2) and the Gaussian term of the derivative.
+VC_DEV float vc_erf_sqrt2_fast(float x, float e) {          // erf(x / sqrt(2)) given e = exp(-x*x/2)
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = 1.0f / (1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * e;
+    return x < 0.0f ? -r : r;
+}
+VC_DEV float vc_gelu_fast(float x) { const float e = vc_expf_fast(-0.5f * x * x); return 0.5f * x * (1.0f + vc_erf_sqrt2_fast(x, e)); }
+VC_DEV float vc_dgelu_fast(float x) {
+    const float e = vc_expf_fast(-0.5f * x * x);
+    return 0.5f * (1.0f + vc_erf_sqrt2_fast(x, e)) + x * 0.3989422804014327f * e;
+}
 
 VC_DEV float vc_apply_act(float v, int act) {
+    if (act == VC_ACT_GELU_FAST) return vc_gelu_fast(v);
     if (act == VC_ACT_GELU) return vc_gelu(v);
     if (act == VC_ACT_RELU) return fmaxf(v, 0.0f);
     if (act == VC_ACT_TANH) return tanhf(v);
     return v;
 }
 VC_DEV float vc_apply_dact(float v, float s, int kind) {
+    if (kind == VC_ACT_GELU_FAST) return v * vc_dgelu_fast(s);
     if (kind == VC_ACT_GELU) return v * vc_dgelu(s);
     if (kind == VC_ACT_RELU) return (s > 0.0f) ? v : 0.0f;
     if (kind == VC_ACT_TANH) return v * (1.0f - s * s);

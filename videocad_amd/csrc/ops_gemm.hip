@@ -113,6 +113,10 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
     if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
     p.debug_skip = g_debug_skip;
+    if (c.ct == VC_BF16) {          // bf16 mode: cheap erf (gemm.h) in both GEMM kernels, so results do not depend on the kernel choice
+        if (p.act == VC_ACT_GELU) p.act = VC_ACT_GELU_FAST;
+        if (p.dact_kind == VC_ACT_GELU) p.dact_kind = VC_ACT_GELU_FAST;
+    }
     p.stagger = g_stagger >= 0 ? g_stagger : 0;
     p.vecA = (((uintptr_t)p.A) % 16 == 0) && ((p.lda * dsize(c.sa)) % 16 == 0);
     p.vecB = (((uintptr_t)p.B) % 16 == 0) && ((p.ldb * dsize(c.sb)) % 16 == 0);

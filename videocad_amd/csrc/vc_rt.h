@@ -58,6 +58,7 @@ VC_DEV vc_s16x4 vc_ds_read_tr16(const void* lds_ptr) {
 VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
 }
+VC_DEV float vc_expf_fast(float x) { return __expf(x); }
 VC_DEV int vc_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }     // x is known to be wave-uniform: keep it in an SGPR
 template <int N> VC_DEV void vc_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // workgroup barrier that does NOT drain vmcnt (DMA stays in flight across it); LDS reads/writes are ordered around it
@@ -137,6 +138,7 @@ VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) { vcemu::mfm
 struct vc_s16x4 { short v[4]; short& operator[](int i) { return v[i]; } const short& operator[](int i) const { return v[i]; } };
 VC_DEV vc_s16x4 vc_ds_read_tr16(const void* p) { vc_s16x4 r; vcemu::ds_read_tr16(p, r.v); return r; }
 VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) { vcemu::dma16(gsrc, lds_piece); }
+VC_DEV float vc_expf_fast(float x) { return expf(x); }
 VC_DEV int vc_uniform(int x) { return x; }
 template <int N> VC_DEV void vc_wait_vmcnt() {}
 VC_DEV void vc_barrier_raw() { vcemu::sync_block(); }
