@@ -57,23 +57,25 @@ def test_gemm_bf16_big(hip):
 
 
 def test_gemm_dma_kernel(hip):
-    """the persistent DMA-fed kernel at sizes where every workgroup streams several tiles (ragged M tail, k-slices with a
-    short last slice, fused bias / GELU / residual), three times each — a mis-counted vmcnt shows up as sporadic wrong tiles"""
+    """the persistent DMA-fed kernel (forced: the automatic choice keeps some of these shapes on the register-staged kernel) at
+    sizes where every workgroup streams several tiles — ragged M tail, k-slices with a short last slice, fused bias / GELU /
+    residual — three times each: a mis-counted vmcnt shows up as sporadic wrong tiles"""
     n0 = hip.vcad_debug_gemm_dma_launches()
-    for rep in range(3):
-        U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1, seed=rep)
-        U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True, seed=rep)
-        U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, trb=1, seed=rep)
-        U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep)
-        U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep)
-    assert hip.vcad_debug_gemm_dma_launches() == n0 + 15, "the big bf16 GEMMs did not take the DMA kernel"
-    hip.vcad_debug_gemm_dma(1)                                   # small problems through the same kernel
+    hip.vcad_debug_gemm_dma(1)
     try:
-        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8)
+        for rep in range(3):
+            U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1, seed=rep)
+            U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True, seed=rep)
+            U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, trb=1, seed=rep)
+            U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep)
+            U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep)
+        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8)      # small problems, same kernel
         U.check_gemm(hip, DEV, 264, 128, 64, BF16, to=F32, tra=1, trb=1, pad=8)
     finally:
         hip.vcad_debug_gemm_dma(-1)
-    assert hip.vcad_debug_gemm_dma_launches() == n0 + 17
+    assert hip.vcad_debug_gemm_dma_launches() == n0 + 17, "a GEMM did not take the DMA kernel"
+    U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True)              # automatic choice: DMA kernel
+    assert hip.vcad_debug_gemm_dma_launches() == n0 + 18
 
 
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16), (1024, BF16)])

@@ -136,6 +136,7 @@ def run(args):
     dt = L.VCAD_BF16 if args.dtype == "bf16" else L.VCAD_F32
     B, T = args.batch, args.seq
     eng = NativeEngine(make_config(dtype=dt, **CANONICAL), device)
+    eng.lib.vcad_debug_gemm_dma(getattr(args, "gemm_dma", -1))
     init_weights(eng, device)
     frames, actions, cad = synthetic_batch(B, T, 1000 * 2 + rank, device)
     stepper = Stepper(eng, world, rank, dropout=args.dropout)

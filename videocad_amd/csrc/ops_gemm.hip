@@ -147,7 +147,12 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
             if (cost < bestc) { bestc = cost; best = ns; }
         }
         const int nt = VC_CEIL_DIV(ktiles, best);
-        if (g_dma_mode == 1 || tiles * best >= 200) {
+        // Where the persistent kernel wins was measured in-model at the C2 shapes (A/B of one train step, profiles/r01_gemm_ab.md):
+        // it loses where its one-workgroup-per-CU design has nothing to overlap a VALU-heavy epilogue with (GELU / GELU' — the
+        // register-staged kernel's second co-resident workgroup hides that), on the long-K dgrad through ds_read_b64_tr_b16
+        // (K >= 2048), and on wgrads with fewer than 16 output tiles (the k-slice slabs dominate).
+        const bool wins = tiles * best >= 200 && !p.act && !p.dact_src && !(lay == 1 && p.K >= 2048) && !(lay == 3 && tiles < 16);
+        if (g_dma_mode == 1 || wins) {
             p.k_per_split = nt * GD_BK;
             p.partial = best > 1 ? scratch : nullptr;
             if (lay == 3) return gemm_launch_dma<float, true, true>(c, best, s);
