@@ -29,8 +29,6 @@ def run(name, M, N, K, to=BF, tra=0, trb=0, bias=False, iters=10, masks=(0, 32, 
     lib.vcad_debug_gemm_skip(0)
 
 R = 104000
-M = (0, 2048, 0, 2048)
-run("qkv fwd", R, 3072, 512, bias=True, masks=M)
-run("mlp-shaped fwd", R, 512, 512, bias=True, masks=M)
-run("dao dgrad", R, 1024, 512, trb=1, masks=M)
-run("dqkv dgrad", R, 512, 3072, trb=1, masks=M)
+run("qkv fwd", R, 3072, 512, bias=True)
+run("dqkv dgrad", R, 512, 3072, trb=1)
+run("qkv wgrad", 3072, 512, R, to=F32, tra=1, trb=1)

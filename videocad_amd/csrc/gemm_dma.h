@@ -78,25 +78,6 @@ VC_DEV vc_s16x8 gd_frag(const vc_bf16* tile, int row0, int ks, int lane) {
     }
 }
 
-// streaming (non-temporal) output stores: C is written once and is far larger than the 4 MiB L2 of an XCD — without the hint
-// the write stream keeps evicting the B panel every tile of that XCD is re-reading
-template <typename T> VC_DEV void gd_quad_st_stream(T* p, const float* v);
-#ifndef VC_EMU
-typedef unsigned int gd_u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int gd_u32x2_t __attribute__((ext_vector_type(2)));
-template <> VC_DEV void gd_quad_st_stream<float>(float* p, const float* v) {
-    gd_u32x4_t q = {vc_f32_bits(v[0]), vc_f32_bits(v[1]), vc_f32_bits(v[2]), vc_f32_bits(v[3])};
-    __builtin_nontemporal_store(q, reinterpret_cast<gd_u32x4_t*>(p));
-}
-template <> VC_DEV void gd_quad_st_stream<vc_bf16>(vc_bf16* p, const float* v) {
-    gd_u32x2_t q = {vc_pack_bf16x2(v[0], v[1]), vc_pack_bf16x2(v[2], v[3])};
-    __builtin_nontemporal_store(q, reinterpret_cast<gd_u32x2_t*>(p));
-}
-#else
-template <> VC_DEV void gd_quad_st_stream<float>(float* p, const float* v) { quad_st<float>(p, v); }
-template <> VC_DEV void gd_quad_st_stream<vc_bf16>(vc_bf16* p, const float* v) { quad_st<vc_bf16>(p, v); }
-#endif
-
 struct GdCursor { int item, kt, ntc, seq, z, tm, tn; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile row, tile column)
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
@@ -109,6 +90,8 @@ VC_DEV void gd_wait_le(int n) {
     else vc_wait_vmcnt<0>();
 }
 
+// (Non-temporal C stores were tried to keep the write stream from evicting the B panel: 3x SLOWER — each lane's 8/16-byte
+// piece of a row then reaches memory as its own partial write instead of merging in L2.  Plain stores it is.)
 // fused epilogue on one accumulator quad (row m, columns n..n+3) with the side input already in registers
 template <typename TO>
 VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], const float (&b4)[4], const vc_u32x4& side) {
@@ -137,7 +120,7 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
     if (p.residual) {
         v[0] += vc_bits_f32(side.x); v[1] += vc_bits_f32(side.y); v[2] += vc_bits_f32(side.z); v[3] += vc_bits_f32(side.w);
     }
-    if (p.debug_skip & 2048) quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v); else gd_quad_st_stream<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
+    quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
 }
 
 template <typename TO, bool TRA, bool TRB>
@@ -320,7 +303,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                             if (plain) {
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) v[k] += b4[k];
-                                if (dbg & 2048) quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v); else gd_quad_st_stream<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
+                                quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
                             } else gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
                         }
                     }
