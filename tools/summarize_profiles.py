@@ -52,8 +52,8 @@ if pmc:
     for k in names[:24]:
         t = ms.get(k, 0)
         print(f"| `{k}` | {rd[k]:.2f} | {wr[k]:.2f} | {t:.3f} | {((rd[k] + wr[k]) / t if t else 0):.2f} |")
-    g_rd = sum(v for k, v in rd.items() if k.startswith("gemm_kernel")); g_wr = sum(v for k, v in wr.items() if k.startswith("gemm_kernel"))
-    g_n = sum(int(r["Calls"]) for r in ours if short(r["Name"]).startswith("gemm_kernel")) / steps_traced
+    g_rd = sum(v for k, v in rd.items() if k.startswith(("gemm_kernel", "gemm_dma_kernel"))); g_wr = sum(v for k, v in wr.items() if k.startswith(("gemm_kernel", "gemm_dma_kernel")))
+    g_n = sum(int(r["Calls"]) for r in ours if short(r["Name"]).startswith(("gemm_kernel", "gemm_dma_kernel"))) / steps_traced
     json.dump({"tag": tag, "gemm_read_GB_per_step": g_rd, "gemm_write_GB_per_step": g_wr, "gemm_launches_per_step": g_n,
                "gemm_hbm_bytes_per_launch": (g_rd + g_wr) * 1e9 / max(g_n, 1), "total_read_GB_per_step": sum(rd.values()),
                "total_write_GB_per_step": sum(wr.values())}, open(os.path.join(base, "pmc.json"), "w"), indent=1)

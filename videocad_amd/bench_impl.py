@@ -187,7 +187,7 @@ def run(args):
             traffic = round(pj["gemm_hbm_bytes_per_launch"]); traffic_src = "profiles/" + cands[-1]
     except Exception:
         pass
-    roof = {"bound": "mfma", "kernel": "gemm_kernel (all Linear fwd/dgrad/wgrad launches of one step)",
+    roof = {"bound": "mfma", "kernel": "gemm_kernel + gemm_dma_kernel (all Linear fwd/dgrad/wgrad launches of one step)",
             "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "alg_bytes_per_launch": round((pby[0] + pby[1] + pby[2]) / max(gemm_n, 1)),
