@@ -47,6 +47,16 @@ def both(name, *a, **k):
 
 
 R = 104000
+if len(sys.argv) > 1 and sys.argv[1] == "nn":
+    lib.vcad_debug_gemm_dma(1)
+    run("dqkv dgrad as NN (W^T shadow) [dma]", R, 512, 3072)
+    run("dqkv dgrad NT [dma]", R, 512, 3072, trb=1)
+    run("dao dgrad as NN [dma]", R, 1024, 512)
+    run("dao dgrad NT [dma]", R, 1024, 512, trb=1)
+    lib.vcad_debug_gemm_dma(0)
+    run("dqkv dgrad as NN [reg]", R, 512, 3072)
+    run("dqkv dgrad NT [reg]", R, 512, 3072, trb=1)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "dma":
     both("vit qkv fwd", R, 3072, 512, bias=True)
     both("vit out fwd (+res, f32 out)", R, 512, 1024, to=F32, bias=True, res=True)
@@ -60,6 +70,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "dma":
     both("vit mlp wgrad", 512, 512, R, to=F32, tra=1, trb=1)
     both("square 4096", 4096, 4096, 4096)
     both("square 8192", 8192, 8192, 8192)
+    both("square 8192 NT", 8192, 8192, 8192, trb=1)
+    both("square 8192 TT", 8192, 8192, 8192, to=F32, tra=1, trb=1)
     sys.exit(0)
 run("vit qkv fwd", R, 3072, 512)
 run("vit out fwd (+res, f32 out)", R, 512, 1024, to=F32, bias=True, res=True)

@@ -34,9 +34,10 @@ struct Epi {
     vc_drop drop = {0u, 0u, 1.0f};
 };
 
+struct TransposeJob { long src_off; long dst_off; int rows, cols; };   // S[src_off + r*cols + c] -> wT[dst_off + c*rows + r]
 struct VitW {       // float offsets into the flat buffer
     long pos, cls, ln1w, ln1b, pew, peb, ln2w, ln2b, normw, normb;
-    struct L { long anw, anb, qkv, ow, ob, fnw, fnb, w1, b1, w4, b4; };
+    struct L { long anw, anb, qkv, ow, ob, fnw, fnb, w1, b1, w4, b4; long qkvT = -1, owT = -1, w1T = -1, w4T = -1; /* offsets into wT */ };
     std::vector<L> l;
 };
 struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w2, b2, n1w, n1b, n2w, n2b, n3w, n3b; };
@@ -74,6 +75,10 @@ struct vcad_engine {
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
     float drop_p = 0.f; uint64_t drop_seed = 0; void* t_dum = nullptr;
+    // bf16 mode: transposed copies W^T[in][out] of the frame ViT's Linear weights, so every big dgrad is a k-contiguous
+    // (ds_read_b128) GEMM instead of a ds_read_b64_tr_b16 one (measured: dqkv dgrad 569 -> 462 us); refreshed lazily after
+    // every weight change (optimizer step / shadow sync / re-plan)
+    vc_bf16* wT = nullptr; bool wT_fresh = false; std::vector<TransposeJob> wT_jobs;
 };
 
 namespace {
@@ -223,6 +228,15 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     const long nlog = (long)c.num_params * c.num_params_values;
     e->dl_cmds = b.take<float>(M * c.num_classes * 4); e->dl_pars = b.take<float>(M * nlog * 4);
     e->norm_part = b.take<float>(1024 * 4); e->norm_out = b.take<float>(8 * 4);
+    e->wT = nullptr; e->wT_jobs.clear(); e->wT_fresh = false;
+    if (e->dt == VC_BF16 && c.enable_past_states) {
+        long off = 0;
+        auto job = [&](long src, int rows, int cols) { e->wT_jobs.push_back(TransposeJob{src, off, rows, cols}); const long o = off; off += (long)rows * cols; return o; };
+        for (auto& l : e->wv[0].l) {
+            l.qkvT = job(l.qkv, 3 * inner, D); l.owT = job(l.ow, D, inner); l.w1T = job(l.w1, c.vit_mlp, D); l.w4T = job(l.w4, D, c.vit_mlp);
+        }
+        e->wT = b.take<vc_bf16>(off * 2);
+    }
     return b.off + 256;
 }
 
@@ -235,6 +249,17 @@ struct Ctx {
     vcad_engine* e; vc_stream_t s;
     int dt() const { return e->dt; }
     Mat W(long off, long ld) const { return e->dt == VC_BF16 ? Mat{(const void*)(e->S + off), VC_BF16, ld} : Mat{(const void*)(e->P + off), VC_F32, ld}; }
+    // transposed shadow (bf16 mode, frame ViT): offT < 0 -> not available
+    bool hasT(long offT) const { return e->wT && offT >= 0; }
+    Mat WT(long offT, long ld) const { return Mat{(const void*)(e->wT + offT), VC_BF16, ld}; }
+    int refresh_wT() const {
+        if (!e->wT || e->wT_fresh) return 0;
+        for (const auto& j : e->wT_jobs) { int rc = vc_transpose_bf16(e->S + j.src_off, e->wT + j.dst_off, j.rows, j.cols, s); if (rc) return rc; }
+        e->wT_fresh = true;
+        return 0;
+    }
+    // dX[M,K] = dY[M,N] W[N,K] through W^T[K][N]: both operands k-contiguous
+    int lin_dgrad_T(Mat dY, Mat WTm, Mat dX, int M, int N, int K, const Epi& ep) const { return gemm(dY, 0, WTm, 0, dX, M, K, N, ep, VC_CAT_GEMM_DGRAD + 1); }
     const float* Pf(long off) const { return e->P + off; }
     float* Gf(long off) const { return e->G + off; }
     Mat A32(const float* p, long ld) const { return Mat{p, VC_F32, ld}; }
@@ -256,9 +281,9 @@ struct Ctx {
         *out = AT(e->t_dum, cols);
         return vc_dropout_mul(e->dt, dx, ldx, e->t_dum, cols, rows, cols, d, s);
     }
-    int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep) const {
+    int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep, int role = 0) const {
         GemmCall c; memset(&c, 0, sizeof(c));
-        c.ct = e->dt; c.sa = A.dt; c.sb = B.dt; c.to = C.dt; c.tra = tra; c.trb = trb;
+        c.role = role; c.ct = e->dt; c.sa = A.dt; c.sb = B.dt; c.to = C.dt; c.tra = tra; c.trb = trb;
         GemmParams& p = c.p;
         p.A = A.p; p.B = B.p; p.C = (void*)C.p; p.M = M; p.N = N; p.K = K; p.lda = A.ld; p.ldb = B.ld; p.ldc = C.ld;
         p.alpha = 1.0f; p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr;
@@ -366,6 +391,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
     const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
     const long N = a.N, R = N * (P + 1), Rp = N * P;
     float* dx = e->t_dx;
+    if (v == 0) CK(cx.refresh_wT());
     const int split = c.vit_depth / 2;
     int Lhi = c.vit_depth - 1, Llo = 0;
     if (part == 1) Llo = split; if (part == 2) Lhi = split - 1;
@@ -386,14 +412,17 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));
         CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
-          CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
+          if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep));
+          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
         CK(cx.lin_wgrad(cx.AT(e->t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
-        CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
+        if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(e->t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
+        else CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         CK(cx.ln_bwd(e->dt, e->t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D));
         // attention block (xm = x + drop(Wo ao + bo))
         CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du));
         CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
-        CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
+        if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
+        else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
         {
             AttnParams p; memset(&p, 0, sizeof(p));
             const char* q = (const char*)l.qkv; char* dq = (char*)e->t_dqkv;
@@ -410,7 +439,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             CK(vc_attn_bwd(e->dt, c.vit_dim_head, p, cx.s));
         }
         CK(cx.lin_wgrad(cx.AT(e->t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
-        CK(cx.lin_dgrad(cx.AT(e->t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(e->t_dh, D), (int)R, 3 * inner, D, Epi()));
+        if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(e->t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(e->t_dh, D), (int)R, 3 * inner, D, Epi()));
+        else CK(cx.lin_dgrad(cx.AT(e->t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(e->t_dh, D), (int)R, 3 * inner, D, Epi()));
         CK(cx.ln_bwd(e->dt, e->t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
     }
     if (part != 1) {
@@ -637,12 +667,13 @@ int vcad_bucket_range(const vcad_engine* e, int b, int64_t* begin, int64_t* end)
 int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, void* shadow) {
     if (!params) { vc_set_error("vcad_bind: params is null"); return VC_ERR_ARG; }
     if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
-    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow;
+    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow; e->wT_fresh = false;
     return 0;
 }
 int vcad_sync_shadow(vcad_engine* e, void* stream) {
     if (e->dt != VC_BF16) return 0;
     if (!e->P || !e->S) { vc_set_error("vcad_sync_shadow: not bound"); return VC_ERR_ARG; }
+    e->wT_fresh = false;
     return vc_cast(VC_BF16, e->P, e->S, e->ptotal, (vc_stream_t)stream);
 }
 size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
@@ -757,6 +788,7 @@ int vcad_optimizer_step(vcad_engine* e, float lr, float b1, float b2, float eps,
     a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
     a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S;
     CK(vc_adam(a, s));
+    e->wT_fresh = false;                  // the bf16 shadow just changed: its transposed copies are rebuilt before the next backward
     if (norm_out) CK(vc_memcpy_d2d_async(norm_out, e->norm_out, 2 * 4, s));
     return 0;
 }

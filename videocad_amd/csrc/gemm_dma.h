@@ -27,9 +27,9 @@
 constexpr int GD_THREADS = 512, GD_BM = 256, GD_BN = 128, GD_BK = 64, GD_STAGES = 3;
 constexpr int GD_A_ELEMS = GD_BM * GD_BK, GD_B_ELEMS = GD_BN * GD_BK, GD_STAGE_ELEMS = GD_A_ELEMS + GD_B_ELEMS;
 constexpr size_t GD_RING_BYTES = (size_t)GD_STAGES * GD_STAGE_ELEMS * 2;         // 147456
-constexpr size_t GD_LDS_BYTES = GD_RING_BYTES + 2 * GD_BN * sizeof(float);        // + two bias rows (double-buffered by item parity)
+constexpr size_t GD_LDS_BYTES = GD_RING_BYTES + 3 * GD_BN * sizeof(float);        // + three bias rows (the prefetch runs up to two items ahead)
 constexpr int GD_PIECES_A = GD_A_ELEMS * 2 / 1024, GD_PIECES_B = GD_B_ELEMS * 2 / 1024;   // 32, 16 (1 KiB each)
-constexpr int GD_PW = (GD_PIECES_A + GD_PIECES_B) / 8;                          // DMA instructions per wave per stage (6)
+constexpr int GD_PW = (GD_PIECES_A + GD_PIECES_B) / 4;                          // DMA instructions per issuing wave per stage (12)
 constexpr int GD_NS = 16;                                                       // epilogue store instructions per wave per tile (2x2x4 quads)
 
 // Per-lane byte offsets of this wave's NP pieces of one operand tile (computed once per item; the k position of a stage is a
@@ -144,7 +144,11 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     const int nt = p.k_per_split / GD_BK, ktiles = p.K / GD_BK;  // k-tiles per slice (the last slice may be shorter)
     const bool use_bias = p.bias && !p.partial;
     const bool use_side = (p.residual || p.dact_src) && !p.partial;
-    constexpr int NPA = GD_PIECES_A / 8, NPB = GD_PIECES_B / 8;
+    // The two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) take turns issuing a WHOLE stage (12 pieces per wave):
+    // the group whose turn it is stalls ~0.3 us in the address path while the other group is already on the matrix cores,
+    // then runs its own MFMAs while the first group waits at the next barrier — issue time no longer adds to MFMA time.
+    constexpr int NPA = GD_PIECES_A / 4, NPB = GD_PIECES_B / 4;
+    const int grp = wave >> 2, wq = wave & 3;
     // bytes one k-tile advances the (wave-uniform) operand base
     const long kstepA = TRA ? (long)GD_BK * p.lda * 2 : (long)GD_BK * 2, kstepB = TRB ? (long)GD_BK * p.ldb * 2 : (long)GD_BK * 2;
 
@@ -161,23 +165,23 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     };
     uint32_t offA[NPA], offB[NPB];
     auto retarget = [&](const GdCursor& c) {
-        gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.tm * GD_BM, p.M, wave * NPA, lane);
-        gd_offsets<TRB, GD_BN, NPB>(offB, p.ldb, c.tn * GD_BN, p.N, wave * NPB, lane);
+        gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.tm * GD_BM, p.M, wq * NPA, lane);
+        gd_offsets<TRB, GD_BN, NPB>(offB, p.ldb, c.tn * GD_BN, p.N, wq * NPB, lane);
     };
     auto issue = [&](const GdCursor& c, int slot) {
         const long kt_abs = (long)c.z * nt + c.kt;
         vc_bf16* st = lds + slot * GD_STAGE_ELEMS;
         // the tile's 128 bias values: issued AHEAD of the item's first stage, so the wait that retires that stage covers them
-        if (use_bias && c.kt == 0 && wave == 0 && lane < GD_BN / 4) vc_dma16(p.bias + c.tn * GD_BN + lane * 4, bias_lds + (c.seq & 1) * GD_BN);
-        gd_issue<NPA>(Ag + kt_abs * kstepA, offA, st, wave * NPA);
-        gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS, wave * NPB);
+        if (use_bias && c.kt == 0 && wq == 0 && lane < GD_BN / 4) vc_dma16(p.bias + c.tn * GD_BN + lane * 4, bias_lds + (c.seq % 3) * GD_BN);
+        gd_issue<NPA>(Ag + kt_abs * kstepA, offA, st, wq * NPA);
+        gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS, wq * NPB);
     };
 
     GdCursor pf{first, 0, 1, 0, 0, 0, 0};
     if (first < last) { locate(pf); retarget(pf); }
     GdCursor cp = pf;
-    int ahead = 0;                                               // stages issued and not yet consumed
-    for (; ahead < GD_STAGES - 1 && pf.item < last; ++ahead) { issue(pf, ahead); if (advance(pf) && pf.item < last) retarget(pf); }
+    int turn = 0;                                                // parity of the stage being consumed == the group that issued it
+    for (int s0 = 0; s0 < GD_STAGES - 1 && pf.item < last; ++s0) { if (grp == (s0 & 1)) issue(pf, s0); if (advance(pf) && pf.item < last) retarget(pf); }
 
     vc_f32x16 acc[2][2];
     int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
@@ -185,15 +189,15 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
 
     // One k-tile: retire stage `slot`, re-arm the slot freed by the previous k-tile, feed the matrix cores.
     // Every instruction here is paid 300+ times per launch by every wave (a wave issues one instruction per ~4 cycles, a
-    // taken branch costs ~5 of those), so the body is kept to: wait, barrier, 6 DMA issues, 16 ds_read, 16 MFMA.
+    // taken branch costs ~5 of those), so the body is kept to: wait, barrier, (every other k-tile) 12 DMA issues, 16 ds_read, 16 MFMA.
     auto ktile_begin = [&]() {
         // stage `slot` must have landed.  VMEM retires in issue order on gfx9, so "at most N outstanding" with N = the number
         // of operations issued AFTER this stage's DMA — the younger stage's pieces and the epilogue stores of the last two
         // k-tiles — is exact: neither the prefetch nor the stores are waited for.  N must never over-count (the stage itself
         // could still be in flight), so only guaranteed stores (interior tile, the C quads) are counted.
-        const int young = young_prev + young_cur;
-        if (young == 0) { if (ahead >= 2) vc_wait_vmcnt<GD_PW>(); else vc_wait_vmcnt<0>(); }
-        else gd_wait_le((ahead >= 2 ? GD_PW : 0) + young);
+        // (a wave only ever waits for the stages its own group issued: on its turn the stage being consumed is its oldest DMA
+        // and nothing younger of its own is in flight yet — the stage after next is issued below, after the barrier)
+        if (grp == turn) gd_wait_le(young_prev + young_cur);
         young_prev = young_cur; young_cur = 0;
         vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
     };
@@ -203,9 +207,10 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     // 1024-cycle MFMA phase — is what this tile shape saturates first; see DESIGN.md.)
     auto ktile_prefetch = [&]() {
         if (pf.item < last) {
-            issue(pf, slot == 0 ? GD_STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
+            if (grp == turn) issue(pf, slot == 0 ? GD_STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
             if (advance(pf) && pf.item < last) retarget(pf);
-        } else --ahead;
+        }
+        turn ^= 1;
     };
     auto ktile_mfma = [&]() {
         const vc_bf16* a_tile = lds + slot * GD_STAGE_ELEMS;
@@ -280,7 +285,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
             }
         }
         ktile_prefetch();
-        const float* brow = bias_lds + (cp.seq & 1) * GD_BN + wn * 64 + 4 * (lane >> 5);
+        const float* brow = bias_lds + (cp.seq % 3) * GD_BN + wn * 64 + 4 * (lane >> 5);
         ktile_mfma();
 
         // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3

@@ -272,3 +272,19 @@ VC_KERNEL __launch_bounds__(256) void cast_kernel(const float* x, TY* y, long n)
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     for (int j = 0; j < 4; ++j) if (i + j < n) vc_st(y + i + j, x[i + j]);
 }
+
+// ---- dst[c][r] = src[r][c] (bf16): the transposed weight shadows of the frame ViT (engine.hip: wT); 32x32 tiles through LDS
+VC_KERNEL __launch_bounds__(256) void transpose_bf16_kernel(const vc_bf16* src, vc_bf16* dst, int rows, int cols) {
+    VC_SHARED uint16_t tile[32 * 33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j * 33 + tx] = (r < rows && c < cols) ? src[(long)r * cols + c].bits : (uint16_t)0;
+    }
+    vc_sync();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) dst[(long)c * rows + r].bits = tile[tx * 33 + j];
+    }
+}

@@ -27,6 +27,7 @@ const char* vc_get_error();
 struct GemmCall {
     int ct, sa, sb, to;         // compute / A-source / B-source / output dtypes
     int tra, trb;
+    int role;                   // profiler category: 0 = infer from the layout, else VC_CAT_GEMM_* + 1 (a dgrad through W^T has the forward's layout)
     GemmParams p;               // vecA/vecB/k_per_split/partial are filled by vc_gemm
 };
 // scratch: fp32 workspace for split-K partial slabs (may be null -> no split)
@@ -49,6 +50,7 @@ int vc_embed_action(int ty, const float* a, const float* W, const float* b, cons
 int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s);
 int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s);
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
+int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]
 
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s);
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s);

@@ -128,6 +128,11 @@ int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
     return VC_OK;
 }
 
+int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s) {
+    VC_LAUNCH(transpose_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(cols, 32), (unsigned)VC_CEIL_DIV(rows, 32)), dim3(256), 0, s, src, dst, rows, cols);
+    return VC_OK;
+}
+
 int vc_loss_fwd(LossParams p, vc_stream_t s) {
     ProfScope ps(VC_CAT_LOSS, 0, (double)p.M * (VC_NPARAM * VC_NVAL + VC_NCMD) * 4, s);
     VC_LAUNCH(loss_rows_kernel, dim3((unsigned)VC_CEIL_DIV(p.M * VC_NPARAM, 4)), dim3(256), 0, s, p);
