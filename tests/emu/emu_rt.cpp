@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 #include <stdint.h>
 
@@ -201,9 +202,10 @@ void mfma_32x32x2_f32(float a, float b, float* c16) {
     wave_sync();
 }
 
-void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem) {
+// Blocks of a launch are independent (the kernels use no inter-block communication), so they are spread over a few host
+// threads; every thread owns its BlockState, fiber stacks and — VC_SHARED being `static thread_local` — its own LDS image.
+static void run_blocks(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem, unsigned first, unsigned stride) {
     int nthreads = block.x * block.y * block.z;
-    if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size %d not a multiple of 64\n", nthreads); abort(); }
     BlockState bs;
     bs.tramp = trampoline; bs.args = args;
     bs.fibers.resize(nthreads);
@@ -211,9 +213,9 @@ void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t
     bs.dyn.resize(shmem + 64);
     for (auto& f : bs.fibers) f.stack = (char*)malloc(kStack);
     g_bs = &bs;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
+    const unsigned total = grid.x * grid.y * grid.z;
+    for (unsigned bi = first; bi < total; bi += stride) {
+        const unsigned bx = bi % grid.x, by = (bi / grid.x) % grid.y, bz = bi / (grid.x * grid.y);
         bs.alive = nthreads; bs.bar_arrived = 0; bs.bar_gen = 0;
         for (auto& w : bs.waves) { w.arrived = 0; w.gen = 0; w.alive = 64; }
         for (int t = 0; t < nthreads; ++t) {
@@ -236,9 +238,8 @@ void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t
             makecontext(&f.uc, (void (*)())fiber_main, 0);
 #endif
         }
-        int idle_rounds = 0;
+        long idle_rounds = 0;
         while (bs.alive > 0) {
-            int before = bs.alive;
             for (int t = 0; t < nthreads; ++t) {
                 if (bs.fibers[t].done) continue;
                 bs.cur = t;
@@ -248,12 +249,28 @@ void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t
                 swapcontext(&bs.sched, &bs.fibers[t].uc);
 #endif
             }
-            (void)before;
             if (++idle_rounds > 100000000) { fprintf(stderr, "emu: deadlock?\n"); abort(); }
         }
     }
     for (auto& f : bs.fibers) free(f.stack);
     g_bs = nullptr;
+}
+
+void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem) {
+    int nthreads = block.x * block.y * block.z;
+    if (nthreads % 64 != 0) { fprintf(stderr, "emu: block size %d not a multiple of 64\n", nthreads); abort(); }
+    const unsigned total = grid.x * grid.y * grid.z;
+    static const unsigned hw = [] {
+        const char* e = getenv("VCEMU_THREADS");
+        unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        return n < 1 ? 1u : (n > 8 ? 8u : n);
+    }();
+    const unsigned nt = total < hw ? total : hw;
+    if (nt <= 1) { run_blocks(trampoline, args, grid, block, shmem, 0, 1); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(run_blocks, trampoline, args, grid, block, shmem, t, nt);
+    run_blocks(trampoline, args, grid, block, shmem, 0, nt);
+    for (auto& th : pool) th.join();
 }
 
 }  // namespace vcemu
