@@ -45,7 +45,9 @@ struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w
 struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo; };
 struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e; };
 struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* st1; float* x1; void* q_c; void* kv_c; float* lse_c; void* ao_c;
-                      float* s2; float* st2; float* x2; void* f1; float* s3; float* st3; float* x3; };
+                      float* s2; float* st2; float* x2; void* f1; float* s3; float* st3; float* x3;
+                      // per-layer homes of the backward's dY tensors, so the layer's 7 weight gradients can be deferred (see Deferred)
+                      void *g_du_ff, *g_df1, *g_du_ca, *g_dq, *g_dkv, *g_du_sa, *g_dqkv; };
 
 }  // namespace
 
@@ -79,6 +81,16 @@ struct vcad_engine {
     // (ds_read_b128) GEMM instead of a ds_read_b64_tr_b16 one (measured: dqkv dgrad 569 -> 462 us); refreshed lazily after
     // every weight change (optimizer step / shadow sync / re-plan)
     vc_bf16* wT = nullptr; bool wT_fresh = false; std::vector<TransposeJob> wT_jobs;
+    // Train mode: the decoder's 56 weight gradients (each a ~25-40 us launch on 2 080 rows) and their 56 bias column sums are
+    // DEFERRED to the end of the decoder backward and run as two grouped GEMM grids + one grouped column-sum — their dY inputs
+    // live in per-layer buffers instead of shared temporaries.  Descriptor tables are built on first use (they hold pointers
+    // into the bound gradient buffer and the planned workspace).
+    struct Deferred {
+        std::vector<GemmCall> calls[2]; GemmParams* d_probs[2] = {nullptr, nullptr}; int* d_tiles[2] = {nullptr, nullptr};
+        int total_tiles[2] = {0, 0}; double flops[2] = {0, 0};
+        std::vector<ColsumJob> cs; ColsumJob* d_cs = nullptr; float* cs_partial = nullptr; int cs_strips = 0, cs_chunks = 0;
+        bool ready = false;
+    } def;
 };
 
 namespace {
@@ -205,6 +217,15 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         d.q_c = b.take<void>(M * H * es); d.kv_c = b.take<void>(M * 2 * H * es); d.lse_c = b.take<float>((long)B * c.nhead * T * 4);
         d.ao_c = b.take<void>(M * H * es); d.s2 = b.take<float>(M * H * 4); d.st2 = b.take<float>(M * 2 * 4); d.x2 = b.take<float>(M * H * 4);
         d.f1 = b.take<void>(M * c.dim_feedforward * es); d.s3 = b.take<float>(M * H * 4); d.st3 = b.take<float>(M * 2 * 4); d.x3 = b.take<float>(M * H * 4);
+        d.g_du_ff = b.take<void>(M * H * es); d.g_df1 = b.take<void>(M * c.dim_feedforward * es); d.g_du_ca = b.take<void>(M * H * es);
+        d.g_dq = b.take<void>(M * H * es); d.g_dkv = b.take<void>(M * 2 * H * es); d.g_du_sa = b.take<void>(M * H * es); d.g_dqkv = b.take<void>(M * 3 * H * es);
+    }
+    {   // deferred-wgrad descriptor tables (device) + column-sum partials
+        const int nl = c.num_decoder_layers;
+        for (int g = 0; g < 2; ++g) { e->def.d_probs[g] = b.take<GemmParams>((size_t)nl * 4 * sizeof(GemmParams)); e->def.d_tiles[g] = b.take<int>((size_t)(nl * 4 + 1) * 4); }
+        e->def.d_cs = b.take<ColsumJob>((size_t)nl * 7 * sizeof(ColsumJob));
+        e->def.cs_partial = b.take<float>((size_t)nl * (VC_CEIL_DIV(M, 128) + 1) * (7L * H + 2L * H + c.dim_feedforward) * 4);
+        e->def.ready = false;
     }
     // backward temporaries (ViT ones sized for the frame ViT, shared with the CAD ViT)
     const long R = M * (P + 1), Rp = M * P;
@@ -276,10 +297,11 @@ struct Ctx {
         return d;
     }
     // masked copy of a residual-stream gradient: du = dx * mask (type T, compact [rows, cols]); returns the matrix to feed wgrad / dgrad
-    int masked(const float* dx, long ldx, long rows, int cols, vc_drop d, Mat* out) const {
+    int masked(const float* dx, long ldx, long rows, int cols, vc_drop d, Mat* out, void* dst = nullptr) const {
         if (!d.key) { *out = A32(dx, ldx); return 0; }
-        *out = AT(e->t_dum, cols);
-        return vc_dropout_mul(e->dt, dx, ldx, e->t_dum, cols, rows, cols, d, s);
+        if (!dst) dst = e->t_dum;
+        *out = AT(dst, cols);
+        return vc_dropout_mul(e->dt, dx, ldx, dst, cols, rows, cols, d, s);
     }
     int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep, int role = 0) const {
         GemmCall c; memset(&c, 0, sizeof(c));
@@ -537,6 +559,51 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
 }
 
 // stage 0: heads + decoder + stem (bucket 0).  Leaves d(cls_state) in t_des and d(cls_cad) in t_dec.
+// Descriptor tables of the deferred decoder weight gradients (vcad_engine::Deferred): group 0 = activations kept in the
+// compute dtype (f1, ao_c, ao_s), group 1 = fp32 residual-stream inputs (x2, x1, memory, layer input).
+int build_deferred(const Ctx& cx, const float* tgt0) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c;
+    const int H = c.hidden_size, ff = c.dim_feedforward; const long M = (long)e->B * e->T;
+    vcad_engine::Deferred& df = e->def;
+    df.calls[0].clear(); df.calls[1].clear(); df.cs.clear();
+    auto add = [&](int g, Mat dY, Mat X, long w_off, long lddw, long b_off, int N, int K) {
+        GemmCall gc; memset(&gc, 0, sizeof(gc));
+        gc.ct = e->dt; gc.sa = dY.dt; gc.sb = X.dt; gc.to = VC_F32; gc.tra = 1; gc.trb = 1;
+        GemmParams& p = gc.p;
+        p.A = dY.p; p.B = X.p; p.C = (void*)cx.Gf(w_off); p.M = N; p.N = K; p.K = (int)M; p.lda = dY.ld; p.ldb = X.ld; p.ldc = lddw; p.alpha = 1.0f;
+        df.calls[g].push_back(gc);
+        ColsumJob j; memset(&j, 0, sizeof(j));
+        j.x = dY.p; j.ld = dY.ld; j.rows = (int)M; j.cols = N; j.out = cx.Gf(b_off); j.is_bf16 = dY.dt == VC_BF16;
+        df.cs.push_back(j);
+    };
+    for (int L = 0; L < c.num_decoder_layers; ++L) {
+        const DecW& w = e->wd[L]; const DecLayerActs& d = e->da[L];
+        const float* xin = L == 0 ? tgt0 : e->da[L - 1].x3;
+        add(0, cx.AT(d.g_du_ff, H), cx.AT(d.f1, ff), w.w2, ff, w.b2, H, ff);
+        add(1, cx.AT(d.g_df1, ff), cx.A32(d.x2, H), w.w1, H, w.b1, ff, H);
+        add(0, cx.AT(d.g_du_ca, H), cx.AT(d.ao_c, H), w.ca_ow, H, w.ca_ob, H, H);
+        add(1, cx.AT(d.g_dq, H), cx.A32(d.x1, H), w.ca_w, H, w.ca_b, H, H);
+        add(1, cx.AT(d.g_dkv, 2 * H), cx.A32(e->mem, H), w.ca_w + (long)H * H, H, w.ca_b + H, 2 * H, H);
+        add(0, cx.AT(d.g_du_sa, H), cx.AT(d.ao_s, H), w.sa_ow, H, w.sa_ob, H, H);
+        add(1, cx.AT(d.g_dqkv, 3 * H), cx.A32(xin, H), w.sa_w, H, w.sa_b, 3 * H, H);
+    }
+    for (int g = 0; g < 2; ++g) {
+        const int n = (int)df.calls[g].size();
+        std::vector<GemmParams> probs(n); std::vector<int> tiles(n + 1);
+        CK(vc_gemm_grouped_prepare(df.calls[g].data(), n, probs.data(), tiles.data()));
+        df.total_tiles[g] = tiles[n]; df.flops[g] = 0;
+        for (const auto& gc : df.calls[g]) df.flops[g] += 2.0 * gc.p.M * gc.p.N * gc.p.K;
+        CK(vc_upload(df.d_probs[g], probs.data(), (size_t)n * sizeof(GemmParams), cx.s));
+        CK(vc_upload(df.d_tiles[g], tiles.data(), (size_t)(n + 1) * sizeof(int), cx.s));
+    }
+    int strips = 0; long poff = 0; const int chunks = (int)VC_CEIL_DIV(M, 128);
+    for (auto& j : df.cs) { j.strip_start = strips; j.part_off = poff; strips += VC_CEIL_DIV(j.cols, 256); poff += (long)chunks * j.cols; }
+    df.cs_strips = strips; df.cs_chunks = chunks;
+    CK(vc_upload(df.d_cs, df.cs.data(), df.cs.size() * sizeof(ColsumJob), cx.s));
+    df.ready = true;
+    return 0;
+}
+
 int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_stream_t s) {
     Ctx cx{e, s}; const vcad_config& c = e->c;
     const int B = e->B, T = e->T, H = c.hidden_size, D = c.vit_dim, ff = c.dim_feedforward; const long M = (long)B * T;
@@ -551,41 +618,53 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     CK(cx.lin_wgrad(cx.A32(dpars, n6), cx.A32(xf, H), cx.Gf(e->o_h6_w), H, cx.Gf(e->o_h6_b), (int)M, n6, H));
     CK(cx.lin_dgrad(cx.A32(dpars, n6), cx.W(e->o_h6_w, H), cx.A32(dx, H), (int)M, n6, H, Epi()));
     { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.A32(dcmds, n5), cx.W(e->o_h5_w, H), cx.A32(dx, H), (int)M, n5, H, ep)); }
+    // Train mode (every dY below is a private masked / bf16 copy): the 7 weight gradients and bias column sums of each layer are
+    // recorded, not launched — see vcad_engine::Deferred.  Eval-mode backward (p = 0: du aliases the live dx) launches them in place.
+    const bool defer = e->drop_p > 0.f;
+    if (defer && !e->def.ready) CK(build_deferred(cx, tgt0));
     for (int L = c.num_decoder_layers - 1; L >= 0; --L) {
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
         const float* xin = L == 0 ? tgt0 : e->da[L - 1].x3;
         // ---- FFN   x3 = LN3(x2 + drop(W2 drop(relu(W1 x2 + b1)) + b2))
         Mat du;
         CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H));
-        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du));
-        CK(cx.lin_wgrad(du, cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
+        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du, d.g_du_ff));
+        if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
         { Epi ep; ep.dact = d.f1; ep.lddact = ff; ep.dkind = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT);   // f1 > 0 <=> z > 0 and kept
-          CK(cx.lin_dgrad(du, cx.W(w.w2, ff), cx.AT(e->t_df1, ff), (int)M, H, ff, ep)); }
-        CK(cx.lin_wgrad(cx.AT(e->t_df1, ff), cx.A32(d.x2, H), cx.Gf(w.w1), H, cx.Gf(w.b1), (int)M, ff, H));
-        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_df1, ff), cx.W(w.w1, H), cx.A32(dx, H), (int)M, ff, H, ep)); }
+          CK(cx.lin_dgrad(du, cx.W(w.w2, ff), cx.AT(d.g_df1, ff), (int)M, H, ff, ep)); }
+        if (!defer) CK(cx.lin_wgrad(cx.AT(d.g_df1, ff), cx.A32(d.x2, H), cx.Gf(w.w1), H, cx.Gf(w.b1), (int)M, ff, H));
+        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_df1, ff), cx.W(w.w1, H), cx.A32(dx, H), (int)M, ff, H, ep)); }
         // ---- cross attention
         CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H));
-        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du));
-        CK(cx.lin_wgrad(du, cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
+        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du, d.g_du_ca));
+        if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
-        { const char* kv = (const char*)d.kv_c; char* dkv = (char*)e->t_dkv;
-          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, nullptr, d.lse_c, c.window_size, e->t_dao_d, e->t_dq, dkv, dkv + (size_t)H * es, H, 2 * H,
+        { const char* kv = (const char*)d.kv_c; char* dkv = (char*)d.g_dkv;
+          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, nullptr, d.lse_c, c.window_size, e->t_dao_d, d.g_dq, dkv, dkv + (size_t)H * es, H, 2 * H,
                       cx.site(3, L, Ctx::K_CA))); }
-        CK(cx.lin_wgrad(cx.AT(e->t_dq, H), cx.A32(d.x1, H), cx.Gf(w.ca_w), H, cx.Gf(w.ca_b), (int)M, H, H));
-        CK(cx.lin_wgrad(cx.AT(e->t_dkv, 2 * H), cx.A32(e->mem, H), cx.Gf(w.ca_w + (long)H * H), H, cx.Gf(w.ca_b + H), (int)M, 2 * H, H));
-        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dq, H), cx.W(w.ca_w, H), cx.A32(dx, H), (int)M, H, H, ep)); }
+        if (!defer) {
+            CK(cx.lin_wgrad(cx.AT(d.g_dq, H), cx.A32(d.x1, H), cx.Gf(w.ca_w), H, cx.Gf(w.ca_b), (int)M, H, H));
+            CK(cx.lin_wgrad(cx.AT(d.g_dkv, 2 * H), cx.A32(e->mem, H), cx.Gf(w.ca_w + (long)H * H), H, cx.Gf(w.ca_b + H), (int)M, 2 * H, H));
+        }
+        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_dq, H), cx.W(w.ca_w, H), cx.A32(dx, H), (int)M, H, H, ep)); }
         { Epi ep; if (L != c.num_decoder_layers - 1) { ep.residual = e->t_dmem; ep.ldr = H; }
-          CK(cx.lin_dgrad(cx.AT(e->t_dkv, 2 * H), cx.W(w.ca_w + (long)H * H, H), cx.A32(e->t_dmem, H), (int)M, 2 * H, H, ep)); }
+          CK(cx.lin_dgrad(cx.AT(d.g_dkv, 2 * H), cx.W(w.ca_w + (long)H * H, H), cx.A32(e->t_dmem, H), (int)M, 2 * H, H, ep)); }
         // ---- self attention
         CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H));
-        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du));
-        CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
+        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du, d.g_du_sa));
+        if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
-        { const char* q = (const char*)d.qkv_s; char* dq = (char*)e->t_dqkv_d;
+        { const char* q = (const char*)d.qkv_s; char* dq = (char*)d.g_dqkv;
           CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, nullptr, d.lse_s, sa_window, e->t_dao_d,
                       dq, dq + (size_t)H * es, dq + (size_t)2 * H * es, 3 * H, 3 * H, cx.site(3, L, Ctx::K_SA))); }
-        CK(cx.lin_wgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.A32(xin, H), cx.Gf(w.sa_w), H, cx.Gf(w.sa_b), (int)M, 3 * H, H));
-        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(e->t_dqkv_d, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }
+        if (!defer) CK(cx.lin_wgrad(cx.AT(d.g_dqkv, 3 * H), cx.A32(xin, H), cx.Gf(w.sa_w), H, cx.Gf(w.sa_b), (int)M, 3 * H, H));
+        { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_dqkv, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }
+    }
+    if (defer) {
+        vcad_engine::Deferred& df = e->def;
+        for (int g = 0; g < 2; ++g)
+            CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], s));
+        CK(vc_colsum_grouped(df.d_cs, (int)df.cs.size(), df.cs_strips, df.cs_chunks, df.cs_partial, s));
     }
     // ---- stem (reference model/autoregressive_transformer.py:144-178); dx = gradient of the decoder's tgt input
     float* dpre = e->t_dpre;
@@ -667,7 +746,7 @@ int vcad_bucket_range(const vcad_engine* e, int b, int64_t* begin, int64_t* end)
 int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, void* shadow) {
     if (!params) { vc_set_error("vcad_bind: params is null"); return VC_ERR_ARG; }
     if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
-    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow; e->wT_fresh = false;
+    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow; e->wT_fresh = false; e->def.ready = false;
     return 0;
 }
 int vcad_sync_shadow(vcad_engine* e, void* stream) {

@@ -320,8 +320,10 @@ VC_DEV vc_s16x8 gemm_frag_bf16(const vc_bf16* tile, int row0, int ks, int lane) 
     }
 }
 
+// The tile program.  (bid, nx, ny) = linear tile id and tile-grid extent of THIS problem, bz = k-slice — the plain kernel
+// passes its own block coordinates, the grouped kernel the position inside the problem a workgroup was assigned to.
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
-VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
+VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, const int ny, const int bz) {
     constexpr int BK = GemmCfg<CT>::BK, STRIDE = GemmCfg<CT>::STRIDE;
     constexpr int GEMM_BM = 64 * WT, GEMM_BN = 64 * WT, WS = 32 * WT;     // block tile, per-wave sub-tile
     VC_DYN_SHARED(CT, lds);
@@ -335,7 +337,7 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     // run of tiles, n fastest: the blocks that share one 128-row A panel (and sweep the small B) hit the same L2.
     int tile_m, tile_n;
     {
-        const int nx = gridDim.x, total = gridDim.x * gridDim.y, bid = blockIdx.y * gridDim.x + blockIdx.x;
+        const int total = nx * ny;
         const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any total
         tile_m = t / nx; tile_n = t - tile_m * nx;
@@ -346,12 +348,12 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
     // run their (MFMA-bound) K-loops and their (HBM-bound) epilogues in lockstep forever.  Half of the FIRST wave of blocks
     // starts ~half a tile late; the offset then persists for the rest of the launch because successors start when
     // predecessors retire.  (Pure scheduling hint: no effect on results.)
-    if (p.stagger > 0 && blockIdx.z == 0) {
-        const int bid0 = blockIdx.y * gridDim.x + blockIdx.x;
+    if (p.stagger > 0 && bz == 0) {
+        const int bid0 = bid;
         if (bid0 < 2 * 256 && ((bid0 >> 3) & 1)) for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
 #endif
-    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kbeg = bz * p.k_per_split;
     const int kend = (kbeg + p.k_per_split < p.K) ? (kbeg + p.k_per_split) : p.K;
     const int nt = (kend - kbeg + BK - 1) / BK;
 
@@ -483,11 +485,32 @@ VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.M && n < p.N) {
-                    if (p.partial) p.partial[((long)blockIdx.z * p.M + m) * p.N + n] = acc[i][j][r];
+                    if (p.partial) p.partial[((long)bz * p.M + m) * p.N + n] = acc[i][j][r];
                     else gemm_epilogue_store<TO>(p, m, n, acc[i][j][r], bias_n);
                 }
             }
     }
+}
+
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
+VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
+    gemm_tile_program<CT, SA, SB, TO, TRA, TRB, WT>(p, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
+}
+
+// Grouped launch: ONE grid over the tiles of many independent problems of the same signature (the decoder's 56 weight
+// gradients, each a ~25 us launch on its own, deferred to the end of the decoder backward).  tile_start[g] = first linear tile of
+// problem g (tile_start[n] = total); the problem descriptors live in device memory.
+struct GemmGroup { const GemmParams* probs; const int* tile_start; int n; };
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
+VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_grouped_kernel(GemmGroup grp) {
+    const int t = blockIdx.x;
+    int g = 0;
+    while (g + 1 < grp.n && grp.tile_start[g + 1] <= t) ++g;                    // n is a few dozen; wave-uniform scalar loop
+    const GemmParams p = grp.probs[g];
+    constexpr int BT = 64 * WT;
+    const int nx = (p.N + BT - 1) / BT, ny = (p.M + BT - 1) / BT;
+    if (t - grp.tile_start[g] >= nx * ny) return;                               // padding up to a multiple of 8 tiles
+    gemm_tile_program<CT, SA, SB, TO, TRA, TRB, WT>(p, t - grp.tile_start[g], nx, ny, 0);
 }
 
 // split-K reducer: sums the fp32 partial slabs in a fixed order (deterministic) and runs the epilogue.

@@ -288,3 +288,43 @@ VC_KERNEL __launch_bounds__(256) void transpose_bf16_kernel(const vc_bf16* src, 
         if (r < rows && c < cols) dst[(long)c * rows + r].bits = tile[tx * 33 + j];
     }
 }
+
+// ---- grouped column sums (the decoder's deferred bias gradients): one grid over the 256-column strips of many jobs.
+// pass 0: partial[job.part_off + chunk * cols + c] = sum of rows [128 chunk, 128 chunk + 128);  pass 1: out[c] = sum over chunks
+// (fixed order: deterministic).  Jobs live in device memory; strip_start[j] = first strip of job j.
+struct ColsumJob { const void* x; long ld; int rows, cols; float* out; int is_bf16; int strip_start; long part_off; };
+VC_KERNEL __launch_bounds__(256) void colsum_grouped_kernel(const ColsumJob* jobs, int njobs, float* partial, int pass) {
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].strip_start <= (int)blockIdx.x) ++j;
+    const ColsumJob job = jobs[j];
+    const int c = ((int)blockIdx.x - job.strip_start) * 256 + threadIdx.x;
+    if (c >= job.cols) return;
+    const int nchunk = (job.rows + 127) / 128;
+    if (pass == 0) {
+        const int chunk = blockIdx.y;
+        if (chunk >= nchunk) return;
+        long r0 = (long)chunk * 128, r1 = r0 + 128; if (r1 > job.rows) r1 = job.rows;
+        float s = 0.f;
+        long r = r0;
+        if (job.is_bf16) {
+            const vc_bf16* x = (const vc_bf16*)job.x;
+            for (; r + 8 <= r1; r += 8) { float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = vc_ld(x + (r + u) * job.ld + c);
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+            for (; r < r1; ++r) s += vc_ld(x + r * job.ld + c);
+        } else {
+            const float* x = (const float*)job.x;
+            for (; r + 8 <= r1; r += 8) { float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[(r + u) * job.ld + c];
+                s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); }
+            for (; r < r1; ++r) s += x[r * job.ld + c];
+        }
+        partial[job.part_off + (long)chunk * job.cols + c] = s;
+    } else {
+        float s = 0.f;
+        for (int k = 0; k < nchunk; ++k) s += partial[job.part_off + (long)k * job.cols + c];
+        job.out[c] = s;
+    }
+}

@@ -32,6 +32,9 @@ struct GemmCall {
 };
 // scratch: fp32 workspace for split-K partial slabs (may be null -> no split)
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s);
+// grouped launch of many same-signature problems in one grid (see ops_gemm.hip)
+int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start);
+int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s);
 
 int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s);
 // partial_ws: >= ln_bwd_blocks(rows) * 2 * C floats; dgamma/dbeta written (not accumulated)
@@ -50,6 +53,8 @@ int vc_embed_action(int ty, const float* a, const float* W, const float* b, cons
 int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s);
 int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s);
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
+// grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
+int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]
 
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s);

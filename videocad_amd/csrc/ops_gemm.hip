@@ -108,7 +108,8 @@ extern "C" void vcad_debug_force_gemm_tile(int tile) { g_force_tile = (tile == 6
 
 static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
 
-int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
+// validation + the per-problem flags every kernel expects (activation remap, 16-byte legality of each operand)
+static int gemm_prepare(GemmCall& c) {
     GemmParams& p = c.p;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
     if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
@@ -128,6 +129,12 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if (eo == 2) p.vecC = p.vecC && ((uintptr_t)p.C % 8 == 0);
     }
     if (g_debug_skip & 16) p.vecC = 0;          // ablation: register-direct epilogue
+    return VC_OK;
+}
+
+int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
+    { int rc = gemm_prepare(c); if (rc) return rc; }
+    GemmParams& p = c.p;
     const int lay = c.tra * 2 + c.trb;
     // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad)
     if (c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && lay != 2 && g_dma_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
@@ -201,4 +208,53 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
 #undef G
     vc_set_error("vc_gemm: unsupported combination ct=%d sa=%d sb=%d to=%d tra=%d trb=%d", c.ct, c.sa, c.sb, c.to, c.tra, c.trb);
     return VC_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------- grouped launch
+// Host half: fills `probs` (device-layout descriptors) and `tile_start` (n + 1 entries, every problem padded to a multiple
+// of 8 tiles so the XCD-aware order inside a problem lines up with the hardware's round-robin); all problems must share the
+// first one's signature.  The caller uploads both arrays to device memory once per plan and launches every step.
+int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start) {
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmCall& c = calls[i];
+        if (c.ct != calls[0].ct || c.sa != calls[0].sa || c.sb != calls[0].sb || c.to != calls[0].to || c.tra != calls[0].tra || c.trb != calls[0].trb) {
+            vc_set_error("vc_gemm_grouped: mixed signatures"); return VC_ERR_ARG;
+        }
+        int rc = gemm_prepare(c); if (rc) return rc;
+        c.p.k_per_split = VC_CEIL_DIV(c.p.K, 64) * 64; c.p.partial = nullptr; c.p.stagger = 0; c.p.debug_skip = 0;
+        probs[i] = c.p; tile_start[i] = t;
+        t += VC_CEIL_DIV(VC_CEIL_DIV(c.p.M, 128) * VC_CEIL_DIV(c.p.N, 128), 8) * 8;
+    }
+    tile_start[n] = t;
+    return VC_OK;
+}
+
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
+static int grouped_launch(const GemmCall& sig, GemmGroup grp, int total_tiles, double flops, vc_stream_t s) {
+    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB, 2>();
+#ifndef VC_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+        attr_set = true;
+    }
+#endif
+    ProfScope ps(sig.role ? sig.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), flops, 0.0, s);
+    VC_LAUNCH((gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>), dim3((unsigned)total_tiles), dim3(GEMM_THREADS), lds, s, grp);
+    return VC_OK;
+}
+
+// Device half: probs / tile_start are DEVICE pointers holding what vc_gemm_grouped_prepare produced.  Only the wgrad layout
+// (tra = trb = 1, fp32 output) is instantiated — that is what the engine defers.
+int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s) {
+    if (n <= 0) return VC_OK;
+    GemmGroup grp{probs, tile_start, n};
+    if (!(sig.tra && sig.trb) || sig.to != VC_F32) { vc_set_error("vc_gemm_grouped: only the wgrad layout is instantiated"); return VC_ERR_UNSUPPORTED; }
+    if (sig.ct == VC_F32) return grouped_launch<float, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.sa == VC_BF16 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, vc_bf16, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.sa == VC_BF16 && sig.sb == VC_F32) return grouped_launch<vc_bf16, vc_bf16, float, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.sa == VC_F32 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, float, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
+    return grouped_launch<vc_bf16, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
 }

@@ -128,6 +128,13 @@ int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
     return VC_OK;
 }
 
+int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s) {
+    if (njobs <= 0) return VC_OK;
+    ProfScope ps(VC_CAT_OTHER, 0, 0, s);
+    VC_LAUNCH(colsum_grouped_kernel, dim3((unsigned)strips, (unsigned)max_chunks), dim3(256), 0, s, jobs, njobs, partial, 0);
+    VC_LAUNCH(colsum_grouped_kernel, dim3((unsigned)strips, 1), dim3(256), 0, s, jobs, njobs, partial, 1);
+    return VC_OK;
+}
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s) {
     VC_LAUNCH(transpose_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(cols, 32), (unsigned)VC_CEIL_DIV(rows, 32)), dim3(256), 0, s, src, dst, rows, cols);
     return VC_OK;

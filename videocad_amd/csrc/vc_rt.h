@@ -26,6 +26,8 @@ typedef hipStream_t vc_stream_t;
 
 static inline int vc_memset_async(void* p, int v, size_t n, vc_stream_t s) { return (int)hipMemsetAsync(p, v, n, s); }
 static inline int vc_memcpy_d2d_async(void* d, const void* s_, size_t n, vc_stream_t s) { return (int)hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
+// small host -> device table upload, ordered on the stream; the (pageable) host buffer may be reused when it returns
+static inline int vc_upload(void* d, const void* h, size_t n, vc_stream_t s) { int rc = (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); return rc ? rc : (int)hipStreamSynchronize(s); }
 static inline int vc_last_launch_error() { return (int)hipGetLastError(); }
 
 VC_DEV void vc_sync() { __syncthreads(); }
@@ -121,6 +123,7 @@ void launch_k(void (*k)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... 
 
 static inline int vc_memset_async(void* p, int v, size_t n, vc_stream_t) { memset(p, v, n); return 0; }
 static inline int vc_memcpy_d2d_async(void* d, const void* s_, size_t n, vc_stream_t) { memmove(d, s_, n); return 0; }
+static inline int vc_upload(void* d, const void* h, size_t n, vc_stream_t) { memcpy(d, h, n); return 0; }
 static inline int vc_last_launch_error() { return 0; }
 
 VC_DEV void vc_sync() { vcemu::sync_block(); }
