@@ -42,6 +42,11 @@ struct VitW {       // float offsets into the flat buffer
 };
 struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w2, b2, n1w, n1b, n2w, n2b, n3w, n3b; };
 
+// Scratch and ViT-backward temporaries exist twice: lane 0 = the caller's stream (frame ViT, decoder), lane 1 = the side stream the
+// CAD ViT (32 images: ~230 launch-bound kernels, 6 % of a step when serialised) runs on concurrently with the frame ViT.
+struct Lane { float* scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
+              float *t_dx, *t_dpe; void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_dum; float* t_delta; };
+
 struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo; };
 struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e; };
 struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* st1; float* x1; void* q_c; void* kv_c; float* lse_c; void* ao_c;
@@ -68,15 +73,14 @@ struct vcad_engine {
     float *ui, *cadterm, *mem, *act; void* cadE;
     float *xfinal;                // = da.back().x3
     // backward temporaries
-    float *t_dx, *t_dpe, *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
-    void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_df1, *t_dq, *t_dkv, *t_dao_d, *t_dqkv_d;
-    float *t_delta;
-    // scratch
-    float *scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
+    float *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
+    void *t_df1, *t_dq, *t_dkv, *t_dao_d, *t_dqkv_d;
+    Lane lane[2];                 // scratch + ViT-backward temporaries per stream (see Lane)
+    vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false;
     float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
-    float drop_p = 0.f; uint64_t drop_seed = 0; void* t_dum = nullptr;
+    float drop_p = 0.f; uint64_t drop_seed = 0;
     // bf16 mode: transposed copies W^T[in][out] of the frame ViT's Linear weights, so every big dgrad is a k-contiguous
     // (ds_read_b128) GEMM instead of a ds_read_b64_tr_b16 one (measured: dqkv dgrad 569 -> 462 us); refreshed lazily after
     // every weight change (optimizer step / shadow sync / re-plan)
@@ -227,23 +231,26 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         e->def.cs_partial = b.take<float>((size_t)nl * (VC_CEIL_DIV(M, 128) + 1) * (7L * H + 2L * H + c.dim_feedforward) * 4);
         e->def.ready = false;
     }
-    // backward temporaries (ViT ones sized for the frame ViT, shared with the CAD ViT)
-    const long R = M * (P + 1), Rp = M * P;
-    e->t_dx = b.take<float>(R * D * 4); e->t_dpe = b.take<float>(Rp * D * 4); e->t_dz = b.take<void>(R * c.vit_mlp * es);
-    e->t_dh = b.take<void>(R * D * es); e->t_dao = b.take<void>(R * inner * es); e->t_dqkv = b.take<void>(R * 3 * inner * es);
-    e->t_dpn = b.take<void>(Rp * pd * es);
-    e->t_dum = b.take<void>((R * D > M * H ? R * D : M * H) * 4);
-    long dmax = (long)B * c.nhead * T; long vmax = M * c.vit_heads * (P + 1);
-    e->t_delta = b.take<float>((dmax > vmax ? dmax : vmax) * 4);
+    // backward temporaries + scratch, per lane: lane 0 (caller's stream) sized for the frame ViT / decoder, lane 1 (side stream) for the CAD ViT
+    for (int ln = 0; ln < 2; ++ln) {
+        Lane& l = e->lane[ln];
+        const long Nv = ln == 0 ? M : (long)B;                       // images this lane's ViT sees
+        const long R = Nv * (P + 1), Rp = Nv * P;
+        l.t_dx = b.take<float>(R * D * 4); l.t_dpe = b.take<float>(Rp * D * 4); l.t_dz = b.take<void>(R * c.vit_mlp * es);
+        l.t_dh = b.take<void>(R * D * es); l.t_dao = b.take<void>(R * inner * es); l.t_dqkv = b.take<void>(R * 3 * inner * es);
+        l.t_dpn = b.take<void>(Rp * pd * es);
+        l.t_dum = b.take<void>((R * D > M * H ? R * D : M * H) * 4);
+        const long dmax = (long)B * c.nhead * T, vmax = Nv * c.vit_heads * (P + 1);
+        l.t_delta = b.take<float>((dmax > vmax ? dmax : vmax) * 4);
+        l.scr_splitk_bytes = 64ul << 20; l.scr_splitk = b.take<float>(l.scr_splitk_bytes);
+        l.scr_colsum_bytes = (ln == 0 ? 64ul : 16ul) << 20; l.scr_colsum = b.take<float>(l.scr_colsum_bytes);
+        l.scr_lnpart_bytes = 1024ul * 2 * 1024 * 4; l.scr_lnpart = b.take<float>(l.scr_lnpart_bytes);
+    }
     e->t_dmem = b.take<float>(M * H * 4); e->t_dcur = b.take<float>(M * H * 4); e->t_dui = b.take<float>(M * H * 4); e->t_dpre = b.take<float>(M * H * 4);
     e->t_dcadterm = b.take<float>((long)B * H * 4); e->t_dcadE = b.take<float>((long)B * H * 4);
     e->t_dec = b.take<float>((long)B * D * 4); e->t_des = b.take<float>(M * D * 4);
     e->t_df1 = b.take<void>(M * c.dim_feedforward * es); e->t_dq = b.take<void>(M * H * es); e->t_dkv = b.take<void>(M * 2 * H * es);
     e->t_dao_d = b.take<void>(M * H * es); e->t_dqkv_d = b.take<void>(M * 3 * H * es);
-    // scratch
-    e->scr_splitk_bytes = 64ul << 20; e->scr_splitk = b.take<float>(e->scr_splitk_bytes);
-    e->scr_colsum_bytes = 64ul << 20; e->scr_colsum = b.take<float>(e->scr_colsum_bytes);
-    e->scr_lnpart_bytes = 1024ul * 2 * 1024 * 4; e->scr_lnpart = b.take<float>(e->scr_lnpart_bytes);
     e->loss_rows = b.take<float>(M * 7 * 3 * 4); e->loss_arg = b.take<int>(M * 7 * 4);
     e->loss_small = b.take<float>(64 * 4); e->loss_metrics = b.take<int>(VC_NMETRIC * 4);
     const long nlog = (long)c.num_params * c.num_params_values;
@@ -267,7 +274,8 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 struct Ctx {
-    vcad_engine* e; vc_stream_t s;
+    vcad_engine* e; vc_stream_t s; int ln = 0;       // ln: which Lane's scratch / temporaries this context may touch
+    const Lane& L() const { return e->lane[ln]; }
     int dt() const { return e->dt; }
     Mat W(long off, long ld) const { return e->dt == VC_BF16 ? Mat{(const void*)(e->S + off), VC_BF16, ld} : Mat{(const void*)(e->P + off), VC_F32, ld}; }
     // transposed shadow (bf16 mode, frame ViT): offT < 0 -> not available
@@ -299,7 +307,7 @@ struct Ctx {
     // masked copy of a residual-stream gradient: du = dx * mask (type T, compact [rows, cols]); returns the matrix to feed wgrad / dgrad
     int masked(const float* dx, long ldx, long rows, int cols, vc_drop d, Mat* out, void* dst = nullptr) const {
         if (!d.key) { *out = A32(dx, ldx); return 0; }
-        if (!dst) dst = e->t_dum;
+        if (!dst) dst = L().t_dum;
         *out = AT(dst, cols);
         return vc_dropout_mul(e->dt, dx, ldx, dst, cols, rows, cols, d, s);
     }
@@ -311,7 +319,7 @@ struct Ctx {
         p.alpha = 1.0f; p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr;
         p.rowadd = ep.rowadd; p.rowadd_div = ep.rdiv; p.rowadd_mod = ep.rmod; p.ld_rowadd = ep.ldrow;
         p.aux = ep.aux; p.ldaux = ep.ldaux; p.dact_src = ep.dact; p.lddact = ep.lddact; p.dact_kind = ep.dkind; p.drop = ep.drop;
-        return vc_gemm(c, e->scr_splitk, e->scr_splitk_bytes, s);
+        return vc_gemm(c, L().scr_splitk, L().scr_splitk_bytes, s);
     }
     // Y[M,N] = X[M,K] W[N,K]^T (+ epilogue)
     int lin_fwd(Mat X, Mat Wm, Mat Y, int M, int N, int K, const Epi& ep) const { return gemm(X, 0, Wm, 0, Y, M, N, K, ep); }
@@ -325,8 +333,8 @@ struct Ctx {
     }
     int colsum(Mat X, long rows, int cols, float* out, int accumulate, int batch = 1, long bsx = 0, long bso = 0) const {
         size_t need = (size_t)batch * vc_colsum_chunks(rows) * cols * 4;      // both tree levels
-        if (need > e->scr_colsum_bytes) { vc_set_error("colsum scratch too small (%zu)", need); return VC_ERR_WORKSPACE; }
-        return vc_colsum(X.dt, X.p, X.ld, rows, cols, out, accumulate, batch, bsx, bso, e->scr_colsum, s);
+        if (need > L().scr_colsum_bytes) { vc_set_error("colsum scratch too small (%zu)", need); return VC_ERR_WORKSPACE; }
+        return vc_colsum(X.dt, X.p, X.ld, rows, cols, out, accumulate, batch, bsx, bso, L().scr_colsum, s);
     }
     int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C) const {
         LnFwdParams p; memset(&p, 0, sizeof(p));
@@ -340,9 +348,19 @@ struct Ctx {
         LnBwdParams p; memset(&p, 0, sizeof(p));
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
-        return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, e->scr_lnpart, Gf(wo), Gf(bo), e->scr_colsum, s);
+        return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s);
     }
 };
+
+// The side stream of lane 1 (created on first use).  Without one (CPU emulator) the CAD ViT simply runs in line.
+bool ensure_side(vcad_engine* e) {
+    if (!vc_has_side_streams() || e->no_side || vc_profile_on()) return false;
+    if (!e->side_ok) {
+        if (vc_stream_create(&e->side) || vc_event_create(&e->ev_fork) || vc_event_create(&e->ev_join)) return false;
+        e->side_ok = true;
+    }
+    return true;
+}
 
 int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bstride) {
     vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
@@ -412,7 +430,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
     vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
     const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
     const long N = a.N, R = N * (P + 1), Rp = N * P;
-    float* dx = e->t_dx;
+    float* dx = cx.L().t_dx;
     if (v == 0) CK(cx.refresh_wT());
     const int split = c.vit_depth / 2;
     int Lhi = c.vit_depth - 1, Llo = 0;
@@ -434,36 +452,36 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));
         CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
-          if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep));
-          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(e->t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
-        CK(cx.lin_wgrad(cx.AT(e->t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
-        if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(e->t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
-        else CK(cx.lin_dgrad(cx.AT(e->t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(e->t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
-        CK(cx.ln_bwd(e->dt, e->t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D));
+          if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep));
+          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
+        CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
+        if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
+        else CK(cx.lin_dgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D));
         // attention block (xm = x + drop(Wo ao + bo))
         CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du));
         CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
-        if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
-        else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(e->t_dao, inner), (int)Rm, D, inner, Epi()));
+        if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
+        else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         {
             AttnParams p; memset(&p, 0, sizeof(p));
-            const char* q = (const char*)l.qkv; char* dq = (char*)e->t_dqkv;
+            const char* q = (const char*)l.qkv; char* dq = (char*)cx.L().t_dqkv;
             p.q = q; p.k = q + (size_t)inner * e->esz; p.v = q + (size_t)2 * inner * e->esz;
-            p.ldq = p.ldk = p.ldv = 3 * inner; p.lse = l.lse; p.delta = e->t_delta;
-            p.dout = e->t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
+            p.ldq = p.ldk = p.ldv = 3 * inner; p.lse = l.lse; p.delta = cx.L().t_delta;
+            p.dout = cx.L().t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
             p.lddq = p.lddk = p.lddv = 3 * inner;
             p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
             p.drop = cx.site(v + 1, L, Ctx::K_ATTN);
             if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero
-                CK(vc_memset_async(e->t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
+                CK(vc_memset_async(cx.L().t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
                 p.Tq = 1; p.ldq = 3 * TI; p.lddq = 3 * TI;
             }
             CK(vc_attn_bwd(e->dt, c.vit_dim_head, p, cx.s));
         }
-        CK(cx.lin_wgrad(cx.AT(e->t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
-        if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(e->t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(e->t_dh, D), (int)R, 3 * inner, D, Epi()));
-        else CK(cx.lin_dgrad(cx.AT(e->t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(e->t_dh, D), (int)R, 3 * inner, D, Epi()));
-        CK(cx.ln_bwd(e->dt, e->t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
+        CK(cx.lin_wgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
+        if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
+        else CK(cx.lin_dgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
     }
     if (part != 1) {
         { const vc_drop d = cx.site(v + 1, 0, Ctx::K_EMB);      // emb_dropout: everything below sees dx * mask
@@ -474,16 +492,16 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         {   // LN(512) backward through the embed mapping
             LnBwdParams p; memset(&p, 0, sizeof(p));
             p.dy = dx; p.lddy = D; p.x = a.pe; p.ldx = D; p.stats = a.stat2; p.gamma = cx.Pf(w.ln2w);
-            p.dx32 = e->t_dpe; p.lddx32 = D; p.rows = Rp; p.P = P;
-            CK(vc_ln_bwd(VC_F32, VC_F32, VC_F32, D, 2, p, e->scr_lnpart, cx.Gf(w.ln2w), cx.Gf(w.ln2b), e->scr_colsum, cx.s));
+            p.dx32 = cx.L().t_dpe; p.lddx32 = D; p.rows = Rp; p.P = P;
+            CK(vc_ln_bwd(VC_F32, VC_F32, VC_F32, D, 2, p, cx.L().scr_lnpart, cx.Gf(w.ln2w), cx.Gf(w.ln2b), cx.L().scr_colsum, cx.s));
         }
-        CK(cx.lin_wgrad(cx.A32(e->t_dpe, D), cx.AT(a.pn, pd), cx.Gf(w.pew), pd, cx.Gf(w.peb), (int)Rp, D, pd));
-        CK(cx.lin_dgrad(cx.A32(e->t_dpe, D), cx.W(w.pew, pd), cx.AT(e->t_dpn, pd), (int)Rp, D, pd, Epi()));
+        CK(cx.lin_wgrad(cx.A32(cx.L().t_dpe, D), cx.AT(a.pn, pd), cx.Gf(w.pew), pd, cx.Gf(w.peb), (int)Rp, D, pd));
+        CK(cx.lin_dgrad(cx.A32(cx.L().t_dpe, D), cx.W(w.pew, pd), cx.AT(cx.L().t_dpn, pd), (int)Rp, D, pd, Epi()));
         {   // LN(1024) parameter gradients (input frames need no gradient)
             LnBwdParams p; memset(&p, 0, sizeof(p));
-            p.dy = e->t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
+            p.dy = cx.L().t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
             p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T;
-            CK(vc_ln_bwd(e->dt, VC_F32, e->dt, pd, 1, p, e->scr_lnpart, cx.Gf(w.ln1w), cx.Gf(w.ln1b), e->scr_colsum, cx.s));
+            CK(vc_ln_bwd(e->dt, VC_F32, e->dt, pd, 1, p, cx.L().scr_lnpart, cx.Gf(w.ln1w), cx.Gf(w.ln1b), cx.L().scr_colsum, cx.s));
         }
     }
     return 0;
@@ -498,7 +516,7 @@ int dec_attn(const Ctx& cx, bool bwd, const void* q, long ldq, const void* k, co
     const int hd = c.hidden_size / c.nhead;
     p.scale = 1.0f / sqrtf((float)hd);
     if (!bwd) return vc_attn_fwd(e->dt, hd, p, cx.s);
-    p.dout = dout; p.lddo = c.hidden_size; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = p.lddv = lddkv; p.delta = e->t_delta;
+    p.dout = dout; p.lddo = c.hidden_size; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = p.lddv = lddkv; p.delta = cx.L().t_delta;
     return vc_attn_bwd(e->dt, hd, p, cx.s);
 }
 
@@ -512,12 +530,18 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     // memory = tanh(image_projection([ui, cad])) only when BOTH flags are set, otherwise tanh(cad embedding) repeated over time.
     const bool pa = c.enable_past_actions, ps = c.enable_past_states;
     const float* ts = c.enable_timestep_embedding ? cx.Pf(e->o_ts) : nullptr;
+    // CAD ViT (B images) on the side stream, issued first so that its ~100 small kernels slot in beside the frame ViT's big ones
+    const bool fork = ps && ensure_side(e);
+    Ctx cxs{e, fork ? e->side : s, 1};
+    if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
+    CK(vit_forward(cxs, 1, e->in_cad, 1, (long)c.image_size * c.image_size));
+    if (fork) CK(vc_event_record(e->ev_join, e->side));
     if (ps) {
         CK(vit_forward(cx, 0, e->in_frames, T, e->in_fbstride));
         Epi ep; ep.bias = cx.Pf(e->o_es_b); ep.rowadd = ts; ep.rdiv = T; ep.rmod = 1; ep.ldrow = H; ep.act = VC_ACT_TANH;
         CK(cx.lin_fwd(cx.AT(e->va[0].e, D), cx.W(e->o_es_w, D), cx.A32(e->ui, H), (int)M, H, D, ep));
     }
-    CK(vit_forward(cx, 1, e->in_cad, 1, (long)c.image_size * c.image_size));
+    if (fork) CK(vc_stream_wait_event(s, e->ev_join));
     { Epi ep; ep.bias = cx.Pf(e->o_ei_b); CK(cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep)); }
     if (pa && ps) {
         { Epi ep; ep.bias = cx.Pf(e->o_ip_b);
@@ -726,7 +750,10 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     *out = e;
     return 0;
 }
-void vcad_engine_destroy(vcad_engine* e) { delete e; }
+void vcad_engine_destroy(vcad_engine* e) {
+    if (e && e->side_ok) { vc_stream_destroy(e->side); vc_event_destroy(e->ev_fork); vc_event_destroy(e->ev_join); }
+    delete e;
+}
 
 int64_t vcad_param_total(const vcad_engine* e) { return e->ptotal; }
 int vcad_param_count(const vcad_engine* e) { return (int)e->plist.size(); }
@@ -839,7 +866,7 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
     int rc = 0;
     switch (stage) {
         case 0: rc = backward_stage0(e, dcmds ? dcmds : e->dl_cmds, dpars ? dpars : e->dl_pars, s); break;
-        case 1: rc = vit_backward(cx, 1, e->t_dec, 0, e->in_cad, 1, img2); break;
+        case 1: { Ctx c1{e, e->bwd_fork ? e->side : s, 1}; rc = vit_backward(c1, 1, e->t_dec, 0, e->in_cad, 1, img2); } break;
         case 2: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride) : 0; break;
         case 3: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride) : 0; break;
         default: vc_set_error("vcad_backward_stage: stage %d out of range", stage); return VC_ERR_ARG;
@@ -848,8 +875,21 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
     if (vc_last_launch_error()) { vc_set_error("vcad_backward: kernel launch failed"); return VC_ERR_LAUNCH; }
     return 0;
 }
+// Whole backward: after stage 0 (heads + decoder + stem) the CAD ViT's backward (stage 1) is independent of the frame ViT's
+// (stages 2-3), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
+// soon as its stage returns) keeps everything on the caller's stream.
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
-    for (int st = 0; st < NB_BUCKETS; ++st) CK(vcad_backward_stage(e, st, dcmds, dpars, stream));
+    vc_stream_t s = (vc_stream_t)stream;
+    CK(vcad_backward_stage(e, 0, dcmds, dpars, stream));
+    const bool fork = e->c.enable_past_states && ensure_side(e);
+    if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
+    e->bwd_fork = fork;
+    int rc = vcad_backward_stage(e, 1, dcmds, dpars, stream);
+    e->bwd_fork = false;
+    if (rc) return rc;
+    if (fork) CK(vc_event_record(e->ev_join, e->side));
+    for (int st = 2; st < NB_BUCKETS; ++st) CK(vcad_backward_stage(e, st, dcmds, dpars, stream));
+    if (fork) CK(vc_stream_wait_event(s, e->ev_join));
     return 0;
 }
 

@@ -31,6 +31,7 @@ struct GemmCall {
     GemmParams p;               // vecA/vecB/k_per_split/partial are filled by vc_gemm
 };
 // scratch: fp32 workspace for split-K partial slabs (may be null -> no split)
+bool vc_profile_on();       // the HIP-event profiler is recording: per-kernel times must not overlap, so no side stream
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s);
 // grouped launch of many same-signature problems in one grid (see ops_gemm.hip)
 int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start);

@@ -21,6 +21,7 @@ ProfScope::ProfScope(int cat, double flops, double bytes, vc_stream_t s) : rec(n
 }
 ProfScope::~ProfScope() { if (rec) { PRec* r = (PRec*)rec; (void)hipEventRecord(r->b, r->s); g_recs.push_back(r); } }
 extern "C" void vcad_profile_begin(void) { g_on = true; }
+bool vc_profile_on() { return g_on; }
 // out arrays of VC_NCAT: milliseconds, flops, bytes, launches.  Synchronises the recorded events.
 extern "C" int vcad_profile_end(double* ms, double* flops, double* bytes, int* launches) {
     g_on = false;
@@ -38,6 +39,7 @@ extern "C" int vcad_profile_end(double* ms, double* flops, double* bytes, int* l
 ProfScope::ProfScope(int, double, double, vc_stream_t) : rec(nullptr) {}
 ProfScope::~ProfScope() {}
 extern "C" void vcad_profile_begin(void) {}
+bool vc_profile_on() { return false; }
 extern "C" int vcad_profile_end(double*, double*, double*, int*) { return 0; }
 #endif
 

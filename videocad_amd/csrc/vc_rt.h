@@ -26,6 +26,14 @@ typedef hipStream_t vc_stream_t;
 
 static inline int vc_memset_async(void* p, int v, size_t n, vc_stream_t s) { return (int)hipMemsetAsync(p, v, n, s); }
 static inline int vc_memcpy_d2d_async(void* d, const void* s_, size_t n, vc_stream_t s) { return (int)hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, s); }
+typedef hipEvent_t vc_event_t;
+static inline int vc_stream_create(vc_stream_t* s) { return (int)hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+static inline int vc_event_create(vc_event_t* ev) { return (int)hipEventCreateWithFlags(ev, hipEventDisableTiming); }
+static inline int vc_event_record(vc_event_t ev, vc_stream_t s) { return (int)hipEventRecord(ev, s); }
+static inline int vc_stream_wait_event(vc_stream_t s, vc_event_t ev) { return (int)hipStreamWaitEvent(s, ev, 0); }
+static inline void vc_stream_destroy(vc_stream_t s) { if (s) (void)hipStreamDestroy(s); }
+static inline void vc_event_destroy(vc_event_t ev) { if (ev) (void)hipEventDestroy(ev); }
+static inline bool vc_has_side_streams() { return true; }
 // small host -> device table upload, ordered on the stream; the (pageable) host buffer may be reused when it returns
 static inline int vc_upload(void* d, const void* h, size_t n, vc_stream_t s) { int rc = (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); return rc ? rc : (int)hipStreamSynchronize(s); }
 static inline int vc_last_launch_error() { return (int)hipGetLastError(); }
@@ -124,6 +132,14 @@ void launch_k(void (*k)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... 
 static inline int vc_memset_async(void* p, int v, size_t n, vc_stream_t) { memset(p, v, n); return 0; }
 static inline int vc_memcpy_d2d_async(void* d, const void* s_, size_t n, vc_stream_t) { memmove(d, s_, n); return 0; }
 static inline int vc_upload(void* d, const void* h, size_t n, vc_stream_t) { memcpy(d, h, n); return 0; }
+typedef void* vc_event_t;                          // the emulator executes launches synchronously: one stream, no events
+static inline int vc_stream_create(vc_stream_t* s) { *s = nullptr; return 0; }
+static inline int vc_event_create(vc_event_t* ev) { *ev = nullptr; return 0; }
+static inline int vc_event_record(vc_event_t, vc_stream_t) { return 0; }
+static inline int vc_stream_wait_event(vc_stream_t, vc_event_t) { return 0; }
+static inline void vc_stream_destroy(vc_stream_t) {}
+static inline void vc_event_destroy(vc_event_t) {}
+static inline bool vc_has_side_streams() { return false; }
 static inline int vc_last_launch_error() { return 0; }
 
 VC_DEV void vc_sync() { vcemu::sync_block(); }
