@@ -76,7 +76,7 @@ struct vcad_engine {
     float *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
     void *t_df1, *t_dq, *t_dkv, *t_dao_d, *t_dqkv_d;
     Lane lane[2];                 // scratch + ViT-backward temporaries per stream (see Lane)
-    vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false;
+    vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false, bwd_side = false;
     float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
@@ -356,7 +356,7 @@ struct Ctx {
 bool ensure_side(vcad_engine* e) {
     if (!vc_has_side_streams() || e->no_side || vc_profile_on()) return false;
     if (!e->side_ok) {
-        if (vc_stream_create(&e->side) || vc_event_create(&e->ev_fork) || vc_event_create(&e->ev_join)) return false;
+        if (vc_stream_create(&e->side) || vc_event_create(&e->ev_fork) || vc_event_create(&e->ev_fork2) || vc_event_create(&e->ev_join)) return false;
         e->side_ok = true;
     }
     return true;
@@ -685,10 +685,14 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_dqkv, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }
     }
     if (defer) {
+        // nothing downstream reads these gradients before the optimiser: in the whole-backward entry point they go to the side
+        // stream (which vcad_backward joins at the end) and run beside the stem and the ViT backward
         vcad_engine::Deferred& df = e->def;
+        vc_stream_t gs = s;
+        if (e->bwd_side) { CK(vc_event_record(e->ev_fork2, s)); CK(vc_stream_wait_event(e->side, e->ev_fork2)); gs = e->side; }
         for (int g = 0; g < 2; ++g)
-            CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], s));
-        CK(vc_colsum_grouped(df.d_cs, (int)df.cs.size(), df.cs_strips, df.cs_chunks, df.cs_partial, s));
+            CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], gs));
+        CK(vc_colsum_grouped(df.d_cs, (int)df.cs.size(), df.cs_strips, df.cs_chunks, df.cs_partial, gs));
     }
     // ---- stem (reference model/autoregressive_transformer.py:144-178); dx = gradient of the decoder's tgt input
     float* dpre = e->t_dpre;
@@ -751,7 +755,7 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     return 0;
 }
 void vcad_engine_destroy(vcad_engine* e) {
-    if (e && e->side_ok) { vc_stream_destroy(e->side); vc_event_destroy(e->ev_fork); vc_event_destroy(e->ev_join); }
+    if (e && e->side_ok) { vc_stream_destroy(e->side); vc_event_destroy(e->ev_fork); vc_event_destroy(e->ev_fork2); vc_event_destroy(e->ev_join); }
     delete e;
 }
 
@@ -880,8 +884,11 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
 // soon as its stage returns) keeps everything on the caller's stream.
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
     vc_stream_t s = (vc_stream_t)stream;
-    CK(vcad_backward_stage(e, 0, dcmds, dpars, stream));
     const bool fork = e->c.enable_past_states && ensure_side(e);
+    e->bwd_side = fork;
+    int rc0 = vcad_backward_stage(e, 0, dcmds, dpars, stream);
+    e->bwd_side = false;
+    if (rc0) return rc0;
     if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
     e->bwd_fork = fork;
     int rc = vcad_backward_stage(e, 1, dcmds, dpars, stream);
