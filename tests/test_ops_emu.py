@@ -82,6 +82,12 @@ def test_attention_causal_d256(emu):
     U.check_attention(emu, "cpu", 1, 2, 70, 256, window=70, causal=1, dt=F32)     # > 64 keys: NPASS = 3 path
 
 
+@pytest.mark.parametrize("T,window", [(64, 64), (37, 37), (37, 10), (64, 1), (5, 3)])
+def test_attention_decoder_mfma(emu, T, window):
+    """bf16, head dim 256, causal (+ band), T <= 64: the matrix-core decoder kernels (attn_mfma.h), forward and backward"""
+    U.check_attention(emu, "cpu", 2, 2, T, 256, window=window, causal=1, dt=BF16)
+
+
 def test_attention_band(emu):
     U.check_attention(emu, "cpu", 2, 1, 23, 256, window=10, causal=1, dt=F32)
     U.check_attention(emu, "cpu", 1, 1, 9, 256, window=1, causal=1, dt=F32)

@@ -93,6 +93,11 @@ def test_attention_decoder_causal(hip, T):
     U.check_attention(hip, DEV, 2, 4, T, 256, window=T, causal=1, dt=F32)
 
 
+@pytest.mark.parametrize("T,window", [(64, 64), (50, 50), (64, 10), (33, 10), (64, 1)])
+def test_attention_decoder_mfma(hip, T, window):
+    U.check_attention(hip, DEV, 4, 4, T, 256, window=window, causal=1, dt=BF16)
+
+
 @pytest.mark.parametrize("window", [1, 5, 10])
 def test_attention_band(hip, window):
     U.check_attention(hip, DEV, 2, 4, 64, 256, window=window, causal=1, dt=F32)

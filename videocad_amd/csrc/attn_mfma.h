@@ -342,3 +342,179 @@ VC_DEV void attn_vit_bwd_mfma_body(const AttnParams& p) {
 #endif
 VC_KERNEL __launch_bounds__(128, 2) void attn_vit_bwd_mfma_kernel_eval(AttnParams p) { attn_vit_bwd_mfma_body<false>(p); }
 VC_KERNEL __launch_bounds__(128, ATTN_BWD_DROP_WAVES) void attn_vit_bwd_mfma_kernel_drop(AttnParams p) { attn_vit_bwd_mfma_body<true>(p); }
+
+// ====================================================================================================================
+// Decoder attention on the matrix cores: one (clip, head) per workgroup, T <= 64 steps, head dim = NCH chunks of 64.
+//
+// Same orientation tricks as the ViT kernels above; the head dimension (256 in the canonical model) is walked in 64-wide
+// chunks that are re-staged through the same small LDS tiles: the score grids accumulate over the chunks, the outputs are
+// produced one chunk at a time from the probability / dS grids that stay in registers.  The mask is the reference's
+// (causal + window band, model/autoregressive_transformer.py:180-188): key j visible to query i iff i - window < j <= i.
+// The wave-per-row kernels in attn.h remain the path for T > 64 and for fp32 mode.
+// ====================================================================================================================
+VC_DEV bool am_visible(int query, int key, int T, int window) { return key < T && key <= query && key > query - window; }
+
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(64) void attn_dec_fwd_mfma_kernel(AttnParams p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[2][AM_T * AM_S];
+    const int lane = threadIdx.x;
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH;
+    vc_f32x16 st[2][2];                       // S^T: [key tile][query tile], lane column = query
+    am_zero(st);
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_wave_barrier();                    // the previous chunk's fragment reads are done before its tiles are overwritten
+        am_stage(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + hd + c * AM_D, p.ldq, T, lane);
+        am_stage(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + hd + c * AM_D, p.ldk, T, lane);
+        vc_wave_barrier();
+        am_mm_nt(st, tiles[1], tiles[0], lane);
+    }
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    uint64_t keep = 0;
+    if (DROP) keep = am_keep_bits<true>(p.drop, dbase0, T, lane);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int query = qt * 32 + (lane & 31);
+        const int qm = query < T ? query : T - 1;              // padding columns: keep the row finite (never stored)
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + am_row(r, lane);
+                const float sc = am_visible(qm, key, T, p.window) ? st[kt][qt][r] * p.scale : -INFINITY;
+                st[kt][qt][r] = sc; m = fmaxf(m, sc);
+            }
+        m = fmaxf(m, vc_shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
+        l += vc_shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][qt][r] *= DROP ? inv * am_keep(keep, kt, qt, r, p.drop.scale) : inv;
+        if (p.lse && lane < 32 && query < T) p.lse[(n * p.H + h) * T + query] = m + logf(l);
+    }
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_wave_barrier();
+        am_stage(tiles[0], (const vc_bf16*)p.v + rowq * p.ldv + hd + c * AM_D, p.ldv, T, lane);
+        vc_wave_barrier();
+        vc_f32x16 o[2][2];
+        am_zero(o);
+        am_mm_tok(o, st, tiles[0], lane);    // O[query][d] = sum_key P[query][key] V[key][d]
+        am_store((vc_bf16*)p.o + rowq * p.ldo + hd + c * AM_D, p.ldo, o, T, lane, 1.0f);
+    }
+}
+
+// Backward: 2 waves per (clip, head) as in the ViT kernel — wave 0 owns "lane = query" (D_i, dQ), wave 1 "lane = key" (dV, dK).
+// Phase 1 accumulates both score-shaped grids of each wave over the head-dim chunks, phase 2 re-stages the chunks and emits
+// the three gradients chunk by chunk.
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(128, 1) void attn_dec_bwd_mfma_kernel(AttnParams p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO chunk
+    VC_SHARED float lse_s[AM_T];
+    VC_SHARED float del_s[AM_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH;
+    const vc_bf16 *Qs = tiles[0], *Ks = tiles[1], *Vs = tiles[2], *dOs = tiles[3];
+    if (tid < AM_T) lse_s[tid] = (tid < T) ? p.lse[(n * p.H + h) * T + tid] : 0.f;
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+
+    vc_f32x16 sg[2][2], dg[2][2];            // wave 0: S^T, dP^T [key tile][query tile]; wave 1: S, dP' [query tile][key tile]
+    am_zero(sg); am_zero(dg);
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_sync();
+        am_stage_nt<128>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + hd + c * AM_D, p.ldq, T, tid);
+        am_stage_nt<128>(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + hd + c * AM_D, p.ldk, T, tid);
+        am_stage_nt<128>(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + hd + c * AM_D, p.ldv, T, tid);
+        am_stage_nt<128>(tiles[3], (const vc_bf16*)p.dout + rowq * p.lddo + hd + c * AM_D, p.lddo, T, tid);
+        vc_sync();
+        if (wave == 0) { am_mm_nt(sg, Ks, Qs, lane); am_mm_nt(dg, Vs, dOs, lane); }
+        else           { am_mm_nt(sg, Qs, Ks, lane); am_mm_nt(dg, dOs, Vs, lane); }
+    }
+    uint64_t keep = 0;
+    if (wave == 0) {   // ---------------- lane = query: P, D_i, dS^T
+        if (DROP) keep = am_keep_bits<true>(p.drop, dbase0, T, lane);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int query = qt * 32 + (lane & 31);
+            const float lse = lse_s[query];
+            float dsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + am_row(r, lane);
+                    const bool ok = query < T && am_visible(query, key, T, p.window);
+                    const float pr = ok ? expf(sg[kt][qt][r] * p.scale - lse) : 0.f;
+                    if (DROP) dg[kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);                    // dP = dP' * mask
+                    sg[kt][qt][r] = pr; dsum += pr * dg[kt][qt][r];
+                }
+            dsum += vc_shfl_xor(dsum, 32);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sg[kt][qt][r] = sg[kt][qt][r] * (dg[kt][qt][r] - dsum);   // dS^T (scale folded into the store)
+            if (lane < 32) del_s[query] = dsum;
+        }
+    } else {           // ---------------- lane = key: P (kept in sg), later dS (in dg)
+        if (DROP) keep = am_keep_bits<false>(p.drop, dbase0, T, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = kt * 32 + (lane & 31);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + am_row(r, lane);
+                    sg[qt][kt][r] = (query < T && am_visible(query, key, T, p.window)) ? expf(sg[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
+                }
+        }
+    }
+    vc_sync();                               // D_i published
+    if (wave == 1) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + am_row(r, lane);
+                    const float ms = DROP ? am_keep(keep, qt, kt, r, p.drop.scale) : 1.0f;
+                    dg[qt][kt][r] = sg[qt][kt][r] * (dg[qt][kt][r] * ms - del_s[query]);                          // dS
+                }
+    }
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_sync();
+        am_stage_nt<128>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + hd + c * AM_D, p.ldq, T, tid);
+        am_stage_nt<128>(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + hd + c * AM_D, p.ldk, T, tid);
+        am_stage_nt<128>(tiles[3], (const vc_bf16*)p.dout + rowq * p.lddo + hd + c * AM_D, p.lddo, T, tid);
+        vc_sync();
+        vc_f32x16 acc[2][2];
+        if (wave == 0) {
+            am_zero(acc);
+            am_mm_tok(acc, sg, Ks, lane);        // dQ[query][d] = sum_key dS[query][key] K[key][d]
+            am_store((vc_bf16*)p.dq + rowq * p.lddq + hd + c * AM_D, p.lddq, acc, T, lane, p.scale);
+        } else {
+            am_zero(acc);
+            am_mm_tok_keep<DROP>(acc, sg, dOs, lane, keep, p.drop.scale);     // dV[key][d] = sum_query P'[query][key] dO[query][d]
+            am_store((vc_bf16*)p.dv + rowq * p.lddv + hd + c * AM_D, p.lddv, acc, T, lane, 1.0f);
+            am_zero(acc);
+            am_mm_tok(acc, dg, Qs, lane);        // dK[key][d] = sum_query dS[query][key] Q[query][d]
+            am_store((vc_bf16*)p.dk + rowq * p.lddk + hd + c * AM_D, p.lddk, acc, T, lane, p.scale);
+        }
+    }
+}

@@ -45,6 +45,13 @@ static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
 }
+// decoder attention on the matrix cores (attn_mfma.h): bf16, head dim 256, causal (+ window band), T <= 64
+static bool dec_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
+    auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
+    bool ok = t == VC_BF16 && D == 4 * AM_D && p.Tq == p.Tk && p.Tq <= AM_T && p.causal && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    if (!bwd) return ok && al(p.o, p.ldo);
+    return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
+}
 static int check_rows_aligned(int t, const AttnParams& p, bool bwd) {
     const long e = (t == VC_BF16) ? 8 : 4;           // elements per 16 bytes
     auto bad = [&](const void* q, long ld) { return q && (((uintptr_t)q % 16) || (ld % e)); };
@@ -63,6 +70,11 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         else VC_LAUNCH((attn_vit_fwd_mfma_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         return VC_OK;
     }
+    if (dec_mfma_ok(t, D, p, false)) {
+        if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
+        else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
+        return VC_OK;
+    }
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
 }
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
@@ -78,6 +90,11 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (mfma_ok(t, D, p, true)) {
         if (p.drop.key) VC_LAUNCH(attn_vit_bwd_mfma_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH(attn_vit_bwd_mfma_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        return VC_OK;
+    }
+    if (dec_mfma_ok(t, D, p, true)) {
+        if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);
