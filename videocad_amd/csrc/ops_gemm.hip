@@ -1,7 +1,7 @@
 // ops_gemm.hip — GEMM dispatch: picks the template instantiation, the 16-byte-load legality flags and the
 // split-K factor (small tile counts with a long reduction, e.g. every wgrad: K = number of tokens).
 #include "ops.h"
-#include "gemm_dma.h"
+#include "gemm_dma.h"      // tile constants only: the persistent kernel is instantiated in ops_gemm_dma.hip
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -73,32 +73,6 @@ static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
     return c.p.k_per_split < 0 ? gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 1>(c, nsplit, s) : gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 2>(c, nsplit, s);
 }
 
-static long g_dma_launches = 0;
-extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
-// persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
-template <typename TO, bool TRA, bool TRB>
-static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
-#ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD_LDS_BYTES);
-        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
-    }
-#endif
-    ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
-                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s);
-    const int tiles_n = c.p.N / GD_BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
-    ++g_dma_launches;
-    const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GD_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
-    if (nsplit > 1) {
-        long tot = (long)c.p.M * c.p.N;
-        VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot, 256)), dim3(256), 0, s, c.p, nsplit);
-    }
-    return VC_OK;
-}
-
 static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal (tests run small problems through it)
 extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
 static int g_stagger = -1;      // -1 = automatic
@@ -111,7 +85,7 @@ extern "C" void vcad_debug_force_gemm_tile(int tile) { g_force_tile = (tile == 6
 static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
 
 // validation + the per-problem flags every kernel expects (activation remap, 16-byte legality of each operand)
-static int gemm_prepare(GemmCall& c) {
+int vc_gemm_prepare(GemmCall& c) {
     GemmParams& p = c.p;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
     if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
@@ -135,7 +109,7 @@ static int gemm_prepare(GemmCall& c) {
 }
 
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
-    { int rc = gemm_prepare(c); if (rc) return rc; }
+    { int rc = vc_gemm_prepare(c); if (rc) return rc; }
     GemmParams& p = c.p;
     const int lay = c.tra * 2 + c.trb;
     // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad)
@@ -164,9 +138,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if (g_dma_mode == 1 || wins) {
             p.k_per_split = nt * GD_BK;
             p.partial = best > 1 ? scratch : nullptr;
-            if (lay == 3) return gemm_launch_dma<float, true, true>(c, best, s);
-            if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false>(c, best, s) : gemm_launch_dma<vc_bf16, false, false>(c, best, s);
-            return c.to == VC_F32 ? gemm_launch_dma<float, false, true>(c, best, s) : gemm_launch_dma<vc_bf16, false, true>(c, best, s);
+            return vc_gemm_dma_launch(c, best, s);
         }
     }
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
@@ -210,53 +182,4 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
 #undef G
     vc_set_error("vc_gemm: unsupported combination ct=%d sa=%d sb=%d to=%d tra=%d trb=%d", c.ct, c.sa, c.sb, c.to, c.tra, c.trb);
     return VC_ERR_UNSUPPORTED;
-}
-
-// ---------------------------------------------------------------------------------------------- grouped launch
-// Host half: fills `probs` (device-layout descriptors) and `tile_start` (n + 1 entries, every problem padded to a multiple
-// of 8 tiles so the XCD-aware order inside a problem lines up with the hardware's round-robin); all problems must share the
-// first one's signature.  The caller uploads both arrays to device memory once per plan and launches every step.
-int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start) {
-    int t = 0;
-    for (int i = 0; i < n; ++i) {
-        GemmCall& c = calls[i];
-        if (c.ct != calls[0].ct || c.sa != calls[0].sa || c.sb != calls[0].sb || c.to != calls[0].to || c.tra != calls[0].tra || c.trb != calls[0].trb) {
-            vc_set_error("vc_gemm_grouped: mixed signatures"); return VC_ERR_ARG;
-        }
-        int rc = gemm_prepare(c); if (rc) return rc;
-        c.p.k_per_split = VC_CEIL_DIV(c.p.K, 64) * 64; c.p.partial = nullptr; c.p.stagger = 0; c.p.debug_skip = 0;
-        probs[i] = c.p; tile_start[i] = t;
-        t += VC_CEIL_DIV(VC_CEIL_DIV(c.p.M, 128) * VC_CEIL_DIV(c.p.N, 128), 8) * 8;
-    }
-    tile_start[n] = t;
-    return VC_OK;
-}
-
-template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
-static int grouped_launch(const GemmCall& sig, GemmGroup grp, int total_tiles, double flops, vc_stream_t s) {
-    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB, 2>();
-#ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
-    }
-#endif
-    ProfScope ps(sig.role ? sig.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), flops, 0.0, s);
-    VC_LAUNCH((gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>), dim3((unsigned)total_tiles), dim3(GEMM_THREADS), lds, s, grp);
-    return VC_OK;
-}
-
-// Device half: probs / tile_start are DEVICE pointers holding what vc_gemm_grouped_prepare produced.  Only the wgrad layout
-// (tra = trb = 1, fp32 output) is instantiated — that is what the engine defers.
-int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s) {
-    if (n <= 0) return VC_OK;
-    GemmGroup grp{probs, tile_start, n};
-    if (!(sig.tra && sig.trb) || sig.to != VC_F32) { vc_set_error("vc_gemm_grouped: only the wgrad layout is instantiated"); return VC_ERR_UNSUPPORTED; }
-    if (sig.ct == VC_F32) return grouped_launch<float, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
-    if (sig.sa == VC_BF16 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, vc_bf16, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
-    if (sig.sa == VC_BF16 && sig.sb == VC_F32) return grouped_launch<vc_bf16, vc_bf16, float, float, true, true>(sig, grp, total_tiles, flops, s);
-    if (sig.sa == VC_F32 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, float, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
-    return grouped_launch<vc_bf16, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
 }

@@ -1,0 +1,38 @@
+// ops_gemm_dma.hip — instantiations and launch of the persistent DMA-fed GEMM (gemm_dma.h); own translation unit so that it
+// compiles in parallel with the register-staged kernels of ops_gemm.hip.
+#include "ops.h"
+#include "gemm_dma.h"
+
+static long g_dma_launches = 0;
+extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
+// persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
+template <typename TO, bool TRA, bool TRB>
+static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
+#ifndef VC_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD_LDS_BYTES);
+        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+        attr_set = true;
+    }
+#endif
+    ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
+                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s);
+    const int tiles_n = c.p.N / GD_BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
+    ++g_dma_launches;
+    const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GD_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
+    if (nsplit > 1) {
+        long tot = (long)c.p.M * c.p.N;
+        VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot, 256)), dim3(256), 0, s, c.p, nsplit);
+    }
+    return VC_OK;
+}
+
+
+int vc_gemm_dma_launch(GemmCall c, int nsplit, vc_stream_t s) {
+    const int lay = c.tra * 2 + c.trb;
+    if (lay == 3) return gemm_launch_dma<float, true, true>(c, nsplit, s);
+    if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false>(c, nsplit, s);
+    return c.to == VC_F32 ? gemm_launch_dma<float, false, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, true>(c, nsplit, s);
+}

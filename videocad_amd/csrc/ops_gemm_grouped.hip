@@ -1,0 +1,51 @@
+// ops_gemm_grouped.hip — grouped GEMM launch (own translation unit: the kernel instantiations compile in parallel with ops_gemm.hip)
+#include "ops.h"
+
+// ---------------------------------------------------------------------------------------------- grouped launch
+// Host half: fills `probs` (device-layout descriptors) and `tile_start` (n + 1 entries, every problem padded to a multiple
+// of 8 tiles so the XCD-aware order inside a problem lines up with the hardware's round-robin); all problems must share the
+// first one's signature.  The caller uploads both arrays to device memory once per plan and launches every step.
+int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start) {
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmCall& c = calls[i];
+        if (c.ct != calls[0].ct || c.sa != calls[0].sa || c.sb != calls[0].sb || c.to != calls[0].to || c.tra != calls[0].tra || c.trb != calls[0].trb) {
+            vc_set_error("vc_gemm_grouped: mixed signatures"); return VC_ERR_ARG;
+        }
+        int rc = vc_gemm_prepare(c); if (rc) return rc;
+        c.p.k_per_split = VC_CEIL_DIV(c.p.K, 64) * 64; c.p.partial = nullptr; c.p.stagger = 0; c.p.debug_skip = 0;
+        probs[i] = c.p; tile_start[i] = t;
+        t += VC_CEIL_DIV(VC_CEIL_DIV(c.p.M, 128) * VC_CEIL_DIV(c.p.N, 128), 8) * 8;
+    }
+    tile_start[n] = t;
+    return VC_OK;
+}
+
+template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
+static int grouped_launch(const GemmCall& sig, GemmGroup grp, int total_tiles, double flops, vc_stream_t s) {
+    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB, 2>();
+#ifndef VC_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+        attr_set = true;
+    }
+#endif
+    ProfScope ps(sig.role ? sig.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), flops, 0.0, s);
+    VC_LAUNCH((gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>), dim3((unsigned)total_tiles), dim3(GEMM_THREADS), lds, s, grp);
+    return VC_OK;
+}
+
+// Device half: probs / tile_start are DEVICE pointers holding what vc_gemm_grouped_prepare produced.  Only the wgrad layout
+// (tra = trb = 1, fp32 output) is instantiated — that is what the engine defers.
+int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s) {
+    if (n <= 0) return VC_OK;
+    GemmGroup grp{probs, tile_start, n};
+    if (!(sig.tra && sig.trb) || sig.to != VC_F32) { vc_set_error("vc_gemm_grouped: only the wgrad layout is instantiated"); return VC_ERR_UNSUPPORTED; }
+    if (sig.ct == VC_F32) return grouped_launch<float, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.sa == VC_BF16 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, vc_bf16, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.sa == VC_BF16 && sig.sb == VC_F32) return grouped_launch<vc_bf16, vc_bf16, float, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.sa == VC_F32 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, float, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
+    return grouped_launch<vc_bf16, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
+}
