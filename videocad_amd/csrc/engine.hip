@@ -343,11 +343,17 @@ struct Ctx {
         return vc_ln_fwd(tx, e->dt, C, 0, p, s);
     }
     // dx32 (+T copy) = add_in + LNbwd(dy);  dgamma/dbeta written to the grad buffer
+    // `du` (optional): also emit the masked copy du = T(dx * mask(site d)) that masked() would produce from dx32 in a second pass
     int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
-               const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C) const {
+               const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C,
+               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr) const {
         LnBwdParams p; memset(&p, 0, sizeof(p));
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
+        if (du) {
+            if (d.key) { void* dst = du_dst ? du_dst : L().t_dum; p.dxt = dst; p.lddxt = C; p.drop = d; *du = AT(dst, C); }
+            else *du = A32(dx32, lddx);
+        }
         return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s);
     }
 };
@@ -441,6 +447,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.ln_bwd(VC_F32, de, D, xl, (long)(P + 1) * D, a.statn, w.normw, w.normb, nullptr, 0, dx, (long)(P + 1) * D, N, D));
     }
     const long TD = (long)(P + 1) * D, TI = (long)(P + 1) * inner;
+    Mat du{nullptr, VC_F32, 0}; bool have_du = false;          // masked gradient entering the current Linear (and whether the previous LayerNorm backward already produced it)
     for (int L = Lhi; L >= Llo; --L) {
         const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
         const float* xin = L == 0 ? a.x0 : a.L[L - 1].xo;
@@ -448,8 +455,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         const long Rm = cls_only ? N : R;                       // rows the MLP / out-proj backward runs over
         const long ldx = cls_only ? TD : D, ldao = cls_only ? TI : inner;
         // MLP (x' = xm + drop(W4 drop(gelu(z)) + b4)): the gradient entering W4 is dx * mask_out
-        Mat du;
-        CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));
+        if (!have_du) CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));     // else: emitted by the layer above's LayerNorm backward
+        have_du = false;
         CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
           if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep));
@@ -457,9 +464,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
         if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         else CK(cx.lin_dgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
-        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D));
-        // attention block (xm = x + drop(Wo ao + bo))
-        CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du));
+        // attention block (xm = x + drop(Wo ao + bo)): the LayerNorm backward also emits du = dx * mask_out
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du));
         CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
         if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
@@ -481,7 +487,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.lin_wgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
         if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
         else CK(cx.lin_dgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
-        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
+        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du)); have_du = true; }
+        else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
     }
     if (part != 1) {
         { const vc_drop d = cx.site(v + 1, 0, Ctx::K_EMB);      // emb_dropout: everything below sees dx * mask
@@ -651,16 +658,14 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         const float* xin = L == 0 ? tgt0 : e->da[L - 1].x3;
         // ---- FFN   x3 = LN3(x2 + drop(W2 drop(relu(W1 x2 + b1)) + b2))
         Mat du;
-        CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H));
-        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du, d.g_du_ff));
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du, d.g_du_ff));
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
         { Epi ep; ep.dact = d.f1; ep.lddact = ff; ep.dkind = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT);   // f1 > 0 <=> z > 0 and kept
           CK(cx.lin_dgrad(du, cx.W(w.w2, ff), cx.AT(d.g_df1, ff), (int)M, H, ff, ep)); }
         if (!defer) CK(cx.lin_wgrad(cx.AT(d.g_df1, ff), cx.A32(d.x2, H), cx.Gf(w.w1), H, cx.Gf(w.b1), (int)M, ff, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_df1, ff), cx.W(w.w1, H), cx.A32(dx, H), (int)M, ff, H, ep)); }
         // ---- cross attention
-        CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H));
-        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du, d.g_du_ca));
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du, d.g_du_ca));
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* kv = (const char*)d.kv_c; char* dkv = (char*)d.g_dkv;
@@ -674,8 +679,7 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         { Epi ep; if (L != c.num_decoder_layers - 1) { ep.residual = e->t_dmem; ep.ldr = H; }
           CK(cx.lin_dgrad(cx.AT(d.g_dkv, 2 * H), cx.W(w.ca_w + (long)H * H, H), cx.A32(e->t_dmem, H), (int)M, 2 * H, H, ep)); }
         // ---- self attention
-        CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H));
-        CK(cx.masked(dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du, d.g_du_sa));
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du, d.g_du_sa));
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* q = (const char*)d.qkv_s; char* dq = (char*)d.g_dqkv;

@@ -132,7 +132,8 @@ struct LnBwdParams {
     const float* gamma;
     const float* add_in; long ldadd;  // optional fp32 tensor added to dx (the residual-path gradient)
     float* dx32; long lddx32;         // optional fp32 dx output (may alias add_in)
-    void* dxt; long lddxt;            // optional T dx output
+    void* dxt; long lddxt;            // optional T dx output; with drop.key != 0 it is dx * dropout-mask(row * C + c): the masked
+    vc_drop drop;                     //   gradient the next (dropped) Linear's wgrad / dgrad consume, fused here instead of a separate pass
     float* partial;                   // [gridDim.x][2][C] dgamma / dbeta partial sums (fixed order => deterministic)
     long rows;
     int img, patch; int P;            // PATCH / EMBED mapping (EMBED: dy row = n*(P+1)+p+1 for x row n*P+p)
@@ -175,7 +176,13 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
                 for (int i = 0; i < VPL; ++i) dx[i] += a[i];
             }
             if (p.dx32) row_store<float, VPL>(p.dx32 + row * p.lddx32, dx, lane);
-            if (p.dxt) row_store<TY, VPL>((TY*)p.dxt + row * p.lddxt, dx, lane);
+            if (p.dxt) {
+                if (p.drop.key) {
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) dx[i] *= vc_drop_mul(p.drop, row * C + (i / 4) * 256 + lane * 4 + (i % 4));
+                }
+                row_store<TY, VPL>((TY*)p.dxt + row * p.lddxt, dx, lane);
+            }
         }
     }
     if (p.partial) {
