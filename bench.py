@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout probability (reference default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-seq186", action="store_true", help="skip the extra seq_len=186 measurement reported beside the headline config")
     ap.add_argument("--gemm-dma", type=int, default=-1, help="A/B switch: 0 = register-staged GEMM only, -1 = automatic (default)")
     args = ap.parse_args()
 
