@@ -128,6 +128,11 @@ int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void
                           int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
                           void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
                           int causal, float scale, void* stream);
+/* same, with the saved forward output o: the 64 < T <= 192 decoder kernels take D_i = rowsum(dO * O) from it */
+int vcad_op_attention_bwd_o(int t, int D, const void* q, const void* k, const void* v, const void* o, int64_t ldo, const void* dout,
+                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
+                            void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
+                            int causal, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -153,9 +153,9 @@ def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=
     dqkv = torch.zeros(B, T, 3, H, D, dtype=dt, device=device)
     delta = torch.empty(B, H, T, device=device)
     db_ = dqkv.data_ptr()
-    rc = lib.vcad_op_attention_bwd(TD[dt], D, C.c_void_p(base), C.c_void_p(base + H * D * es), C.c_void_p(base + 2 * H * D * es), ptr(do),
-                                   ld, ld, ld, H * D, ptr(lse), ptr(delta), C.c_void_p(db_), C.c_void_p(db_ + H * D * es),
-                                   C.c_void_p(db_ + 2 * H * D * es), ld, ld, ld, B, H, T, T, window, causal, scale, st)
+    rc = lib.vcad_op_attention_bwd_o(TD[dt], D, C.c_void_p(base), C.c_void_p(base + H * D * es), C.c_void_p(base + 2 * H * D * es), ptr(o), H * D,
+                                     ptr(do), ld, ld, ld, H * D, ptr(lse), ptr(delta), C.c_void_p(db_), C.c_void_p(db_ + H * D * es),
+                                     C.c_void_p(db_ + 2 * H * D * es), ld, ld, ld, B, H, T, T, window, causal, scale, st)
     L.check(lib, rc, "attn_bwd")
     ref.backward(do.double().cpu())
     tolb = 1e-5 if dt == torch.float32 else 1.5e-2

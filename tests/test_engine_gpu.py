@@ -189,15 +189,18 @@ def _masks_for(eng, B, T):
     return mod.engine_masks(eng, O.CANONICAL_CONFIG, B, T)
 
 
-@pytest.mark.parametrize("dtype,tol_logit,tol_grad", [(L.VCAD_F32, 1e-4, 2e-3), (L.VCAD_BF16, 3e-2, 6e-2)])
-def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol_grad, gemm_dma_mode):
+@pytest.mark.parametrize("dtype,tol_logit,tol_grad,B,T", [(L.VCAD_F32, 1e-4, 2e-3, 2, 4), (L.VCAD_BF16, 3e-2, 6e-2, 2, 4),
+                                                          (L.VCAD_BF16, 3e-2, 6e-2, 1, 70)],
+                         ids=["f32-T4", "bf16-T4", "bf16-T70-long-decoder-attention"])
+def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol_grad, B, T, gemm_dma_mode):
     """Canonical model, p = 0.1 at every site: the engine's masks are exported (vcad_debug_dropout_mask) and applied by the
     oracle as explicit multipliers.  fp32 mode must agree tightly; bf16 mode (MFMA attention path with in-register masks)
     within bf16 tolerance."""
     if dtype == L.VCAD_F32 and gemm_dma_mode[0] == 1:
         pytest.skip("the DMA kernel is bf16 only")
+    if T > 64 and gemm_dma_mode[0] == 1:
+        pytest.skip("one GEMM mode is enough for the long-horizon case")
     eng = build(dtype)
-    B, T = 2, 4
     eng.set_dropout(0.1, seed=77)
     batch = synth.make_batch(B, T, seed=8)
     weights = {k: eng.view(k).cpu().numpy() for k in eng.table}

@@ -88,6 +88,12 @@ def test_attention_decoder_mfma(emu, T, window):
     U.check_attention(emu, "cpu", 2, 2, T, 256, window=window, causal=1, dt=BF16)
 
 
+@pytest.mark.parametrize("T,window", [(70, 70), (186, 186), (186, 10), (130, 1), (192, 100)])
+def test_attention_decoder_mfma_long(emu, T, window):
+    """64 < T <= 192: the key-block kernels (forward, D_i pre-pass, dQ and dK/dV kernels)"""
+    U.check_attention(emu, "cpu", 1, 2, T, 256, window=window, causal=1, dt=BF16)
+
+
 def test_attention_band(emu):
     U.check_attention(emu, "cpu", 2, 1, 23, 256, window=10, causal=1, dt=F32)
     U.check_attention(emu, "cpu", 1, 1, 9, 256, window=1, causal=1, dt=F32)

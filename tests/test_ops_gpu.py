@@ -98,6 +98,11 @@ def test_attention_decoder_mfma(hip, T, window):
     U.check_attention(hip, DEV, 4, 4, T, 256, window=window, causal=1, dt=BF16)
 
 
+@pytest.mark.parametrize("T,window", [(70, 70), (186, 186), (186, 10), (128, 1), (192, 100)])
+def test_attention_decoder_mfma_long(hip, T, window):
+    U.check_attention(hip, DEV, 3, 4, T, 256, window=window, causal=1, dt=BF16)
+
+
 @pytest.mark.parametrize("window", [1, 5, 10])
 def test_attention_band(hip, window):
     U.check_attention(hip, DEV, 2, 4, 64, 256, window=window, causal=1, dt=F32)

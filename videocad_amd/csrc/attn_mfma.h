@@ -518,3 +518,354 @@ VC_KERNEL __launch_bounds__(128, 1) void attn_dec_bwd_mfma_kernel(AttnParams p) 
         }
     }
 }
+
+// ====================================================================================================================
+// Decoder attention for 64 < T <= 192 (three 64-step blocks; the canonical maximum horizon is 186): the same machinery per
+// (query block, key block) pair.
+//   forward  : one wave per (clip, head, query block); the <= 3 visible key blocks' S^T grids stay in registers, one softmax
+//              over all of them, then O chunk by chunk.
+//   backward : attn_dec_bwd_q (lane = query) first accumulates D_i over its <= 3 key blocks, then writes their dS to LDS as bf16
+//              [query][key] tiles and reads them back as the A operand of dQ = dS K; attn_dec_bwd_kv (lane = key, launched
+//              after it, reads D_i) does the same with P' and dS of its <= 3 query blocks for dV = P'^T dO and dK = dS^T Q
+//              (transposed LDS reads).
+// ====================================================================================================================
+constexpr int AM_MAXB = 3;
+constexpr size_t AM_LONG_Q_LDS = (size_t)(4 + AM_MAXB) * AM_T * AM_S * 2, AM_LONG_KV_LDS = (size_t)(4 + 2 * AM_MAXB) * AM_T * AM_S * 2;
+
+// keep-bits with global (query, key) offsets of the block pair
+template <bool QCOL>
+VC_DEV uint64_t am_keep_bits_g(const vc_drop& d, uint32_t base, int T, int q0, int k0, int lane) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ti = t >> 1, tj = t & 1;
+            const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
+            const int query = q0 + (QCOL ? col : row), key = k0 + (QCOL ? row : col);
+            const uint32_t h = vc_hash32(((base + (uint32_t)(query * T + key)) * 0x9E3779B1u) ^ d.key);
+            const uint32_t bit = ((h >> 8) >= d.thr) ? 1u : 0u;
+            if (ti == 0) lo |= bit << (tj * 16 + r); else hi |= bit << (tj * 16 + r);
+        }
+    }
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+// first / last key block a query block can see, and vice versa (causal + window band)
+VC_DEV int am_kb_lo(int qb, int window) { const int k = qb * AM_T - window + 1; return k > 0 ? k / AM_T : 0; }
+VC_DEV int am_qb_hi(int kb, int window, int nblk) { const int q = (kb * AM_T + AM_T - 1 + window - 1) / AM_T; return q < nblk - 1 ? q : nblk - 1; }
+// A fragment from a row-major [m][k] bf16 LDS tile with the SAME k-slot order the transposed B fragments use
+// (k = k0 + 4h + {0..3, 8..11}): two 8-byte reads
+VC_DEV vc_s16x8 am_frag_kmap(const vc_bf16* tile, int row0, int k0, int lane) {
+    const vc_bf16* p = tile + (row0 + (lane & 31)) * AM_S + k0 + 4 * (lane >> 5);
+    const vc_u32x2 lo = *reinterpret_cast<const vc_u32x2*>(p), hi = *reinterpret_cast<const vc_u32x2*>(p + 8);
+    vc_s16x8 r;
+    r[0] = (short)(lo.x & 0xffffu); r[1] = (short)(lo.x >> 16); r[2] = (short)(lo.y & 0xffffu); r[3] = (short)(lo.y >> 16);
+    r[4] = (short)(hi.x & 0xffffu); r[5] = (short)(hi.x >> 16); r[6] = (short)(hi.y & 0xffffu); r[7] = (short)(hi.y >> 16);
+    return r;
+}
+// write an accumulator grid to an LDS tile as bf16; TRANSPOSE: grid element (register row, lane column) -> tile[column][row]
+template <bool TRANSPOSE>
+VC_DEV void am_grid_to_lds(vc_bf16* tile, const vc_f32x16 (&g)[2][2], int lane) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
+                tile[TRANSPOSE ? col * AM_S + row : row * AM_S + col] = vc_f32_to_bf16(g[ti][tj][r]);
+            }
+}
+// out[m][d] += sum_k A[m][k] Y[k][d]: A row-major LDS tile (k-mapped fragments), Y token-major LDS tile (transposed reads)
+VC_DEV void am_mm_lds_rowA(vc_f32x16 (&out)[2][2], const vc_bf16* A, const vc_bf16* Y, int lane) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        vc_s16x8 a[2], b[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) { a[o] = am_frag_kmap(A, o * 32, 16 * s4, lane); b[o] = am_frag_tr(Y, 16 * s4, o * 32, lane); }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
+    }
+}
+// out[m][d] += sum_k A[k][m] Y[k][d]: both operands token-major LDS tiles (transposed reads)
+VC_DEV void am_mm_lds_colA(vc_f32x16 (&out)[2][2], const vc_bf16* A, const vc_bf16* Y, int lane) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        vc_s16x8 a[2], b[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) { a[o] = am_frag_tr(A, 16 * s4, o * 32, lane); b[o] = am_frag_tr(Y, 16 * s4, o * 32, lane); }
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
+    }
+}
+
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(64) void attn_dec_fwd_long_mfma_kernel(AttnParams p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[2][AM_T * AM_S];
+    const int lane = threadIdx.x;
+    const int T = p.Tq, nblk = (T + AM_T - 1) / AM_T;
+    const int qb = blockIdx.x % nblk; const long bh = blockIdx.x / nblk;
+    const int h = (int)(bh % p.H); const long n = bh / p.H;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH;
+    const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;            // rows of this query block
+    const int kb0 = am_kb_lo(qb, p.window);
+    vc_f32x16 st[AM_MAXB][2][2];
+#pragma unroll
+    for (int i = 0; i < AM_MAXB; ++i) am_zero(st[i]);
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_wave_barrier();
+        am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
+#pragma unroll
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int kb = kb0 + i;
+            if (kb <= qb) {
+                const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
+                vc_wave_barrier();
+                am_stage(tiles[1], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
+                vc_wave_barrier();
+                am_mm_nt(st[i], tiles[1], tiles[0], lane);
+            }
+        }
+    }
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int ql = qt * 32 + (lane & 31);
+        const int query = q0 + (ql < tq ? ql : tq - 1);                       // padding columns: keep the row finite (never stored)
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int kb = kb0 + i;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * AM_T + kt * 32 + am_row(r, lane);
+                    const float sc = (kb <= qb && am_visible(query, key, T, p.window)) ? st[i][kt][qt][r] * p.scale : -INFINITY;
+                    st[i][kt][qt][r] = sc; m = fmaxf(m, sc);
+                }
+        }
+        m = fmaxf(m, vc_shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < AM_MAXB; ++i)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float e = expf(st[i][kt][qt][r] - m); st[i][kt][qt][r] = e; l += e; }
+        l += vc_shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int i = 0; i < AM_MAXB; ++i)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[i][kt][qt][r] *= inv;
+        if (p.lse && lane < 32 && ql < tq) p.lse[(n * p.H + h) * T + q0 + ql] = m + logf(l);
+    }
+    if (DROP) {
+#pragma unroll
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int kb = kb0 + i;
+            if (kb <= qb) {
+                const uint64_t keep = am_keep_bits_g<true>(p.drop, dbase0, T, q0, kb * AM_T, lane);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) st[i][kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_f32x16 o[2][2];
+        am_zero(o);
+#pragma unroll
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int kb = kb0 + i;
+            if (kb <= qb) {
+                const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
+                vc_wave_barrier();
+                am_stage(tiles[0], (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd + c * AM_D, p.ldv, tk, lane);
+                vc_wave_barrier();
+                am_mm_tok(o, st[i], tiles[0], lane);
+            }
+        }
+        am_store((vc_bf16*)p.o + (rowq + q0) * p.ldo + hd + c * AM_D, p.ldo, o, tq, lane, 1.0f);
+    }
+}
+
+// backward, lane = query: D_i and dQ of one query block.  D_i = sum_key P dP is accumulated over the key blocks in a first
+// pass with exactly the P and dP the second pass uses (so a query that sees a single key gets dS == 0 bit-exactly, as in the
+// reference — the rowsum(dO * O) identity would leave rounding noise there that Adam amplifies to lr-sized steps); it is also
+// written to p.delta for the dK/dV kernel that is launched next.
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(64) void attn_dec_bwd_q_long_mfma_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, smem);                             // (4 + AM_MAXB) tiles
+    vc_bf16 (*tiles)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem);                       // Q, dO (query block) ; K, V (key block) chunk
+    vc_bf16 (*dst)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem + 4 * AM_T * AM_S);       // dS[query][key] per key block
+    const int lane = threadIdx.x;
+    const int T = p.Tq, nblk = (T + AM_T - 1) / AM_T;
+    const int qb = blockIdx.x % nblk; const long bh = blockIdx.x / nblk;
+    const int h = (int)(bh % p.H); const long n = bh / p.H;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH;
+    const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;
+    const int kb0 = am_kb_lo(qb, p.window);
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    const float* lse = p.lse + (n * p.H + h) * T + q0;
+    float dsum[2] = {0.f, 0.f};
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int kb = kb0 + i;
+            if (kb > qb) break;
+            const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
+            vc_f32x16 st[2][2], dpt[2][2];
+            am_zero(st); am_zero(dpt);
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                vc_wave_barrier();
+                am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
+                am_stage(tiles[1], (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd + c * AM_D, p.lddo, tq, lane);
+                am_stage(tiles[2], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
+                am_stage(tiles[3], (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd + c * AM_D, p.ldv, tk, lane);
+                vc_wave_barrier();
+                am_mm_nt(st, tiles[2], tiles[0], lane);          // S^T[key][query]
+                am_mm_nt(dpt, tiles[3], tiles[1], lane);         // dP'^T[key][query]
+            }
+            uint64_t keep = 0;
+            if (DROP) keep = am_keep_bits_g<true>(p.drop, dbase0, T, q0, k0, lane);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int ql = qt * 32 + (lane & 31);
+                const bool qok = ql < tq;
+                const float ls = qok ? lse[ql] : 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + kt * 32 + am_row(r, lane);
+                        const bool ok = qok && am_visible(q0 + ql, key, T, p.window);
+                        const float pr = ok ? expf(st[kt][qt][r] * p.scale - ls) : 0.f;
+                        const float dpm = dpt[kt][qt][r] * (DROP ? am_keep(keep, kt, qt, r, p.drop.scale) : 1.0f);   // dP = dP' * mask
+                        if (pass == 0) dsum[qt] += pr * dpm;
+                        else st[kt][qt][r] = pr * (dpm - dsum[qt]);                                                    // dS^T
+                    }
+            }
+            if (pass == 1) am_grid_to_lds<true>(dst[i], st, lane);   // -> [query][key]
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                dsum[qt] += vc_shfl_xor(dsum[qt], 32);
+                const int ql = qt * 32 + (lane & 31);
+                if (lane < 32 && ql < tq) p.delta[(n * p.H + h) * T + q0 + ql] = dsum[qt];
+            }
+        }
+    }
+    vc_wave_barrier();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_f32x16 dq[2][2];
+        am_zero(dq);
+#pragma unroll 1
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int kb = kb0 + i;
+            if (kb > qb) break;
+            const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
+            vc_wave_barrier();
+            am_stage(tiles[2], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
+            vc_wave_barrier();
+            am_mm_lds_rowA(dq, dst[i], tiles[2], lane);      // dQ[query][d] += sum_key dS[query][key] K[key][d]
+        }
+        am_store((vc_bf16*)p.dq + (rowq + q0) * p.lddq + hd + c * AM_D, p.lddq, dq, tq, lane, p.scale);
+    }
+}
+
+// backward, lane = key: dK, dV of one key block
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(64) void attn_dec_bwd_kv_long_mfma_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, smem);                             // 4 + 2 * AM_MAXB tiles = 90 KiB
+    vc_bf16 (*tiles)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem);                                   // Q, dO ; K, V chunk
+    vc_bf16 (*pt)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem + 4 * AM_T * AM_S);                    // P'[query][key] per query block
+    vc_bf16 (*dst)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem + (4 + AM_MAXB) * AM_T * AM_S);       // dS[query][key] per query block
+    const int lane = threadIdx.x;
+    const int T = p.Tq, nblk = (T + AM_T - 1) / AM_T;
+    const int kb = blockIdx.x % nblk; const long bh = blockIdx.x / nblk;
+    const int h = (int)(bh % p.H); const long n = bh / p.H;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH;
+    const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
+    const int qb1 = am_qb_hi(kb, p.window, nblk);
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+#pragma unroll 1
+    for (int i = 0; i < AM_MAXB; ++i) {
+        const int qb = kb + i;
+        if (qb > qb1) break;
+        const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;
+        const float* lse = p.lse + (n * p.H + h) * T + q0;
+        const float* del = p.delta + (n * p.H + h) * T + q0;
+        vc_f32x16 sn[2][2], dp[2][2];
+        am_zero(sn); am_zero(dp);
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            vc_wave_barrier();
+            am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
+            am_stage(tiles[1], (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd + c * AM_D, p.lddo, tq, lane);
+            am_stage(tiles[2], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
+            am_stage(tiles[3], (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd + c * AM_D, p.ldv, tk, lane);
+            vc_wave_barrier();
+            am_mm_nt(sn, tiles[0], tiles[2], lane);          // S[query][key]
+            am_mm_nt(dp, tiles[1], tiles[3], lane);          // dP'[query][key]
+        }
+        uint64_t keep = 0;
+        if (DROP) keep = am_keep_bits_g<false>(p.drop, dbase0, T, q0, k0, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = k0 + kt * 32 + (lane & 31);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = qt * 32 + am_row(r, lane);
+                    const bool ok = ql < tq && am_visible(q0 + ql, key, T, p.window);
+                    const float pr = ok ? expf(sn[qt][kt][r] * p.scale - lse[ql < tq ? ql : 0]) : 0.f;
+                    const float ms = DROP ? am_keep(keep, qt, kt, r, p.drop.scale) : 1.0f;
+                    dp[qt][kt][r] = pr * (dp[qt][kt][r] * ms - (ql < tq ? del[ql] : 0.f));                       // dS
+                    sn[qt][kt][r] = pr * ms;                                                                      // P'
+                }
+        }
+        am_grid_to_lds<false>(pt[i], sn, lane);
+        am_grid_to_lds<false>(dst[i], dp, lane);
+    }
+    vc_wave_barrier();
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        vc_f32x16 dv[2][2], dk[2][2];
+        am_zero(dv); am_zero(dk);
+#pragma unroll 1
+        for (int i = 0; i < AM_MAXB; ++i) {
+            const int qb = kb + i;
+            if (qb > qb1) break;
+            const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;
+            vc_wave_barrier();
+            am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
+            am_stage(tiles[1], (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd + c * AM_D, p.lddo, tq, lane);
+            vc_wave_barrier();
+            am_mm_lds_colA(dv, pt[i], tiles[1], lane);       // dV[key][d] += sum_q P'[q][key] dO[q][d]
+            am_mm_lds_colA(dk, dst[i], tiles[0], lane);      // dK[key][d] += sum_q dS[q][key] Q[q][d]
+        }
+        am_store((vc_bf16*)p.dv + (rowq + k0) * p.lddv + hd + c * AM_D, p.lddv, dv, tk, lane, 1.0f);
+        am_store((vc_bf16*)p.dk + (rowq + k0) * p.lddk + hd + c * AM_D, p.lddk, dk, tk, lane, p.scale);
+    }
+}

@@ -59,4 +59,16 @@ int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void
     return vc_attn_bwd(t, D, p, (vc_stream_t)stream);
 }
 
+// same, with the saved forward output o (lets the long-sequence decoder kernels take D_i = rowsum(dO * O); see attn_mfma.h)
+int vcad_op_attention_bwd_o(int t, int D, const void* q, const void* k, const void* v, const void* o, int64_t ldo, const void* dout, int64_t ldq,
+                            int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
+                            void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
+                            int causal, float scale, void* stream) {
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.o = (void*)o; p.ldo = ldo; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.lse = (float*)lse; p.delta = delta;
+    p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.window = window; p.causal = causal; p.scale = scale;
+    return vc_attn_bwd(t, D, p, (vc_stream_t)stream);
+}
+
 }  // extern "C"

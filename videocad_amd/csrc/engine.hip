@@ -669,7 +669,7 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* kv = (const char*)d.kv_c; char* dkv = (char*)d.g_dkv;
-          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, nullptr, d.lse_c, c.window_size, e->t_dao_d, d.g_dq, dkv, dkv + (size_t)H * es, H, 2 * H,
+          CK(dec_attn(cx, true, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, d.ao_c, d.lse_c, c.window_size, e->t_dao_d, d.g_dq, dkv, dkv + (size_t)H * es, H, 2 * H,
                       cx.site(3, L, Ctx::K_CA))); }
         if (!defer) {
             CK(cx.lin_wgrad(cx.AT(d.g_dq, H), cx.A32(d.x1, H), cx.Gf(w.ca_w), H, cx.Gf(w.ca_b), (int)M, H, H));
@@ -683,7 +683,7 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* q = (const char*)d.qkv_s; char* dq = (char*)d.g_dqkv;
-          CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, nullptr, d.lse_s, sa_window, e->t_dao_d,
+          CK(dec_attn(cx, true, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, sa_window, e->t_dao_d,
                       dq, dq + (size_t)H * es, dq + (size_t)2 * H * es, 3 * H, 3 * H, cx.site(3, L, Ctx::K_SA))); }
         if (!defer) CK(cx.lin_wgrad(cx.AT(d.g_dqkv, 3 * H), cx.A32(xin, H), cx.Gf(w.sa_w), H, cx.Gf(w.sa_b), (int)M, 3 * H, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_dqkv, 3 * H), cx.W(w.sa_w, H), cx.A32(dx, H), (int)M, 3 * H, H, ep)); }

@@ -52,6 +52,20 @@ static bool dec_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
 }
+// ... and for 64 < T <= 192 (key-block loop)
+static bool dec_long_ok(int t, int D, const AttnParams& p, bool bwd) {
+    auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
+    bool ok = t == VC_BF16 && D == 4 * AM_D && p.Tq == p.Tk && p.Tq > AM_T && p.Tq <= AM_MAXB * AM_T && p.causal && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    if (!bwd) return ok && al(p.o, p.ldo);
+    return ok && al(p.dout, p.lddo) && p.lse && p.delta && p.dq && p.dk && p.dv;
+}
+template <typename K> static int set_dyn_lds(K kern, size_t bytes) {
+#ifndef VC_EMU
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+#endif
+    return VC_OK;
+}
 static int check_rows_aligned(int t, const AttnParams& p, bool bwd) {
     const long e = (t == VC_BF16) ? 8 : 4;           // elements per 16 bytes
     auto bad = [&](const void* q, long ld) { return q && (((uintptr_t)q % 16) || (ld % e)); };
@@ -75,6 +89,12 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         return VC_OK;
     }
+    if (dec_long_ok(t, D, p, false)) {
+        const unsigned g = (unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T));
+        if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 4>), dim3(g), dim3(64), 0, s, p);
+        else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 4>), dim3(g), dim3(64), 0, s, p);
+        return VC_OK;
+    }
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
 }
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
@@ -95,6 +115,25 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (dec_mfma_ok(t, D, p, true)) {
         if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        return VC_OK;
+    }
+    if (dec_long_ok(t, D, p, true)) {
+        static bool attr = false;
+        if (!attr) {
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<true, 4>, AM_LONG_Q_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 4>, AM_LONG_Q_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 4>, AM_LONG_KV_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<false, 4>, AM_LONG_KV_LDS)) return rc;
+            attr = true;
+        }
+        const unsigned g = (unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T));
+        if (p.drop.key) {
+            VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<true, 4>), dim3(g), dim3(64), AM_LONG_Q_LDS, s, p);
+            VC_LAUNCH((attn_dec_bwd_kv_long_mfma_kernel<true, 4>), dim3(g), dim3(64), AM_LONG_KV_LDS, s, p);
+        } else {
+            VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<false, 4>), dim3(g), dim3(64), AM_LONG_Q_LDS, s, p);
+            VC_LAUNCH((attn_dec_bwd_kv_long_mfma_kernel<false, 4>), dim3(g), dim3(64), AM_LONG_KV_LDS, s, p);
+        }
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);

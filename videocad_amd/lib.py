@@ -62,6 +62,8 @@ PROTOTYPES = {
     "vcad_op_attention_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "vcad_op_attention_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "vcad_op_attention_bwd_o": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                     _i, _i, _i, _i, _i, _i, _f, _vp]),
 }
 
 
