@@ -95,6 +95,10 @@ int vcad_dlogits_offsets(const vcad_engine* e, size_t* off_cmds, size_t* off_par
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dparams, void* stream);
 /* the same, one DDP bucket at a time (stage 0 .. vcad_bucket_count-1, in order) so the caller can overlap RCCL */
 int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
+/* Stage 1 (the CAD ViT's backward, independent of stages 2-3) on the library's side stream: the caller runs stages 2 and 3
+   and their all-reduces, then vcad_join_side() (its stream waits for stage 1) and only then reduces bucket 1. */
+int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
+int vcad_join_side(vcad_engine* e, void* stream);
 
 /* ---- clip_grad_norm_(max_norm) + Adam.step (reference trainer.py:493-494); step = 1-based Adam step count;
  * grad_scale multiplies gradients first (1/world_size after an all-reduce SUM); norm_out: fp32 [2] = |g|, clip coef */

@@ -266,3 +266,32 @@ def test_f32_other_wirings_match_reference_goldens(golden_dir, case):
         assert float(eng.view(n, eng.grads).abs().max()) == 0.0, n
     norm = eng.optimizer_step(lr=1e-5)
     assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < 1e-3 * float(gold["total_grad_norm"])
+
+
+def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
+    """The data-parallel order (stage 0, stage 1 on the side stream, stages 2-3, join) must produce exactly the gradients of
+    the single-call backward: same kernels, only the stream they are issued on differs."""
+    eng = build(L.VCAD_BF16)
+    B, T = 2, 8
+    batch = synth.make_batch_torch(B, T, 11, DEV, None)
+    fr, ac, cad = batch["frames"], batch["actions"], batch["cad_image"]
+
+    def run(staged):
+        eng.set_dropout(0.1, seed=5)
+        cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
+        eng.loss(cmds, pars, ac[:, 1:])
+        eng.grads.zero_()
+        if not staged:
+            eng.backward()
+        else:
+            eng.backward(stage=0)
+            eng.backward(stage=1, side=True)
+            for st in range(2, len(eng.buckets)):
+                eng.backward(stage=st)
+            eng.join_side()
+        torch.cuda.synchronize()
+        return eng.grads.clone()
+
+    g_whole, g_staged = run(False), run(True)
+    assert bool(torch.equal(g_whole, g_staged)), float((g_whole - g_staged).abs().max())
+    assert float(g_whole.abs().sum()) > 0

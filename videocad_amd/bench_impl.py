@@ -70,12 +70,20 @@ class Stepper:
             eng.backward()
         else:
             cur = torch.cuda.current_stream(eng.device)
-            for st, (lo, hi) in enumerate(eng.buckets):
-                eng.backward(stage=st)
+
+            def reduce_bucket(st):
+                lo, hi = eng.buckets[st]
                 ev = torch.cuda.Event(); ev.record(cur)
                 with torch.cuda.stream(self.comm_stream):
                     self.comm_stream.wait_event(ev)
                     dist.all_reduce(eng.grads[lo:hi])                             # RCCL SUM; the 1/world is folded into Adam
+
+            # same order as trainer.GradSync: the CAD ViT's backward (stage 1) on the engine's side stream, its bucket reduced last
+            eng.backward(stage=0); reduce_bucket(0)
+            eng.backward(stage=1, side=True)
+            for st in range(2, len(eng.buckets)):
+                eng.backward(stage=st); reduce_bucket(st)
+            eng.join_side(); reduce_bucket(1)
             cur.wait_stream(self.comm_stream)
         eng.optimizer_step(lr=1e-5, grad_scale=1.0 / self.world)
         return loss, met

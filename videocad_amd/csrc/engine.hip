@@ -76,7 +76,7 @@ struct vcad_engine {
     float *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
     void *t_df1, *t_dq, *t_dkv, *t_dao_d, *t_dqkv_d;
     Lane lane[2];                 // scratch + ViT-backward temporaries per stream (see Lane)
-    vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false, bwd_side = false;
+    vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false, bwd_side = false, side_pending = false;
     float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
@@ -883,6 +883,25 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
     if (vc_last_launch_error()) { vc_set_error("vcad_backward: kernel launch failed"); return VC_ERR_LAUNCH; }
     return 0;
 }
+// Data-parallel callers: stage 1 (the CAD ViT's backward) launched on the side stream; its bucket may be all-reduced only after
+// vcad_join_side() has made the caller's stream wait for it — so the caller runs stages 2 and 3 (and their all-reduces) first.
+int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dpars, void* stream) {
+    if (stage != 1) { vc_set_error("vcad_backward_stage_side: only stage 1 (CAD ViT) can run on the side stream"); return VC_ERR_ARG; }
+    vc_stream_t s = (vc_stream_t)stream;
+    const bool fork = e->c.enable_past_states && ensure_side(e);
+    if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
+    e->bwd_fork = fork;
+    int rc = vcad_backward_stage(e, 1, dcmds, dpars, stream);
+    e->bwd_fork = false;
+    if (rc) return rc;
+    if (fork) { CK(vc_event_record(e->ev_join, e->side)); e->side_pending = true; }
+    return 0;
+}
+int vcad_join_side(vcad_engine* e, void* stream) {
+    if (e->side_pending) { CK(vc_stream_wait_event((vc_stream_t)stream, e->ev_join)); e->side_pending = false; }
+    return 0;
+}
+
 // Whole backward: after stage 0 (heads + decoder + stem) the CAD ViT's backward (stage 1) is independent of the frame ViT's
 // (stages 2-3), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
 // soon as its stage returns) keeps everything on the caller's stream.

@@ -132,13 +132,20 @@ class NativeEngine:
         dp = self.ws[op.value: op.value + B * T * npar * 4].view(torch.float32).view(B, T, npar)
         return dc, dp
 
-    def backward(self, dcmds=None, dpars=None, stage: Optional[int] = None):
+    def backward(self, dcmds=None, dpars=None, stage: Optional[int] = None, side: bool = False):
+        """stage=None: whole backward.  stage=k: one gradient bucket's worth (data-parallel callers).  side=True (stage 1 only): launch on
+        the library's side stream — call join_side() before touching that bucket's gradients."""
         if dcmds is not None:
             dcmds = dcmds.contiguous().float(); dpars = dpars.contiguous().float()
-        if stage is None:
+        if side:
+            L.check(self.lib, self.lib.vcad_backward_stage_side(self.h, stage, _ptr(dcmds), _ptr(dpars), self.stream()), "backward_stage_side")
+        elif stage is None:
             L.check(self.lib, self.lib.vcad_backward(self.h, _ptr(dcmds), _ptr(dpars), self.stream()), "backward")
         else:
             L.check(self.lib, self.lib.vcad_backward_stage(self.h, stage, _ptr(dcmds), _ptr(dpars), self.stream()), "backward_stage")
+
+    def join_side(self):
+        L.check(self.lib, self.lib.vcad_join_side(self.h, self.stream()), "join_side")
 
     def optimizer_step(self, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0):
         self.step_count += 1

@@ -50,6 +50,8 @@ PROTOTYPES = {
     "vcad_dlogits_offsets": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "vcad_backward": (_i, [_vp, _vp, _vp, _vp]),
     "vcad_backward_stage": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vcad_backward_stage_side": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "vcad_join_side": (_i, [_vp, _vp]),
     "vcad_optimizer_step": (_i, [_vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "vcad_profile_begin": (None, []),
     "vcad_profile_end": (_i, [C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_int * 8)]),

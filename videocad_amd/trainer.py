@@ -64,12 +64,21 @@ class GradSync:
                 self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
             return
         cur = torch.cuda.current_stream(eng.device)
-        for st, (lo, hi) in enumerate(eng.buckets):
-            eng.backward(dcmds, dpars, stage=st)
+
+        def reduce_bucket(st):
+            lo, hi = eng.buckets[st]
             ev = torch.cuda.Event(); ev.record(cur)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
                 self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
+
+        # stage 1 (CAD ViT: ~230 small kernels) runs on the engine's side stream beside the frame ViT's stages 2-3; its bucket is
+        # reduced last, after join_side() has ordered it before `cur`
+        eng.backward(dcmds, dpars, stage=0); reduce_bucket(0)
+        eng.backward(dcmds, dpars, stage=1, side=True)
+        for st in range(2, len(eng.buckets)):
+            eng.backward(dcmds, dpars, stage=st); reduce_bucket(st)
+        eng.join_side(); reduce_bucket(1)
         cur.wait_stream(self.stream)
 
 
