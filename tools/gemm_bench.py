@@ -47,6 +47,14 @@ def both(name, *a, **k):
 
 
 R = 104000
+if len(sys.argv) > 1 and sys.argv[1] == "heads":
+    for tile in (128, 64):
+        lib.vcad_debug_force_gemm_tile(tile)
+        run(f"heads fwd (f32 A, f32 out) tile{tile}", 2080, 6000, 1024, sa=F32, to=F32, bias=True)
+        run(f"heads wgrad (f32 A dlogits, f32 B) tile{tile}", 6000, 1024, 2080, sa=F32, sb=F32, to=F32, tra=1, trb=1)
+        run(f"heads wgrad (bf16 B) tile{tile}", 6000, 1024, 2080, sa=F32, sb=BF, to=F32, tra=1, trb=1)
+        run(f"heads dgrad (f32 A) tile{tile}", 2080, 1024, 6000, sa=F32, to=BF, trb=1)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "nn":
     lib.vcad_debug_gemm_dma(1)
     run("dqkv dgrad as NN (W^T shadow) [dma]", R, 512, 3072)

@@ -146,7 +146,8 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     // 2048-token GEMMs): 4x the blocks and no split-K pass.  Long token reductions still split K.
     long tiles128 = (long)VC_CEIL_DIV(p.M, 128) * VC_CEIL_DIV(p.N, 128);
     // (not for the long token reductions of wgrad: halving the tile doubles operand traffic per FLOP there; those split K instead)
-    const bool small = g_force_tile ? (g_force_tile == 64) : (tiles128 < 256 && p.K <= 4096);
+    // (wgrad layout: up to 512 tiles — the heads' 6000x1024 gradient over 2 080 tokens runs 256 -> 153 us on the small tile)
+    const bool small = g_force_tile ? (g_force_tile == 64) : (tiles128 < (lay == 3 ? 512 : 256) && p.K <= 4096);
     const int BT = small ? 64 : 128;
     long tiles = (long)VC_CEIL_DIV(p.M, BT) * VC_CEIL_DIV(p.N, BT);
     int nsplit = 1;
