@@ -33,6 +33,7 @@ def run(M, N, K, to=BF, tra=0, trb=0, bias=False, iters=3):
 
 
 R = 104000
-run(R, 3072, 512, bias=True)
-run(R, 512, 3072, trb=1)
-run(3072, 512, R, to=F32, tra=1, trb=1)
+run(R, 3072, 512, bias=True)                       # QKV forward
+run(R, 512, 3072)                                  # dqkv dgrad through the transposed weight shadow (k-contiguous)
+run(3072, 512, R, to=F32, tra=1, trb=1)            # QKV wgrad
+run(8192, 8192, 8192)                              # reference point
