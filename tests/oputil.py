@@ -22,6 +22,13 @@ def load_emu():
     return L.declare(C.CDLL(EMU_PATH))
 
 
+def ensure_hip_lib():
+    """the gfx950 product library is git-ignored: cross-compile it (hipcc works without a GPU) when a fresh checkout lacks it"""
+    if not os.path.exists(L.LIB_PATH):
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "videocad_amd", "csrc"), "all"])
+    return L.LIB_PATH
+
+
 def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
