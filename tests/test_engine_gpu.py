@@ -295,3 +295,38 @@ def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
     g_whole, g_staged = run(False), run(True)
     assert bool(torch.equal(g_whole, g_staged)), float((g_whole - g_staged).abs().max())
     assert float(g_whole.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("pa,ps,tse", [(True, False, False), (False, True, True), (False, False, False)])
+def test_bf16_train_mode_other_wirings(pa, ps, tse):
+    """Throughput-mode train step (dropout on: deferred grouped decoder wgrads, LayerNorm-fused masked copies, side stream only when
+    the frame ViT exists) on the three non-canonical wirings: its gradients must agree with the SAME engine run in eval-style
+    ordering — p = 0.1 masks are part of both runs, but the second goes through the staged entry point (no side stream, no
+    deferral to it) — and two identical runs must be bitwise equal."""
+    cfg = dict(O.CANONICAL_CONFIG)
+    cfg.update(enable_past_actions=pa, enable_past_states=ps, enable_timestep_embedding=tse)
+    keys = CFG_KEYS + ("enable_past_actions", "enable_past_states", "enable_timestep_embedding")
+    eng = NativeEngine(make_config(dtype=L.VCAD_BF16, **{k: cfg[k] for k in keys}), DEV)
+    for k, sh in O.param_shapes(cfg).items():
+        eng.view(k).copy_(synth.make_param_torch(k, sh, DEV))
+    eng.sync_shadow()
+    batch = synth.make_batch_torch(2, 6, 21, DEV, None)
+    fr, ac, cad = batch["frames"], batch["actions"], batch["cad_image"]
+
+    def run(staged):
+        eng.set_dropout(0.1, seed=9)
+        cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
+        loss, _ = eng.loss(cmds, pars, ac[:, 1:])
+        eng.grads.zero_()
+        if staged:
+            for st in range(len(eng.buckets)):
+                eng.backward(stage=st)
+        else:
+            eng.backward()
+        torch.cuda.synchronize()
+        return float(loss[0]), eng.grads.clone()
+
+    l1, g1 = run(False); l2, g2 = run(False); l3, g3 = run(True)
+    assert np.isfinite(l1) and bool(torch.isfinite(g1).all()) and float(g1.abs().sum()) > 0
+    assert l1 == l2 and bool(torch.equal(g1, g2)), "train step is not deterministic"
+    assert bool(torch.equal(g1, g3)), float((g1 - g3).abs().max())
