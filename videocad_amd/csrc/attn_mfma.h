@@ -146,24 +146,57 @@ VC_DEV void am_store(vc_bf16* g, long ld, const vc_f32x16 (&acc)[2][2], int T, i
 // packed into one 64-bit word so the mask costs 2 registers instead of 64 live multipliers.
 // bit (ti*2 + tj)*16 + r  <->  element (row = ti*32 + am_row(r), lane column = tj*32 + (lane&31)) of a grid whose rows are
 // keys and columns queries when QCOL, else rows = queries and columns = keys.   idx = base + query*T + key.
+// (q0, k0: global offsets of the 64x64 block, multiples of 64.)  One hash serves two consecutive elements (vc_rt.h): with T even
+// an aligned key pair of one query shares it, so
+//   QCOL  (registers walk the keys)   : accumulator registers r = 2j, 2j+1 hold keys k, k+1 — one hash per register pair;
+//   !QCOL (registers walk the queries): lanes l, l^1 hold keys k, k+1 of the same queries — each computes the hashes of every other
+//                                        register row and they swap (one xor-1 shuffle per hash);
+// odd T (never the case for the canonical 50-token ViT / even horizons) falls back to one hash per element.
 template <bool QCOL>
-VC_DEV uint64_t am_keep_bits(const vc_drop& d, uint32_t base, int T, int lane) {
-    uint32_t lo = 0, hi = 0;                  // tiles (0,0),(0,1) -> lo ; (1,0),(1,1) -> hi   (rolled loop: keeps register pressure flat)
+VC_DEV uint64_t am_keep_bits_g(const vc_drop& d, uint32_t base, int T, int q0, int k0, int lane) {
+    uint32_t lo = 0, hi = 0;                  // tiles (0,0),(0,1) -> lo ; (1,0),(1,1) -> hi   (rolled loops: keep register pressure flat)
+    if ((T & 1) == 0) {
 #pragma unroll 1
-    for (int r = 0; r < 16; ++r) {
+        for (int j = 0; j < 8; ++j) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ti = t >> 1, tj = t & 1;
-            const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
-            const int query = QCOL ? col : row, key = QCOL ? row : col;
-            const uint32_t h = vc_hash32(((base + (uint32_t)(query * T + key)) * 0x9E3779B1u) ^ d.key);
-            const uint32_t bit = ((h >> 8) >= d.thr) ? 1u : 0u;
-            if (ti == 0) lo |= bit << (tj * 16 + r); else hi |= bit << (tj * 16 + r);
+            for (int t = 0; t < 4; ++t) {
+                const int ti = t >> 1, tj = t & 1;
+                const int col = tj * 32 + (lane & 31);
+                uint32_t b0, b1;              // keep bits of registers 2j and 2j + 1
+                if (QCOL) {
+                    const int key = k0 + ti * 32 + am_row(2 * j, lane);                       // even; register 2j+1 holds key + 1
+                    const uint32_t h = vc_drop_hash(d, (base + (uint32_t)((q0 + col) * T + key)) >> 1);
+                    b0 = vc_drop_keep_lo(d, h) ? 1u : 0u; b1 = vc_drop_keep_hi(d, h) ? 1u : 0u;
+                } else {
+                    const int par = lane & 1;                                                 // this lane hashes register row 2j + par
+                    const int query = q0 + ti * 32 + am_row(2 * j + par, lane);
+                    const uint32_t mine = vc_drop_hash(d, (base + (uint32_t)(query * T + k0 + (col & ~1))) >> 1);
+                    const uint32_t other = (uint32_t)vc_shfl_xor((int)mine, 1);               // partner lane: same key pair, row 2j + 1 - par
+                    const uint32_t h0 = par ? other : mine, h1 = par ? mine : other;          // hashes of rows 2j, 2j + 1
+                    b0 = ((col & 1) ? vc_drop_keep_hi(d, h0) : vc_drop_keep_lo(d, h0)) ? 1u : 0u;
+                    b1 = ((col & 1) ? vc_drop_keep_hi(d, h1) : vc_drop_keep_lo(d, h1)) ? 1u : 0u;
+                }
+                const uint32_t two = (b0 | (b1 << 1)) << (tj * 16 + 2 * j);
+                if (ti == 0) lo |= two; else hi |= two;
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ti = t >> 1, tj = t & 1;
+                const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
+                const int query = q0 + (QCOL ? col : row), key = k0 + (QCOL ? row : col);
+                const uint32_t bit = vc_drop_keep(d, base + (uint32_t)(query * T + key)) ? 1u : 0u;
+                if (ti == 0) lo |= bit << (tj * 16 + r); else hi |= bit << (tj * 16 + r);
+            }
         }
     }
-    const uint64_t bits = (uint64_t)lo | ((uint64_t)hi << 32);
-    return bits;
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
+template <bool QCOL>
+VC_DEV uint64_t am_keep_bits(const vc_drop& d, uint32_t base, int T, int lane) { return am_keep_bits_g<QCOL>(d, base, T, 0, 0, lane); }
 VC_DEV float am_keep(uint64_t bits, int ti, int tj, int r, float scale) { return ((bits >> ((ti * 2 + tj) * 16 + r)) & 1) ? scale : 0.0f; }
 
 template <bool DROP>
@@ -532,24 +565,6 @@ VC_KERNEL __launch_bounds__(128, 1) void attn_dec_bwd_mfma_kernel(AttnParams p) 
 constexpr int AM_MAXB = 3;
 constexpr size_t AM_LONG_Q_LDS = (size_t)(4 + AM_MAXB) * AM_T * AM_S * 2, AM_LONG_KV_LDS = (size_t)(4 + 2 * AM_MAXB) * AM_T * AM_S * 2;
 
-// keep-bits with global (query, key) offsets of the block pair
-template <bool QCOL>
-VC_DEV uint64_t am_keep_bits_g(const vc_drop& d, uint32_t base, int T, int q0, int k0, int lane) {
-    uint32_t lo = 0, hi = 0;
-#pragma unroll 1
-    for (int r = 0; r < 16; ++r) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ti = t >> 1, tj = t & 1;
-            const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
-            const int query = q0 + (QCOL ? col : row), key = k0 + (QCOL ? row : col);
-            const uint32_t h = vc_hash32(((base + (uint32_t)(query * T + key)) * 0x9E3779B1u) ^ d.key);
-            const uint32_t bit = ((h >> 8) >= d.thr) ? 1u : 0u;
-            if (ti == 0) lo |= bit << (tj * 16 + r); else hi |= bit << (tj * 16 + r);
-        }
-    }
-    return (uint64_t)lo | ((uint64_t)hi << 32);
-}
 // first / last key block a query block can see, and vice versa (causal + window band)
 VC_DEV int am_kb_lo(int qb, int window) { const int k = qb * AM_T - window + 1; return k > 0 ? k / AM_T : 0; }
 VC_DEV int am_qb_hi(int kb, int window, int nblk) { const int q = (kb * AM_T + AM_T - 1 + window - 1) / AM_T; return q < nblk - 1 ? q : nblk - 1; }

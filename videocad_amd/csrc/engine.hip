@@ -298,10 +298,7 @@ struct Ctx {
     enum { K_EMB = 1, K_ATTN = 2, K_OUT = 3, K_MLP_ACT = 4, K_MLP_OUT = 5, K_SA = 6, K_SA_OUT = 7, K_CA = 8, K_CA_OUT = 9, K_FF_ACT = 10, K_FF_OUT = 11 };
     vc_drop site(int module, int layer, int kind) const {
         vc_drop d = {0u, 0u, 1.0f};
-        if (e->drop_p > 0.f) {
-            d.key = vc_drop_key(e->drop_seed, ((uint32_t)module << 16) | ((uint32_t)layer << 8) | (uint32_t)kind);
-            d.thr = (uint32_t)(e->drop_p * 16777216.0f); d.scale = 1.0f / (1.0f - e->drop_p);
-        }
+        if (e->drop_p > 0.f) d = vc_drop_make(vc_drop_key(e->drop_seed, ((uint32_t)module << 16) | ((uint32_t)layer << 8) | (uint32_t)kind), e->drop_p);
         return d;
     }
     // masked copy of a residual-stream gradient: du = dx * mask (type T, compact [rows, cols]); returns the matrix to feed wgrad / dgrad

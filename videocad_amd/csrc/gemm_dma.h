@@ -103,8 +103,8 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
         for (int k = 0; k < 4; ++k) v[k] = vc_apply_act(v[k], p.act);
     }
     if (p.drop.key) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] *= vc_drop_mul(p.drop, (long)m * p.N + n + k);
+        { float dm[4]; vc_drop_mul4(p.drop, (uint32_t)((long)m * p.N + n), dm);
+          for (int k = 0; k < 4; ++k) v[k] *= dm[k]; }
     }
     if (p.dact_src) {
         float s4[4];

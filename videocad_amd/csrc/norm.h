@@ -95,7 +95,7 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
             for (int i = 0; i < VPL; ++i) c[i] += q[i];
             if (p.drop.key) {
 #pragma unroll
-                for (int i = 0; i < VPL; ++i) c[i] *= vc_drop_mul(p.drop, row * C + (i / 4) * 256 + lane * 4 + (i % 4));
+                for (int q4 = 0; q4 < VPL / 4; ++q4) { float dm[4]; vc_drop_mul4(p.drop, (uint32_t)(row * C + q4 * 256 + lane * 4), dm); for (int k = 0; k < 4; ++k) c[q4 * 4 + k] *= dm[k]; }
             }
             row_store<float, VPL>(p.y32 + row * p.ldy32, c, lane);
             return;
@@ -117,7 +117,7 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
         for (int i = 0; i < VPL; ++i) v[i] += q[i];
         if (p.drop.key) {
 #pragma unroll
-            for (int i = 0; i < VPL; ++i) v[i] *= vc_drop_mul(p.drop, row * C + (i / 4) * 256 + lane * 4 + (i % 4));
+            for (int q4 = 0; q4 < VPL / 4; ++q4) { float dm[4]; vc_drop_mul4(p.drop, (uint32_t)(row * C + q4 * 256 + lane * 4), dm); for (int k = 0; k < 4; ++k) v[q4 * 4 + k] *= dm[k]; }
         }
     }
     if (p.y32) row_store<float, VPL>(p.y32 + out_row * p.ldy32, v, lane);
@@ -179,7 +179,7 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
             if (p.dxt) {
                 if (p.drop.key) {
 #pragma unroll
-                    for (int i = 0; i < VPL; ++i) dx[i] *= vc_drop_mul(p.drop, row * C + (i / 4) * 256 + lane * 4 + (i % 4));
+                    for (int q4 = 0; q4 < VPL / 4; ++q4) { float dm[4]; vc_drop_mul4(p.drop, (uint32_t)(row * C + q4 * 256 + lane * 4), dm); for (int k = 0; k < 4; ++k) dx[q4 * 4 + k] *= dm[k]; }
                 }
                 row_store<TY, VPL>((TY*)p.dxt + row * p.lddxt, dx, lane);
             }
@@ -241,8 +241,8 @@ VC_KERNEL __launch_bounds__(256) void dropout_mul_kernel(const float* in, long l
     const long r = i / cols; const int c = (int)(i % cols);
     float v[4];
     quad_load<float>(in + r * ld_in + c, v);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] *= vc_drop_mul(d, i + k);
+    { float dm[4]; vc_drop_mul4(d, (uint32_t)i, dm);                              // i is a multiple of 4
+      for (int k = 0; k < 4; ++k) v[k] *= dm[k]; }
     quad_store<TY>(out + r * ld_out + c, v);
 }
 

@@ -213,19 +213,36 @@ VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_b
 VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
-// ---- dropout: counter-based, stateless.  keep-multiplier of element `idx` at a site = (hash(key, idx) >= thr) ? scale : 0,
-// so the backward regenerates exactly the forward's mask from (key, idx) — no mask tensors in HBM.
-// key = vc_drop_key(step seed, site id) (0 = disabled), thr = p * 2^24, scale = 1 / (1 - p).
+// ---- dropout: counter-based, stateless.  One 32-bit hash serves TWO consecutive elements (12-bit draws from bits 8..19 and
+// 20..31): keep-multiplier of element idx at a site = (draw(hash(key, idx >> 1), idx & 1) >= thr) ? scale : 0, so the backward
+// regenerates exactly the forward's mask from (key, idx) — no mask tensors in HBM — and aligned runs of elements pay half a
+// hash each (the two integer multiplies of the mixer are quarter-rate VALU on CDNA).
+// key = vc_drop_key(step seed, site id) (0 = disabled), thr = round(p * 4096), scale = 4096 / (4096 - thr) (unbiased for the
+// effective p = thr / 4096; p = 0.1 -> 0.10010).
 struct vc_drop { uint32_t key, thr; float scale; };
 VC_HD uint32_t vc_hash32(uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
 VC_HD uint32_t vc_drop_key(uint64_t seed, uint32_t site) {
     uint32_t k = vc_hash32((uint32_t)seed ^ vc_hash32((uint32_t)(seed >> 32) + 0x9E3779B9u * (site + 1u)));
     return k | 1u;
 }
+VC_HD vc_drop vc_drop_make(uint32_t key, float p) {
+    vc_drop d; d.key = key; d.thr = (uint32_t)(p * 4096.0f + 0.5f); d.scale = 4096.0f / (float)(4096u - d.thr);
+    return d;
+}
+VC_HD uint32_t vc_drop_hash(const vc_drop& d, uint32_t pair) { return vc_hash32((pair * 0x9E3779B1u) ^ d.key); }          // pair = idx >> 1
+VC_HD bool vc_drop_keep_lo(const vc_drop& d, uint32_t h) { return ((h >> 8) & 0xFFFu) >= d.thr; }                           // even idx
+VC_HD bool vc_drop_keep_hi(const vc_drop& d, uint32_t h) { return (h >> 20) >= d.thr; }                                     // odd idx
 // element indices are 32-bit: every site has < 2^32 elements (checked on the host when the workspace is planned)
-VC_HD float vc_drop_mul(const vc_drop& d, uint32_t idx) {
-    const uint32_t h = vc_hash32((idx * 0x9E3779B1u) ^ d.key);
-    return ((h >> 8) >= d.thr) ? d.scale : 0.0f;
+VC_HD bool vc_drop_keep(const vc_drop& d, uint32_t idx) {
+    const uint32_t h = vc_drop_hash(d, idx >> 1);
+    return (idx & 1u) ? vc_drop_keep_hi(d, h) : vc_drop_keep_lo(d, h);
+}
+VC_HD float vc_drop_mul(const vc_drop& d, uint32_t idx) { return vc_drop_keep(d, idx) ? d.scale : 0.0f; }
+// four consecutive elements starting at an EVEN index: two hashes
+VC_HD void vc_drop_mul4(const vc_drop& d, uint32_t idx, float (&m)[4]) {
+    const uint32_t h0 = vc_drop_hash(d, idx >> 1), h1 = vc_drop_hash(d, (idx >> 1) + 1u);
+    m[0] = vc_drop_keep_lo(d, h0) ? d.scale : 0.0f; m[1] = vc_drop_keep_hi(d, h0) ? d.scale : 0.0f;
+    m[2] = vc_drop_keep_lo(d, h1) ? d.scale : 0.0f; m[3] = vc_drop_keep_hi(d, h1) ? d.scale : 0.0f;
 }
 
 #define VC_CEIL_DIV(a, b) (((a) + (b) - 1) / (b))
