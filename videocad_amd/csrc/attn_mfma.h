@@ -201,14 +201,14 @@ VC_DEV float am_keep(uint64_t bits, int ti, int tj, int r, float scale) { return
 
 template <bool DROP>
 VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
-    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[3][AM_T * AM_S];
+    // two LDS tiles (18 KB): V takes Q's tile once S is in registers — 8 instead of 5 single-wave workgroups per CU
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[2][AM_T * AM_S];
     const int lane = threadIdx.x;
     const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
     const int T = p.Tq;
     const long rowq = n * T;
     am_stage(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, lane);
     am_stage(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, lane);
-    am_stage(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, lane);
     vc_wave_barrier();
     const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
     uint64_t keep = 0;
@@ -216,6 +216,8 @@ VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
     vc_f32x16 st[2][2];                       // S^T: [key tile][query tile], lane column = query
     am_zero(st);
     am_mm_nt(st, tiles[1], tiles[0], lane);
+    vc_wave_barrier();                        // Q's fragments are consumed: its tile now receives V (the load overlaps the softmax)
+    am_stage(tiles[0], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, lane);
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         float m = -INFINITY;
@@ -242,9 +244,10 @@ VC_KERNEL __launch_bounds__(64) void attn_vit_fwd_mfma_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) st[kt][qt][r] *= DROP ? inv * am_keep(keep, kt, qt, r, p.drop.scale) : inv;
         if (p.lse && lane < 32 && query < T) p.lse[(n * p.H + h) * T + query] = m + logf(l);
     }
+    vc_wave_barrier();
     vc_f32x16 o[2][2];
     am_zero(o);
-    am_mm_tok(o, st, tiles[2], lane);        // O[query][d] = sum_key P[query][key] V[key][d]
+    am_mm_tok(o, st, tiles[0], lane);        // O[query][d] = sum_key P[query][key] V[key][d]
     am_store((vc_bf16*)p.o + rowq * p.ldo + h * AM_D, p.ldo, o, T, lane, 1.0f);
 }
 
