@@ -524,3 +524,22 @@ VC_KERNEL __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmParams p, in
     const int n = (int)(idx % p.N);
     gemm_epilogue_store<TO>(p, (int)(idx / p.N), n, s, p.bias ? p.bias[n] : 0.0f);
 }
+
+// same, four consecutive columns per thread (16-byte slab reads, the vector epilogue): used whenever the row-wise epilogue is legal
+template <typename TO>
+VC_KERNEL __launch_bounds__(256) void gemm_splitk_reduce4_kernel(GemmParams p, int nsplit) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;               // quad index
+    const long total = (long)p.M * p.N;
+    if (q * 4 >= total) return;
+    const long idx = q * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nsplit; ++z) {
+        float v[4]; quad_ld_f32(p.partial + (long)z * total + idx, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += v[k];
+    }
+    const int n = (int)(idx % p.N), m = (int)(idx / p.N);
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) quad_ld_f32(p.bias + n, b4);
+    gemm_epilogue_quad<TO>(p, m, n, s, b4);
+}

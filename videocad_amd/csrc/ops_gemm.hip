@@ -63,7 +63,8 @@ static int gemm_launch_wt(GemmCall c, int nsplit, vc_stream_t s) {
     VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>), grid, dim3(GEMM_THREADS), lds, s, c.p);
     if (nsplit > 1) {
         long total = (long)c.p.M * c.p.N;
-        VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total, 256)), dim3(256), 0, s, c.p, nsplit);
+        if (c.p.vecC && c.p.N % 4 == 0) VC_LAUNCH((gemm_splitk_reduce4_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total / 4, 256)), dim3(256), 0, s, c.p, nsplit);
+        else VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total, 256)), dim3(256), 0, s, c.p, nsplit);
     }
     return VC_OK;
 }

@@ -24,7 +24,8 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GD_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;
-        VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot, 256)), dim3(256), 0, s, c.p, nsplit);
+        if (c.p.vecC && c.p.N % 4 == 0) VC_LAUNCH((gemm_splitk_reduce4_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot / 4, 256)), dim3(256), 0, s, c.p, nsplit);
+        else VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot, 256)), dim3(256), 0, s, c.p, nsplit);
     }
     return VC_OK;
 }
