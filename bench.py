@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """bench.py — training frames/s of the VideoCAD behaviour-cloning step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU over RCCL — under torch.distributed.run the ranks
+                                                          come from the launcher; run directly, bench.py spawns its N ranks itself)
 
-One step = BaseTrainer._process_batch on one synthetic loader-shaped batch already resident in HBM:
+One step = videocad_amd.trainer.BaseTrainer.train_step (what _process_batch calls) on one synthetic loader-shaped batch resident in HBM:
 forward -> fused loss -> backward -> (gradient all-reduce over RCCL, overlapped, N > 1) -> clip(1.0) -> Adam.
 Prints ONE JSON line on rank 0.
 """
@@ -31,10 +32,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seq186", action="store_true", help="skip the extra seq_len=186 measurement reported beside the headline config")
     ap.add_argument("--gemm-dma", type=int, default=-1, help="A/B switch: 0 = register-staged GEMM only, -1 = automatic (default)")
+    ap.add_argument("--uint8-frames", action="store_true", help="feed uint8 grayscale pixels (normalised inside the patchify kernel) instead of fp32 frames")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (pinned host -> HBM staged) measurement reported beside the headline")
+    ap.add_argument("--profile-only", action="store_true", help="rocprofv3 runs: only the headline workload's train steps (no seq-186 / PCIe / parity / CPU-baseline legs)")
     args = ap.parse_args()
+    if args.profile_only:
+        args.no_cpu_baseline = args.no_seq186 = args.no_pcie = args.no_parity = True
 
-    from videocad_amd.bench_impl import run
-    run(args)
+    from videocad_amd.bench_impl import launch
+    launch(args)
 
 
 if __name__ == "__main__":

@@ -75,16 +75,28 @@ int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kin
 /* ---- AutoRegressiveTransformer.forward (reference model/autoregressive_transformer.py:121-220)
  * frames: fp32, frame (b,t) at frames + b*frame_bstride + t*S*S  (so batch['frames'][:, :-1] needs no copy)
  * actions_norm: fp32 [B,T,7] already normalised (reference trainer.py:800-804); cad: fp32 [B,1,S,S]
- * cmds_out fp32 [B,T,num_classes], params_out fp32 [B,T,num_params*num_params_values] */
+ * cmds_out fp32 [B,T,num_classes], params_out fp32 [B,T,num_params*num_params_values]
+ * Limits: 1 <= T <= 192 (the decoder attention kernels hold at most three 64-key blocks; the dataset's maximum horizon is
+ * 186, reference README.md:40 — max_ep_len = 1000 only sizes the timestep table) and B*T*50*3072 < 2^32 (dropout indices). */
 int vcad_forward(vcad_engine* e, const float* frames, int64_t frame_bstride, const float* actions_norm, const float* cad,
                  int B, int T, float* cmds_out, float* params_out, void* stream);
 
+/* The same with the loader's native pixels: frames / cad are uint8 GRAYSCALE (PIL 'L' of the stored frames, reference
+ * data_loader.py:441-447; cv2 BGR2GRAY of the CAD render, :471-476) and torchvision's ToTensor + Normalize(0.5, 0.5) (reference
+ * main.py:103-108) is applied inside the patchify kernels with the same fp32 operations — bit-identical patch vectors, a quarter
+ * of the PCIe / HBM bytes.  frame_bstride in BYTES(= pixels); pointers and stride 4-byte aligned. */
+int vcad_forward_u8(vcad_engine* e, const uint8_t* frames, int64_t frame_bstride, const float* actions_norm, const uint8_t* cad,
+                    int B, int T, float* cmds_out, float* params_out, void* stream);
+
 /* ---- MultiClassesTrainer.compute_loss (reference trainer.py:935-1063, flexible_cross_entropy :853-917)
- * targets: fp32 [B*T,7] = raw batch['actions'][:, 1:]; class_weights: fp32 [6][1000] (use_mse = 0) or NULL
+ * targets: fp32 [B*T,7] = raw batch['actions'][:, 1:]
+ * label_weights: HOST pointer, 5 floats = class_weights.json["Label"] as the caller read it from ./class_weights.json
+ *   (reference trainer.py:822-825: the command-CE class weights AND, through [0,0,1,1,2,3], the six per-head multipliers :962)
+ * class_weights: DEVICE fp32 [6][1000] per-class CE weights of the six parameter heads (use_mse = 0) or NULL (use_mse = 1)
  * loss_out: fp32 [8] = total, cmd, param0..5;  metrics_out: int32 [32] (slots in loss.h)
  * also leaves d(loss)/d(logits) in the workspace for vcad_backward(NULL, NULL) */
 int vcad_loss(vcad_engine* e, const float* cmds, const float* params, const float* targets, int B, int T, int use_mse,
-              const float* class_weights, float* loss_out, int32_t* metrics_out, void* stream);
+              const float* label_weights, const float* class_weights, float* loss_out, int32_t* metrics_out, void* stream);
 
 /* byte offsets (inside the caller's workspace) of the d(loss)/d(logits) tensors vcad_loss wrote: fp32 [B*T,5], [B*T,6000] */
 int vcad_dlogits_offsets(const vcad_engine* e, size_t* off_cmds, size_t* off_params);
@@ -105,16 +117,40 @@ int vcad_join_side(vcad_engine* e, void* stream);
 int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, float eps, float max_norm, int step,
                         float grad_scale, float* norm_out, void* stream);
 
+/* per-bucket learning rates (lr_per_bucket: HOST, vcad_bucket_count() floats): the reference's `frozen` mode (trainer.py:237-251)
+ * gives cad_embedding_model, state_embedding_model and the rest their own lr = buckets 1, 2-3 and 0; the clip norm stays global */
+int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_per_bucket, float beta1, float beta2, float eps, float max_norm,
+                               int step, float grad_scale, float* norm_out, void* stream);
+
+/* ---- AutoRegressiveTransformer.sequential_inference (reference model/autoregressive_transformer.py:222-275), incrementally:
+ * the reference re-encodes the whole prefix at every step (O(T^2) ViT passes per clip); the model is causal, so each step here
+ * encodes ONE new frame per clip and attends to cached per-layer keys / values.  eval mode (dropout off) regardless of
+ * vcad_set_dropout.  The caller's workspace must hold vcad_infer_workspace_bytes(B, Tmax).
+ *   vcad_infer_begin : CAD ViT + embed_image (+ its image_projection term), resets the caches; cad fp32 [B,1,S,S] (or uint8, _u8)
+ *   vcad_infer_step  : steps t = 0, 1, ... in order; frame = frame t of every clip (clip b at frame + b*frame_bstride, same pixel
+ *                      type as begin), action_norm fp32 [B,7] = the (normalised) action fed at position t (zeros, or the masked
+ *                      arg-max of step t-1, reference :249-263); cmds_out fp32 [B,5], params_out fp32 [B,6000] = logits of step t */
+size_t vcad_infer_workspace_bytes(const vcad_engine* e, int B, int Tmax);
+int vcad_infer_begin(vcad_engine* e, const float* cad, int B, int Tmax, void* stream);
+int vcad_infer_begin_u8(vcad_engine* e, const uint8_t* cad, int B, int Tmax, void* stream);
+int vcad_infer_step(vcad_engine* e, int t, const void* frame, int64_t frame_bstride, const float* action_norm,
+                    float* cmds_out, float* params_out, void* stream);
+
 /* ---- optional HIP-event profiler: per kernel family (8 categories: gemm fwd/dgrad/wgrad, attention, norm, loss,
  * optimiser, other) elapsed ms, algorithmic FLOPs, algorithmic bytes, launches — measured on the launch stream. */
 void vcad_profile_begin(void);
 int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launches[8]);
 
-/* test hook: force the GEMM block tile (64 or 128; 0 = automatic choice by problem size) */
+/* ---- test / ablation hooks.  These (and the profiler switch above) are the ONLY process-global state of the library; they
+ * select between kernels that compute the same result and are never touched by the product path (videocad_amd/*.py).
+ * force the GEMM block tile (64 or 128; 0 = automatic choice by problem size) */
 void vcad_debug_force_gemm_tile(int tile);
-/* -1 automatic, 0 never, 1 whenever legal: routes bf16 GEMMs through the persistent DMA-fed kernel (tests) */
+/* -1 automatic, 0 never, 1 whenever legal: routes bf16 GEMMs through the persistent DMA-fed kernel (tests, bench A/B) */
 void vcad_debug_gemm_dma(int mode);
 long vcad_debug_gemm_dma_launches(void);
+/* ablation (tools/gemm_ablate*.py): start-offset of the first wave / bit mask of pipeline stages to skip; 0 = off */
+void vcad_debug_gemm_stagger(int n);
+void vcad_debug_gemm_skip(int mask);
 
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,

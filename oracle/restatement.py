@@ -276,10 +276,12 @@ def flexible_ce(logits: Tensor, targets: Tensor, tolerance: int) -> Tensor:
 
 
 def compute_loss(cmds: Tensor, params: Tensor, actions: Tensor, use_mse: bool = True,
-                 class_weights: Optional[dict] = None) -> Tuple[Tensor, dict]:
-    """actions = raw (un-normalised) batch['actions'][:, 1:]  (trainer.py:490, 935-1063)."""
+                 class_weights: Optional[dict] = None, label_weights=None) -> Tuple[Tensor, dict]:
+    """actions = raw (un-normalised) batch['actions'][:, 1:]  (trainer.py:490, 935-1063).
+    label_weights: class_weights.json["Label"] as the trainer read it (trainer.py:822-825); default = the shipped file's values."""
     actions = actions.long()
     a_cmd, a_par = actions[..., 0], actions[..., 1:]
+    LABEL_WEIGHTS = list(label_weights) if label_weights is not None else globals()["LABEL_WEIGHTS"]
     w = torch.tensor(LABEL_WEIGHTS, dtype=torch.float32)
     loss_cmd = F.cross_entropy(cmds.reshape(-1, 5), a_cmd.reshape(-1), weight=w, ignore_index=-1)
     loss_params = 0

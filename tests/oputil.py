@@ -1,5 +1,6 @@
 """Shared op-level parity checks: the same functions drive the CPU emulator build (tests/emu/libvcad_emu.so,
 host pointers) and the real HIP library (device pointers), comparing each kernel with plain PyTorch fp32 math."""
+import contextlib
 import ctypes as C
 import math
 import os
@@ -20,6 +21,28 @@ def load_emu():
             if f.endswith((".h", ".hip"))):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "videocad_amd", "csrc"), "emu"])
     return L.declare(C.CDLL(EMU_PATH))
+
+
+_EMU = None
+
+
+@contextlib.contextmanager
+def emulated():
+    """Route `videocad_amd.lib.load()` to the host-emulator build for the duration (tests only — the product has no such
+    switch: it loads csrc/libvcad_hip.so or raises)."""
+    global _EMU
+    if _EMU is None:
+        _EMU = load_emu()
+    old = L._lib
+    L._lib = _EMU
+    try:
+        yield _EMU
+    finally:
+        L._lib = old
+
+
+LABEL_W = [0.04332685213392362, 0.02915898563179938, 0.267566828114559, 0.6005346809501417, 0.05941265316957628]
+# ^ tests/golden/class_weights.json "Label" (the trainer reads the file; engine-level tests pass the list)
 
 
 def ensure_hip_lib():

@@ -57,19 +57,27 @@ def test_state_dict_matches_appendix_b_and_factory_surface():
 
 
 def small_model(emu, **over):
-    cfg = dict(CANON); cfg.update(num_decoder_layers=1, window_size=2, max_ep_len=8, compute_dtype="f32", _lib=emu, vit_depth=1); cfg.update(over)
+    cfg = dict(CANON); cfg.update(num_decoder_layers=1, window_size=2, max_ep_len=8, compute_dtype="f32", vit_depth=1); cfg.update(over)
     ocfg = dict(O.CANONICAL_CONFIG); ocfg.update(vit_depth=1, num_decoder_layers=1, window_size=2, max_ep_len=8)
     return cfg, ocfg
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def emu():
-    return U.load_emu()
+    with U.emulated() as e:
+        yield e
+
+
+def _cwd_with_class_weights(tmp_path):
+    import shutil
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), os.path.join(str(tmp_path), "class_weights.json"))
+    os.chdir(str(tmp_path))
 
 
 def test_autograd_bridge_and_trainer_step_under_emulator(emu, tmp_path, monkeypatch):
     """model(inputs) -> torch loss -> loss.backward() gives the oracle's gradients; trainer._process_batch == oracle step."""
     monkeypatch.chdir(tmp_path)
+    _cwd_with_class_weights(tmp_path)
     # depth-reduced model (vit_depth=1, 1 decoder layer), B=1, T=2: the emulator executes every lane as a fiber
     cfg, ocfg = small_model(emu)
     model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
@@ -103,20 +111,25 @@ def test_autograd_bridge_and_trainer_step_under_emulator(emu, tmp_path, monkeypa
 
 def _ddp_worker(rank, world, port, tmp, q):
     import torch.distributed as dist
-    os.chdir(tmp)
+    _cwd_with_class_weights(tmp)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
-        emu = U.load_emu()
-        cfg, ocfg = small_model(emu)
+        L._lib = U.load_emu()                        # this process only ever runs the emulator build
+        cfg, ocfg = small_model(None)
+        torch.manual_seed(1234 + rank)               # every rank draws DIFFERENT initial weights (the reference seeds nothing) ...
         model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
         shapes = O.param_shapes(ocfg)
-        model.load_state_dict({k: torch.from_numpy(synth.make_param(k, s)) for k, s in shapes.items()}, strict=True)
+        if rank == 0:                                 # ... and only rank 0 holds the weights the check expects
+            model.load_state_dict({k: torch.from_numpy(synth.make_param(k, s)) for k, s in shapes.items()}, strict=True)
         model.eval()
         batch = synth.make_batch(1, 2, seed=10 + rank)
         tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
         pk = {"loader": [tb], "sampler": None}
         tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=rank)
         assert tr.gradsync.world == world
+        # GradSync's constructor broadcast rank 0's parameters (what the DDP wrap did in the reference, experiment.py:104-109)
+        w0 = torch.from_numpy(synth.make_param("embed_state.weight", shapes["embed_state.weight"]))
+        assert torch.equal(model.embed_state.weight.detach(), w0), "initial parameters were not broadcast from rank 0"
         tr._process_batch(tb)
         if rank == 0:
             q.put({n: p.detach().clone().numpy() for n, p in model.named_parameters()})

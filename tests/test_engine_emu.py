@@ -23,7 +23,7 @@ def build(cfg, dtype, lib):
     weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
     keys = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
             "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size")
-    eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in keys}), "cpu", lib=lib)
+    eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in keys}), "cpu")
     assert set(eng.table) == set(shapes), set(eng.table) ^ set(shapes)
     for k, w in weights.items():
         assert eng.table[k][2] == tuple(shapes[k])
@@ -32,9 +32,10 @@ def build(cfg, dtype, lib):
     return eng, weights
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def emu():
-    return U.load_emu()
+    with U.emulated() as e:
+        yield e
 
 
 def test_engine_step_matches_oracle_f32(emu):
@@ -52,7 +53,7 @@ def test_engine_step_matches_oracle_f32(emu):
     assert U.relerr(pars, opars) < 1e-5, U.relerr(pars, opars)
     assert bool((pars.argmax(-1) == opars.argmax(-1)).all())
 
-    loss, met = eng.loss(cmds, pars, actions[:, 1:])
+    loss, met = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
     oloss, ometrics, ototal, _, _ = ot.step(batch)
     assert abs(float(loss[0]) - float(oloss)) < 2e-5 * max(1.0, abs(float(oloss))), (float(loss[0]), float(oloss))
     m = met.tolist()
@@ -138,7 +139,7 @@ def test_engine_train_mode_dropout_matches_oracle_with_same_masks(emu):
     frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
     cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
     assert U.relerr(pars, opars) < 1e-5 and U.relerr(cmds, ocmds) < 1e-5, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
-    loss, met = eng.loss(cmds, pars, actions[:, 1:])
+    loss, met = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(oloss)) < 2e-5 * max(1.0, abs(float(oloss)))
     eng.backward()
     worst = ("", 0.0)
@@ -165,7 +166,7 @@ def test_engine_other_wirings_match_oracle(emu, pa, ps, tse):
     keys = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
             "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size",
             "enable_past_actions", "enable_past_states", "enable_timestep_embedding")
-    eng = NativeEngine(make_config(dtype=L.VCAD_F32, **{k: cfg[k] for k in keys}), "cpu", lib=emu)
+    eng = NativeEngine(make_config(dtype=L.VCAD_F32, **{k: cfg[k] for k in keys}), "cpu")
     assert set(eng.table) == set(shapes) and all(eng.table[k][2] == tuple(shapes[k]) for k in shapes)
     for k, w in weights.items():
         eng.view(k).copy_(torch.from_numpy(w))
@@ -175,7 +176,7 @@ def test_engine_other_wirings_match_oracle(emu, pa, ps, tse):
     frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
     cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
     assert U.relerr(pars, opars) < 1e-5 and U.relerr(cmds, ocmds) < 1e-5
-    loss, _ = eng.loss(cmds, pars, actions[:, 1:])
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(oloss)) < 2e-5 * max(1.0, abs(float(oloss)))
     eng.backward()
     for k in weights:

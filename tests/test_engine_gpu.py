@@ -55,7 +55,7 @@ def test_f32_step_matches_reference_goldens(golden_dir, case):
     assert float((pcmp - gp).abs().max()) < 1e-3 * float(gp.abs().max())
     assert np.array_equal(pars.argmax(-1).cpu().numpy(), gold["params_argmax"])
     assert np.array_equal(cmds.argmax(-1).cpu().numpy(), gold["cmds_argmax"])
-    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:])
+    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
     gm = json.loads(str(gold["metrics_json"]))
     m = met.tolist()
@@ -92,7 +92,7 @@ def test_f32_window1_forward(golden_dir):
     batch, cmds, pars, gc, gp, pcmp = run_case(eng, gold, 2, 8, 3, None, False)
     assert U.relerr(cmds, gc) < 1e-4 and U.relerr(pcmp, gp) < 1e-4
     assert np.array_equal(pars.argmax(-1).cpu().numpy(), gold["params_argmax"])
-    loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:])
+    loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
 
 
@@ -117,7 +117,7 @@ def test_bf16_step_close_to_goldens(golden_dir, gemm_dma_mode):
     agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
     print(f"\n[bf16 vs fp32 reference] params-logit MAE {mae:.3e}  norm-wise rel {rel:.3e}  argmax agreement {agree:.3f}  cmd rel {U.relerr(cmds, gc):.3e}")
     assert rel < 3e-2 and agree > 0.85
-    loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:])
+    loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(gold["loss"])) < 2e-2 * abs(float(gold["loss"]))
     eng.backward()
     names = [str(n) for n in gold["grad_names"]]
@@ -156,6 +156,7 @@ def test_fused_loss_matches_reference_loss_cases(golden_dir):
     cw_json = json.load(open(os.path.join(golden_dir, "class_weights.json")))
     names = ["x", "y", "Key Pressed", "Times Key Pressed", "Scroll Amount", "Typed Value"]
     cw = torch.tensor([cw_json[k] for k in names], dtype=torch.float32, device=DEV).contiguous()
+    lw = cw_json["Label"]
     B, T = cases["B"], cases["T"]
     eng = build(L.VCAD_F32)
     b = synth.make_batch_torch(B, T, 1, DEV)
@@ -174,10 +175,10 @@ def test_fused_loss_matches_reference_loss_cases(golden_dir):
             acts[..., 1:][m] = torch.where(acts[..., 1:][m] > 500, torch.tensor(999.0), torch.tensor(998.0))
         cm, pm, acts = cm.to(DEV), pm.to(DEV).contiguous(), acts.to(DEV)
         from videocad_amd.trainer import metrics_from_counters
-        out, met = eng.loss(cm, pm, acts, use_mse=True)
+        out, met = eng.loss(cm, pm, acts, lw, use_mse=True)
         assert abs(float(out[0]) - c["loss_use_mse"]) < 2e-5 * max(1.0, abs(c["loss_use_mse"])), (name, float(out[0]), c["loss_use_mse"])
         assert metrics_from_counters(met.tolist()) == c["metrics_use_mse"], name
-        out, met = eng.loss(cm, pm, acts, use_mse=False, class_weights=cw)
+        out, met = eng.loss(cm, pm, acts, lw, use_mse=False, class_weights=cw)
         assert abs(float(out[0]) - c["loss_no_mse"]) < 2e-5 * max(1.0, abs(c["loss_no_mse"])), (name, float(out[0]), c["loss_no_mse"])
         assert metrics_from_counters(met.tolist()) == c["metrics_no_mse"], name
 
@@ -210,7 +211,7 @@ def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol
     fr = torch.from_numpy(batch["frames"]).to(DEV); ac = torch.from_numpy(batch["actions"]).to(DEV); cad = torch.from_numpy(batch["cad_image"]).to(DEV)
     cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
     assert U.relerr(pars, opars) < tol_logit and U.relerr(cmds, ocmds) < tol_logit, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
-    loss, _ = eng.loss(cmds, pars, ac[:, 1:])
+    loss, _ = eng.loss(cmds, pars, ac[:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(oloss)) < max(tol_logit, 1e-4) * abs(float(oloss))
     eng.backward()
     rels = []
@@ -253,7 +254,7 @@ def test_f32_other_wirings_match_reference_goldens(golden_dir, case):
     batch, cmds, pars, gc, gp, pcmp = run_case(eng, gold, meta["B"], meta["T"], meta["seed"], None, False)
     assert U.relerr(cmds, gc) < 1e-4 and U.relerr(pcmp, gp) < 1e-4
     assert np.array_equal(pars.argmax(-1).cpu().numpy(), gold["params_argmax"])
-    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:])
+    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
     from videocad_amd.trainer import metrics_from_counters
     assert metrics_from_counters(met.tolist()) == json.loads(str(gold["metrics_json"]))
@@ -279,7 +280,7 @@ def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
     def run(staged):
         eng.set_dropout(0.1, seed=5)
         cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
-        eng.loss(cmds, pars, ac[:, 1:])
+        eng.loss(cmds, pars, ac[:, 1:], U.LABEL_W)
         eng.grads.zero_()
         if not staged:
             eng.backward()
@@ -316,7 +317,7 @@ def test_bf16_train_mode_other_wirings(pa, ps, tse):
     def run(staged):
         eng.set_dropout(0.1, seed=9)
         cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
-        loss, _ = eng.loss(cmds, pars, ac[:, 1:])
+        loss, _ = eng.loss(cmds, pars, ac[:, 1:], U.LABEL_W)
         eng.grads.zero_()
         if staged:
             for st in range(len(eng.buckets)):

@@ -1,0 +1,117 @@
+"""Parity at BASELINE.json's REAL sizes: C2 = 32 clips x 64 steps, C4's per-GPU shape = 16 x 186 (the
+three-key-block decoder attention kernels), C3 = 64 x 128 — through the C ABI, against the oracle.
+
+Size-independent construction: the full batch is K repetitions of the same two clips.  Every clip is processed independently by
+forward, the loss is a mean over (identical, repeated) rows and the parameter gradient a mean over clips, so the full-size run
+must reproduce — logits, loss, metric counters / K, every parameter gradient — what the fp32 oracle computes on the 2-clip batch
+(seconds on the host), up to summation order.  Nothing is sampled away: all B*T frames go through every kernel at full grid size."""
+import numpy as np
+import pytest
+import torch
+
+import oputil as U
+from oracle import restatement as O
+from videocad_amd import lib as L
+from videocad_amd import synth
+from videocad_amd.engine import NativeEngine, make_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CFG_KEYS = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
+            "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size")
+GRAD_PROBES = ["predict_action_class_0_999.weight", "predict_action_class_0_4.bias", "transformer_decoder.layers.7.linear2.weight",
+               "transformer_decoder.layers.7.multihead_attn.in_proj_weight", "transformer_decoder.layers.0.self_attn.in_proj_weight",
+               "transformer_decoder.layers.0.norm1.weight", "embed_action.weight", "timestep_embedding.weight", "image_projection.weight",
+               "embed_state.weight", "embed_image.bias", "state_embedding_model.transformer.layers.5.0.to_qkv.weight",
+               "state_embedding_model.transformer.layers.3.1.net.1.weight", "state_embedding_model.transformer.layers.0.0.to_out.0.weight",
+               "state_embedding_model.to_patch_embedding.2.weight", "state_embedding_model.pos_embedding",
+               "cad_embedding_model.transformer.layers.2.1.net.4.weight", "cad_embedding_model.to_patch_embedding.1.weight"]
+
+_ORACLE = {}
+
+
+def oracle_two_clips(T):
+    """fp32 oracle on the 2-clip batch of horizon T (cached per T: C2/C3/C4 differ in T)."""
+    if T not in _ORACLE:
+        shapes = O.param_shapes()
+        weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
+        batch = synth.make_batch(2, T, seed=40 + T)
+        ot = O.OracleTrainer(weights)
+        loss, metrics, cmds, pars = ot.loss_and_grads(batch)
+        gn = {n: float(ot.P[n].grad.double().norm()) for n in GRAD_PROBES}
+        total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ot.P.values() if p.grad is not None)))
+        _ORACLE[T] = dict(batch=batch, loss=float(loss), metrics=metrics, cmds=cmds.detach(), pars=pars.detach(), gn=gn, total=total)
+    return _ORACLE[T]
+
+
+def build(dtype):
+    cfg = O.CANONICAL_CONFIG
+    eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in CFG_KEYS}), DEV)
+    for k, s in O.param_shapes(cfg).items():
+        eng.view(k).copy_(synth.make_param_torch(k, s, DEV))
+    eng.sync_shadow()
+    return eng
+
+
+def tiled(batch, K):
+    rep = lambda a: torch.from_numpy(a).to(DEV).repeat(K, *([1] * (a.ndim - 1)))
+    return rep(batch["frames"]), rep(batch["actions"]), rep(batch["cad_image"])
+
+
+@pytest.mark.parametrize("name,B,T", [("C2", 32, 64), ("C4_per_gpu", 16, 186), ("C3", 64, 128)])
+def test_full_size_step_matches_oracle_f32(name, B, T):
+    ref = oracle_two_clips(T)
+    K = B // 2
+    eng = build(L.VCAD_F32)
+    frames, actions, cad = tiled(ref["batch"], K)
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    # every repetition of the two clips gives the oracle's logits: 1e-3 relative gate (measured ~1e-6), arg-max bit-exact
+    for rep in (0, K // 2, K - 1):
+        c, p = cmds[2 * rep: 2 * rep + 2].cpu(), pars[2 * rep: 2 * rep + 2].cpu()
+        assert U.relerr(c, ref["cmds"]) < 1e-4 and U.relerr(p, ref["pars"]) < 1e-4, (name, rep, U.relerr(p, ref["pars"]))
+        assert float((p - ref["pars"]).abs().max()) < 1e-3 * float(ref["pars"].abs().max())
+        assert torch.equal(p.argmax(-1), ref["pars"].argmax(-1)) and torch.equal(c.argmax(-1), ref["cmds"].argmax(-1))
+    loss, met = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - ref["loss"]) < 2e-5 * abs(ref["loss"]), (name, float(loss[0]), ref["loss"])
+    m = met.tolist()
+    assert m[L.MET_TOTAL] == K * ref["metrics"]["total_predictions"] and m[L.MET_CORRECT] == K * ref["metrics"]["correct_predictions"]
+    assert m[L.MET_PAR_COUNT:L.MET_PAR_COUNT + 6] == [K * x for x in ref["metrics"]["param_counts"]]
+    eng.backward()
+    for n, want in ref["gn"].items():
+        got = float(eng.view(n, eng.grads).double().norm())
+        assert abs(got - want) <= 2e-3 * want + 1e-9, (name, n, got, want)
+    norm = eng.optimizer_step(lr=1e-5)
+    assert abs(float(norm[0]) - ref["total"]) < 1e-3 * ref["total"]
+
+
+@pytest.mark.parametrize("name,B,T", [("C2", 32, 64), ("C4_per_gpu", 16, 186), ("C3", 64, 128)])
+def test_full_size_step_bf16_close_and_train_mode_sane(name, B, T):
+    """Throughput mode at full size: logits / loss / gradients close to the fp32 oracle (reported), then ONE train-mode step with
+    dropout 0.1 on the same engine: finite, gradient norm in the eval run's ballpark, weights move."""
+    ref = oracle_two_clips(T)
+    K = B // 2
+    eng = build(L.VCAD_BF16)
+    frames, actions, cad = tiled(ref["batch"], K)
+    an = O.normalize_actions(actions[:, :-1])
+    cmds, pars = eng.forward(frames[:, :-1], an, cad)
+    p = pars[:2].cpu()
+    rel, mae = U.relerr(p, ref["pars"]), float((p - ref["pars"]).abs().mean())
+    agree = float((p.argmax(-1) == ref["pars"].argmax(-1)).float().mean())
+    print(f"\n[{name} bf16 vs fp32 oracle] logit MAE {mae:.3e}  rel {rel:.3e}  argmax agreement {agree:.4f}")
+    assert rel < 3e-2 and agree > 0.85
+    assert torch.equal(pars[:2], pars[2 * (K - 1):])                       # repetitions are bit-identical: no cross-clip leakage at full grid size
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - ref["loss"]) < 2e-2 * abs(ref["loss"])
+    eng.backward()
+    worst = max(abs(float(eng.view(n, eng.grads).double().norm()) - w) / w for n, w in ref["gn"].items())
+    assert worst < 8e-2, worst
+    g_eval = float(eng.optimizer_step(lr=0.0)[0])                           # lr 0: weights untouched, norm reported
+    w0 = eng.view("embed_state.weight").clone()
+    eng.set_dropout(0.1, seed=7)
+    cmds, pars = eng.forward(frames[:, :-1], an, cad)
+    loss_t, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    eng.backward()
+    g_train = float(eng.optimizer_step(lr=1e-5)[0])
+    assert np.isfinite(float(loss_t[0])) and np.isfinite(g_train) and 0.3 * g_eval < g_train < 3.0 * g_eval, (g_eval, g_train)
+    assert not torch.equal(pars[:2], pars[2 * (K - 1):])                    # dropout masks differ per clip
+    assert not torch.equal(eng.view("embed_state.weight"), w0)

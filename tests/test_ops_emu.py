@@ -97,3 +97,10 @@ def test_attention_decoder_mfma_long(emu, T, window):
 def test_attention_band(emu):
     U.check_attention(emu, "cpu", 2, 1, 23, 256, window=10, causal=1, dt=F32)
     U.check_attention(emu, "cpu", 1, 1, 9, 256, window=1, causal=1, dt=F32)
+
+
+@pytest.mark.parametrize("T,window,dt", [(37, 37, BF16), (37, 10, BF16), (70, 70, BF16), (130, 10, BF16), (23, 10, F32), (70, 70, F32)])
+def test_attention_head_dim_128(emu, T, window, dt):
+    """nhead = 8 at hidden 1024 (reference final_experiments.json / the *_large configs): head dim 128 = two 64-wide chunks in the
+    matrix-core decoder kernels, DPL = 2 in the wave-per-row kernels"""
+    U.check_attention(emu, "cpu", 1, 2, T, 128, window=window, causal=1, dt=dt)

@@ -107,3 +107,9 @@ def test_attention_decoder_mfma_long(hip, T, window):
 def test_attention_band(hip, window):
     U.check_attention(hip, DEV, 2, 4, 64, 256, window=window, causal=1, dt=F32)
     U.check_attention(hip, DEV, 2, 4, 186, 256, window=window, causal=1, dt=BF16)
+
+
+@pytest.mark.parametrize("T,window,dt", [(64, 64, BF16), (64, 10, BF16), (186, 186, BF16), (186, 10, BF16), (186, 186, F32), (64, 10, F32)])
+def test_attention_head_dim_128(hip, T, window, dt):
+    """nhead = 8 at hidden 1024 (reference final_experiments.json / *_large configs)"""
+    U.check_attention(hip, DEV, 3, 8, T, 128, window=window, causal=1, dt=dt)

@@ -16,11 +16,14 @@ def short(name):
 
 
 bench = json.loads(open(os.path.join(base, "bench_default.json")).read().strip().splitlines()[-1])
-steps_traced = bench["steps"] + bench["warmup"] + 1          # + the profiled step
-print(f"# {tag}: rocprofv3 evidence for `python bench.py`\n")
+stats = list(csv.DictReader(open(os.path.join(base, "trace", "bench_kernel_stats.csv"))))
+# steps that ACTUALLY ran under the tracer = launches of the once-per-step optimiser kernel (r01 assumed a count and was off by 1.7x / 6x)
+adam = [r for r in stats if short(r["Name"]).startswith("adam_kernel")]
+steps_traced = int(adam[0]["Calls"]) if adam else bench["steps"] + bench["warmup"] + 1
+assert steps_traced == bench["steps"] + bench["warmup"] + 1, (steps_traced, bench["steps"], bench["warmup"])   # timed + warm-up + the HIP-event step
+print(f"# {tag}: rocprofv3 evidence for `python bench.py --profile-only` (C2 workload only; {steps_traced} train steps ran under the tracer)\n")
 print("## bench line\n```json\n" + json.dumps(bench, indent=1)[:6000] + "\n```\n")
 
-stats = list(csv.DictReader(open(os.path.join(base, "trace", "bench_kernel_stats.csv"))))
 ours = [r for r in stats if "at::native" not in r["Name"] and "rocclr" not in r["Name"] and "Cijk" not in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in ours)
 print(f"## kernel-trace stats ({steps_traced} steps traced; library kernels only; {tot / steps_traced / 1e6:.2f} ms of kernel time per step)\n")
@@ -29,25 +32,30 @@ for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"]))[:30]:
     print(f"| `{short(r['Name'])}` | {int(r['Calls']) / steps_traced:.1f} | {float(r['AverageNs']) / 1e3:.1f} | "
           f"{float(r['TotalDurationNs']) / steps_traced / 1e6:.3f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
 
-pmc = {}
+pmc, pmc_steps = {}, {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     path = os.path.join(base, f"pmc_{c}", "pmc_counter_collection.csv")
     if not os.path.exists(path):
         continue
     agg = collections.defaultdict(float)
+    adam_ids = set()
     for row in csv.DictReader(open(path)):
         if "at::native" in row["Kernel_Name"] or "rocclr" in row["Kernel_Name"]:
             continue
         agg[short(row["Kernel_Name"])] += float(row["Counter_Value"])
+        if short(row["Kernel_Name"]).startswith("adam_kernel"):
+            adam_ids.add(row.get("Dispatch_Id"))
     pmc[c] = agg
+    pmc_steps[c] = max(len(adam_ids), 1)
 if pmc:
-    nsteps = 2.0                                              # --steps 1 --warmup 0 + the profiled step
+    nsteps = float(min(pmc_steps.values()))                   # steps that ran in the PMC passes, counted (adam_kernel dispatches)
+    assert len(set(pmc_steps.values())) == 1, pmc_steps
     names = sorted(set().union(*[set(v) for v in pmc.values()]), key=lambda k: -(2 * pmc.get("FETCH_SIZE", {}).get(k, 0) + pmc.get("WRITE_SIZE", {}).get(k, 0)))
     rd = {k: 2 * 1024 * pmc.get("FETCH_SIZE", {}).get(k, 0) / nsteps / 1e9 for k in names}
     wr = {k: 1024 * pmc.get("WRITE_SIZE", {}).get(k, 0) / nsteps / 1e9 for k in names}
     ms = {short(r["Name"]): float(r["TotalDurationNs"]) / steps_traced / 1e6 for r in ours}
     print(f"\n## HBM-side traffic per step (PMC; FETCH_SIZE x2 per the gfx950 correction)\n")
-    print(f"total read {sum(rd.values()):.1f} GB + write {sum(wr.values()):.1f} GB per step\n")
+    print(f"total read {sum(rd.values()):.1f} GB + write {sum(wr.values()):.1f} GB per step ({int(nsteps)} steps ran in each PMC pass)\n")
     print("| kernel | read GB/step | write GB/step | ms/step | effective TB/s |\n|---|---|---|---|---|")
     for k in names[:24]:
         t = ms.get(k, 0)

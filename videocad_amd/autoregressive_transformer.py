@@ -59,14 +59,22 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, model, frames, actions, cad, *params):
         cmds, pars = model._engine.forward(frames, actions, cad)
         ctx.model = model
+        model._fwd_id += 1
+        ctx.fwd_id = model._fwd_id
         return cmds, pars
 
     @staticmethod
     def backward(ctx, dcmds, dpars):
         model = ctx.model
         eng = model._engine
+        if ctx.fwd_id != model._fwd_id:
+            raise RuntimeError("videocad_amd: backward through a forward that is no longer the engine's current one (the engine keeps the "
+                               "activations of the most recent forward only)")
         eng.backward(dcmds.contiguous(), dpars.reshape(dpars.shape[0], dpars.shape[1], -1).contiguous())
-        grads = tuple(eng.view(n, eng.grads) for n in model._param_names)
+        # the engine WRITES its flat gradient buffer on every backward; autograd may adopt what we return as p.grad and add the next
+        # backward into it in place, so hand it a private copy (one flat clone, parameters are views of it)
+        flat = eng.grads.clone()
+        grads = tuple(eng.view(n, flat) for n in model._param_names)
         return (None, None, None, None) + grads
 
 
@@ -75,7 +83,7 @@ class AutoRegressiveTransformer(nn.Module):
                  enable_past_actions=False, enable_past_states=False, enable_timestep_embedding=False, num_classes=5,
                  num_params=6, num_params_values=1000, num_decoder_layers=8, dim_feedforward=512,
                  use_pretrained_cad_model=False, nhead=4, dropout=0.1, normalize=False, device=None, encoder="vit",
-                 num_views=0, window_size=1, compute_dtype: str = "bf16", _lib=None, **kwargs):
+                 num_views=0, window_size=1, compute_dtype: str = "bf16", **kwargs):
         super().__init__()
         assert window_size > 0, "Window size must be greater than 0"          # reference :52
         if encoder != "vit" or use_pretrained_cad_model:
@@ -100,13 +108,15 @@ class AutoRegressiveTransformer(nn.Module):
                           enable_past_actions=enable_past_actions, enable_past_states=enable_past_states,
                           enable_timestep_embedding=enable_timestep_embedding,
                           **{k: kwargs[k] for k in ("vit_depth",) if k in kwargs})    # extension (tests): shallower ViT
-        self._engine = NativeEngine(cfg, "cpu", lib=_lib)
+        self._engine = NativeEngine(cfg, "cpu")
         self._param_names = list(self._engine.table.keys())
         for name in self._param_names:
             _attach(self, name, nn.Parameter(self._engine.view(name), requires_grad=True))
         self._plist = [dict(self.named_parameters())[n] for n in self._param_names]
         self._shadow_fresh = False
         self._drop_step = 0
+        self._drop_rank = 0                                                  # data-parallel rank (set by the trainer): every rank draws its own masks
+        self._fwd_id = 0
         self.reset_parameters()
         self.action_mask = torch.tensor([[1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 1, 0],
                                          [0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0]]).float()   # reference :83-89 (plain attribute)
@@ -173,7 +183,7 @@ class AutoRegressiveTransformer(nn.Module):
         """train(): p = dropout with a fresh seed per forward (the backward reuses it); eval(): off."""
         if self.training and self.dropout_p > 0:
             self._drop_step += 1
-            self._engine.set_dropout(self.dropout_p, seed=(self._drop_seed_base << 20) + self._drop_step)
+            self._engine.set_dropout(self.dropout_p, seed=(self._drop_seed_base << 44) | ((self._drop_rank & 0xFFF) << 32) | (self._drop_step & 0xFFFFFFFF))
         else:
             self._engine.set_dropout(0.0, 0)
 
@@ -209,13 +219,15 @@ class AutoRegressiveTransformer(nn.Module):
         frames, actions, cad = inputs["frames"], inputs["actions"], inputs["cad_image"]
         if inputs.get("multiview_images", None) is not None and self.num_views > 0:
             raise NotImplementedError("multiview")
-        if self._engine.params.device.type != "cuda" and self._engine.lib is L._lib:
+        if self._engine.params.device.type != "cuda" and b"gfx950" in self._engine.lib.vcad_version():
             raise RuntimeError("videocad_amd has no CPU fallback: move the model to a ROCm device (model.to('cuda'))")
         if not self._shadow_fresh:
             self._engine.sync_shadow()
         self._shadow_fresh = False
         self._arm_dropout()
-        frames = frames.float(); actions = actions.float(); cad = cad.float()
+        if frames.dtype != torch.uint8:                          # uint8 pixel batches are normalised inside the patchify kernel
+            frames = frames.float(); cad = cad.float()
+        actions = actions.float()
         if torch.is_grad_enabled():
             cmds, pars = _EngineFn.apply(self, frames, actions, cad, *self._plist)
         else:
@@ -223,22 +235,55 @@ class AutoRegressiveTransformer(nn.Module):
         return cmds, pars
 
     @torch.no_grad()
-    def sequential_inference(self, ui_images, cad_image, action=False):
-        """reference :222-275 (step-by-step prediction; re-encodes the prefix each step like the reference does)"""
+    def sequential_inference(self, ui_images, cad_image, action=False, cached=True):
+        """reference :222-275: step-by-step prediction, (cmds [B,T,5], params [B,T,6,1000]).
+
+        The reference re-runs `forward` on the prefix [0..t] for every t (t+1 ViT passes per step).  The model is causal, so with
+        `cached=True` (default) each step encodes one new frame per clip and attends to cached keys / values (vcad_infer_begin /
+        vcad_infer_step): same numbers, O(T) instead of O(T^2) frames.  `cached=False` keeps the reference's literal loop.
+        action=True feeds back the masked arg-max of the previous step (the reference's version of that branch indexes a [B,6]
+        tensor with [:, :, 3] and raises; here the time axis is kept so it runs)."""
         B, T = ui_images.shape[:2]
         device = ui_images.device
-        cmds_out, pars_out = [], []
-        actions = torch.zeros(B, 1, self.act_dim, device=device) if action else None
+        was_training = self.training
+        self.eval()
+        try:
+            if cached and T <= 192:
+                return self._sequential_cached(ui_images, cad_image, action)
+            cmds_out, pars_out = [], []
+            actions = torch.zeros(B, 1, self.act_dim, device=device) if action else None
+            for t in range(T):
+                inputs = {"frames": ui_images[:, : t + 1], "actions": actions if action else torch.zeros(B, t + 1, 7, device=device),
+                          "timesteps": torch.arange(t + 1, device=device), "cad_image": cad_image}
+                cmd, params = self.forward(inputs)
+                if action:
+                    actions = torch.cat([actions, self._next_action(cmd[:, -1:], params[:, -1:])], dim=1)
+                cmds_out.append(cmd[:, -1].clone()); pars_out.append(params[:, -1].clone())
+            return torch.stack(cmds_out, dim=1), torch.stack(pars_out, dim=1)
+        finally:
+            self.train(was_training)
+
+    def _next_action(self, cmd, params):
+        """[B,1,5], [B,1,6,1000] logits -> the normalised action [B,1,7] fed at the next position (reference :249-263)"""
+        cmd_pred = torch.argmax(cmd, dim=-1)                                  # [B,1]
+        nxt = self.apply_action_mask(cmd_pred, torch.argmax(params, dim=-1)).float()
+        return self.normalize_actions(torch.cat([cmd_pred.unsqueeze(-1).float(), nxt], dim=2))
+
+    def _sequential_cached(self, ui_images, cad_image, action):
+        eng = self._engine
+        if eng.params.device.type != "cuda" and b"gfx950" in eng.lib.vcad_version():
+            raise RuntimeError("videocad_amd has no CPU fallback: move the model to a ROCm device (model.to('cuda'))")
+        if not self._shadow_fresh:
+            eng.sync_shadow()
+        B, T = ui_images.shape[:2]
+        if ui_images.dtype != torch.uint8:
+            ui_images = ui_images.float(); cad_image = cad_image.float()
+        eng.infer_begin(cad_image, B, T)
+        cmds = torch.empty(B, T, 5, device=ui_images.device); pars = torch.empty(B, T, 6, self._engine.cfg.num_params_values, device=ui_images.device)
+        a = torch.zeros(B, self.act_dim, device=ui_images.device)
         for t in range(T):
-            inputs = {"frames": ui_images[:, : t + 1], "actions": actions if action else torch.zeros(B, t + 1, 7, device=device),
-                      "timesteps": torch.arange(t + 1, device=device), "cad_image": cad_image}
-            cmd, params = self.forward(inputs)
+            c, p = eng.infer_step(t, ui_images[:, t], a)
+            cmds[:, t] = c; pars[:, t] = p
             if action:
-                # (the reference indexes a [B,6] tensor with [:, :, 3] here and raises; we keep the time axis so it runs)
-                cmd_pred = torch.argmax(cmd[:, -1:], dim=-1)                       # [B,1]
-                param_pred = torch.argmax(params[:, -1:], dim=-1)                  # [B,1,6]
-                nxt = self.apply_action_mask(cmd_pred, param_pred).float()
-                nxt = torch.cat([cmd_pred.unsqueeze(-1).float(), nxt], dim=2)      # [B,1,7]
-                actions = torch.cat([actions, self.normalize_actions(nxt)], dim=1)
-            cmds_out.append(cmd[:, -1].clone()); pars_out.append(params[:, -1].clone())
-        return torch.stack(cmds_out, dim=1), torch.stack(pars_out, dim=1)
+                a = self._next_action(c.unsqueeze(1), p.unsqueeze(1))[:, 0]
+        return cmds, pars

@@ -30,6 +30,9 @@ struct AttnParams {
     void* dq; void* dk; void* dv; long lddq, lddk, lddv;         // type T
     float* delta;                                                // [B][H][Tq]  D_i
     vc_drop drop;                                                // attention-probability dropout, idx = ((b*H+h)*Tq+i)*Tk+j (key 0 = off)
+    // cached single-step inference (forward, wave-per-row kernel only): query row i sits at absolute position qpos + i, and clip b's
+    // keys / values start at row b * kv_rows of the cache (0 = the dense layout: b * Tk)
+    int qpos; int kv_rows;
 };
 
 // sum_d row[d] * bc[d]; bc: LDS, same address for all lanes (broadcast).  The row is walked in 16-byte chunks, four
@@ -98,8 +101,10 @@ VC_KERNEL __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const long total = (long)p.B * p.H * p.Tq;
     if (wid >= total) return;
     const int i = (int)(wid % p.Tq); const int h = (int)((wid / p.Tq) % p.H); const int b = (int)(wid / ((long)p.Tq * p.H));
-    const int lo = (i - p.window + 1 > 0) ? (i - p.window + 1) : 0;
-    const int hi = p.causal ? (i < p.Tk - 1 ? i : p.Tk - 1) : (p.Tk - 1);
+    const int ia = i + p.qpos;                                   // absolute position of this query
+    const long kvb = (long)b * (p.kv_rows ? p.kv_rows : p.Tk);   // first key / value row of clip b
+    const int lo = (ia - p.window + 1 > 0) ? (ia - p.window + 1) : 0;
+    const int hi = p.causal ? (ia < p.Tk - 1 ? ia : p.Tk - 1) : (p.Tk - 1);
     const int nk = hi - lo + 1;
     const T* qrow = (const T*)p.q + ((long)b * p.Tq + i) * p.ldq + h * D;
 #pragma unroll
@@ -112,7 +117,7 @@ VC_KERNEL __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         const int jj = ps * 64 + lane;
         s[ps] = -INFINITY;
         if (jj < nk) {
-            const T* krow = (const T*)p.k + ((long)b * p.Tk + lo + jj) * p.ldk + h * D;
+            const T* krow = (const T*)p.k + (kvb + lo + jj) * p.ldk + h * D;
             s[ps] = attn_dot_row<T, D>(krow, qs[wave]) * p.scale;
         }
         m = fmaxf(m, s[ps]);
@@ -133,7 +138,7 @@ VC_KERNEL __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         int cnt = nk - ps * 64; cnt = cnt > 64 ? 64 : cnt;
-        attn_accum_rows<T, DPL>(acc, (const T*)p.v + ((long)b * p.Tk + lo + ps * 64) * p.ldv + h * D + lane * DPL, p.ldv, cnt, s[ps]);
+        attn_accum_rows<T, DPL>(acc, (const T*)p.v + (kvb + lo + ps * 64) * p.ldv + h * D + lane * DPL, p.ldv, cnt, s[ps]);
     }
     const float inv = 1.0f / l;
     T* orow = (T*)p.o + ((long)b * p.Tq + i) * p.ldo + h * D + lane * DPL;

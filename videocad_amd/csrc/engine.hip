@@ -65,10 +65,14 @@ struct vcad_engine {
     VitW wv[2]; std::vector<DecW> wd;      // [0] = state_embedding_model, [1] = cad_embedding_model
     long o_es_w, o_es_b, o_ei_w, o_ei_b, o_ip_w, o_ip_b, o_ea_w, o_ea_b, o_ts, o_h5_w, o_h5_b, o_h6_w, o_h6_b;
     float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr; vc_bf16* S = nullptr;
-    char* ws = nullptr; size_t ws_bytes = 0;
+    char* ws = nullptr; size_t ws_bytes = 0; char* planned_ws = nullptr;
+    // incremental inference (vcad_infer_begin / vcad_infer_step): per decoder layer the projected keys / values of every step so
+    // far — self-attention over the tgt stream, cross-attention over the memory stream — laid out [B][Tmax][2H]
+    int infer_T = 0, infer_t = 0, infer_u8 = 0; std::vector<void*> ic_kv_s, ic_kv_c;
     // ---- per-(B,T) plan
     int B = 0, T = 0; bool fwd_valid = false;
-    const float* in_frames = nullptr; long in_fbstride = 0; const float* in_actions = nullptr; const float* in_cad = nullptr;
+    const void* in_frames = nullptr; long in_fbstride = 0; const float* in_actions = nullptr; const void* in_cad = nullptr;
+    int in_u8 = 0;                // frames / cad are uint8 grayscale pixels, normalised inside the patchify kernels (vcad_forward_u8)
     VitActs va[2]; std::vector<DecLayerActs> da;
     float *ui, *cadterm, *mem, *act; void* cadE;
     float *xfinal;                // = da.back().x3
@@ -365,7 +369,7 @@ bool ensure_side(vcad_engine* e) {
     return true;
 }
 
-int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bstride) {
+int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstride) {
     vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
     const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
     const long N = a.N, R = N * (P + 1), Rp = N * P;
@@ -373,7 +377,7 @@ int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bst
     {   // patchify + LN(1024)
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = img; p.gamma = cx.Pf(w.ln1w); p.beta = cx.Pf(w.ln1b); p.yt = a.pn; p.ldyt = pd; p.stats = a.pstat; p.rows = Rp; p.eps = 1e-5f;
-        p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.ldx = img_bstride;
+        p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.ldx = img_bstride; p.u8 = e->in_u8;
         CK(vc_ln_fwd(VC_F32, e->dt, pd, 1, p, cx.s));
     }
     { Epi ep; ep.bias = cx.Pf(w.peb); CK(cx.lin_fwd(cx.AT(a.pn, pd), cx.W(w.pew, pd), cx.A32(a.pe, D), (int)Rp, D, pd, ep)); }
@@ -429,7 +433,7 @@ int vit_forward(const Ctx& cx, int v, const float* img, long img_T, long img_bst
 
 // de: fp32 [N, D] gradient of the cls embedding.  first/last layer range lets the caller split into DDP stages.
 int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 = top half (cls-LN + upper layers), 2 = bottom half + embed*/,
-                 const float* img, long img_T, long img_bstride) {
+                 const void* img, long img_T, long img_bstride) {
     vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
     const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
     const long N = a.N, R = N * (P + 1), Rp = N * P;
@@ -504,7 +508,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         {   // LN(1024) parameter gradients (input frames need no gradient)
             LnBwdParams p; memset(&p, 0, sizeof(p));
             p.dy = cx.L().t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
-            p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T;
+            p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.u8 = e->in_u8;
             CK(vc_ln_bwd(e->dt, VC_F32, e->dt, pd, 1, p, cx.L().scr_lnpart, cx.Gf(w.ln1w), cx.Gf(w.ln1b), cx.L().scr_colsum, cx.s));
         }
     }
@@ -738,15 +742,27 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
 extern "C" {
 
 const char* vcad_last_error(void) { return vc_get_error(); }
-const char* vcad_version(void) { return "videocad_amd 0.1 (gfx950)"; }
+#ifdef VC_EMU
+const char* vcad_version(void) { return "videocad_amd 0.2 (host emulator build: tests only)"; }
+#else
+const char* vcad_version(void) { return "videocad_amd 0.2 (gfx950)"; }
+#endif
 
 int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (!cfg || !out) { vc_set_error("null argument"); return VC_ERR_ARG; }
     if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_BF16) { vc_set_error("bad dtype %d", cfg->dtype); return VC_ERR_ARG; }
     if (cfg->hidden_size % cfg->nhead) { vc_set_error("hidden_size %% nhead != 0"); return VC_ERR_ARG; }
     const int hd = cfg->hidden_size / cfg->nhead;
-    if ((hd != 256 && hd != 64) || cfg->vit_dim_head != 64) { vc_set_error("head dims (%d, %d) unsupported (64/256)", hd, cfg->vit_dim_head); return VC_ERR_UNSUPPORTED; }
+    if ((hd != 256 && hd != 128 && hd != 64) || cfg->vit_dim_head != 64) { vc_set_error("head dims (%d, %d) unsupported (decoder 64/128/256, ViT 64)", hd, cfg->vit_dim_head); return VC_ERR_UNSUPPORTED; }
     if (cfg->window_size < 1) { vc_set_error("window_size must be > 0 (reference model/autoregressive_transformer.py:52)"); return VC_ERR_ARG; }
+    // every shape constraint of the kernels is checked HERE, so an unsupported reference config fails at construction (INTEGRATION.md
+    // lists which of the reference's model_configs these exclude), never at the first forward
+    if (cfg->hidden_size != 1024) { vc_set_error("hidden_size %d unsupported: the LayerNorm / stem kernels are specialised for 1024", cfg->hidden_size); return VC_ERR_UNSUPPORTED; }
+    if (cfg->vit_dim != 512 || cfg->patch_size * cfg->patch_size != 1024 || cfg->image_size % cfg->patch_size) {
+        vc_set_error("ViT dims (dim=%d, patch=%d, image=%d) unsupported: LayerNorm kernels need dim 512 and 32x32 patches", cfg->vit_dim, cfg->patch_size, cfg->image_size); return VC_ERR_UNSUPPORTED; }
+    { const int g = cfg->image_size / cfg->patch_size; if (g * g + 1 > 64) { vc_set_error("ViT token count %d exceeds the 64-token attention tile", g * g + 1); return VC_ERR_UNSUPPORTED; } }
+    if (cfg->num_classes != 5 || cfg->num_params != 6 || cfg->num_params_values != 1000) { vc_set_error("heads must be 5 + 6x1000 (reference model/autoregressive_transformer.py:218)"); return VC_ERR_UNSUPPORTED; }
+    if (cfg->dim_feedforward % 8 || cfg->vit_mlp % 8) { vc_set_error("dim_feedforward / vit_mlp must be multiples of 8 (16-byte bf16 rows)"); return VC_ERR_UNSUPPORTED; }
     vcad_engine* e = new vcad_engine();
     e->c = *cfg; e->dt = cfg->dtype; e->esz = cfg->dtype == VCAD_BF16 ? 2 : 4;
     if (cfg->vit_depth < 1 || cfg->num_decoder_layers < 1) { vc_set_error("vit_depth / num_decoder_layers must be >= 1"); delete e; return VC_ERR_ARG; }
@@ -791,7 +807,7 @@ size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
     vcad_engine tmp = *e;
     return plan(&tmp, B, T, nullptr);
 }
-int vcad_set_workspace(vcad_engine* e, void* ws, size_t bytes) { e->ws = (char*)ws; e->ws_bytes = bytes; e->fwd_valid = false; e->B = e->T = 0; return 0; }
+int vcad_set_workspace(vcad_engine* e, void* ws, size_t bytes) { e->ws = (char*)ws; e->ws_bytes = bytes; e->fwd_valid = false; e->B = e->T = 0; e->planned_ws = nullptr; e->infer_T = 0; return 0; }
 
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed) {
     if (!(p >= 0.f && p < 1.f)) { vc_set_error("vcad_set_dropout: p must be in [0, 1)"); return VC_ERR_ARG; }
@@ -806,16 +822,31 @@ int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kin
     return 0;
 }
 
+static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, const float* actions, const void* cad, int u8, int B, int T,
+                       float* cmds_out, float* pars_out, void* stream);
 int vcad_forward(vcad_engine* e, const float* frames, int64_t fbstride, const float* actions, const float* cad, int B, int T,
                  float* cmds_out, float* pars_out, void* stream) {
+    return forward_any(e, frames, fbstride, actions, cad, 0, B, T, cmds_out, pars_out, stream);
+}
+int vcad_forward_u8(vcad_engine* e, const uint8_t* frames, int64_t fbstride, const float* actions, const uint8_t* cad, int B, int T,
+                    float* cmds_out, float* pars_out, void* stream) {
+    if (((uintptr_t)frames | (uintptr_t)cad | (uintptr_t)fbstride) & 3) { vc_set_error("vcad_forward_u8: frames / cad / batch stride must be 4-byte aligned"); return VC_ERR_ARG; }
+    return forward_any(e, frames, fbstride, actions, cad, 1, B, T, cmds_out, pars_out, stream);
+}
+static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, const float* actions, const void* cad, int u8, int B, int T,
+                       float* cmds_out, float* pars_out, void* stream) {
     if (!e->P) { vc_set_error("vcad_forward: parameters not bound"); return VC_ERR_ARG; }
     if (B < 1 || T < 1 || T > e->c.max_ep_len) { vc_set_error("vcad_forward: bad B=%d T=%d", B, T); return VC_ERR_ARG; }
     if (T > 192) { vc_set_error("vcad_forward: T=%d exceeds the attention kernels' 192-key limit", T); return VC_ERR_UNSUPPORTED; }
     if ((double)B * T * 50.0 * 3072.0 >= 4294967296.0) { vc_set_error("vcad_forward: B*T=%d too large for 32-bit dropout indices", B * T); return VC_ERR_UNSUPPORTED; }
     if (!e->ws) { vc_set_error("vcad_forward: no workspace"); return VC_ERR_WORKSPACE; }
-    size_t need = plan(e, B, T, e->ws);
-    if (need > e->ws_bytes) { vc_set_error("vcad_forward: workspace %zu < %zu bytes", e->ws_bytes, need); return VC_ERR_WORKSPACE; }
-    e->B = B; e->T = T; e->in_frames = frames; e->in_fbstride = fbstride; e->in_actions = actions; e->in_cad = cad;
+    if (B != e->B || T != e->T || e->planned_ws != e->ws) {     // same (B, T, workspace): pointers, deferred tables and W^T jobs stay valid
+        { vcad_engine tmp = *e; const size_t need = plan(&tmp, B, T, nullptr);
+          if (need > e->ws_bytes) { vc_set_error("vcad_forward: workspace %zu < %zu bytes", e->ws_bytes, need); return VC_ERR_WORKSPACE; } }
+        plan(e, B, T, e->ws);
+        e->planned_ws = e->ws; e->infer_T = 0;
+    }
+    e->B = B; e->T = T; e->in_frames = frames; e->in_fbstride = fbstride; e->in_actions = actions; e->in_cad = cad; e->in_u8 = u8;
     e->fwd_valid = false;
     int rc = engine_forward(e, cmds_out, pars_out, (vc_stream_t)stream);
     if (rc) return rc;
@@ -825,17 +856,16 @@ int vcad_forward(vcad_engine* e, const float* frames, int64_t fbstride, const fl
 }
 
 static void fill_loss_params(vcad_engine* e, LossParams& p, const float* cmds, const float* pars, const float* targets, int B, int T,
-                             int use_mse, const float* class_w) {
+                             int use_mse, const float* label_w_host, const float* class_w) {
     memset(&p, 0, sizeof(p));
     const vcad_config& c = e->c; const long M = (long)B * T;
     p.cmds = cmds; p.ldc = c.num_classes; p.pars = pars; p.ldp = (long)c.num_params * c.num_params_values; p.targets = targets;
     p.M = M; p.T = T; p.use_mse = use_mse;
     const int tol[6] = {2, 2, 50, 200, 500, 2};            // reference trainer.py:827 (TOLERANCE = 3)
     const int above[6] = {0, 0, 1, 1, 1, 0};               // reference trainer.py:829 (metrics only; the loss window is always one-sided)
-    const float lw[5] = {0.04332685213392362f, 0.02915898563179938f, 0.267566828114559f, 0.6005346809501417f, 0.05941265316957628f};
     const int p2l[6] = {0, 0, 1, 1, 2, 3};                 // reference trainer.py:825
     for (int i = 0; i < 6; ++i) { p.tol[i] = tol[i]; p.above[i] = above[i]; p.param_to_label[i] = p2l[i]; }
-    for (int i = 0; i < 5; ++i) p.label_w[i] = lw[i];
+    for (int i = 0; i < 5; ++i) p.label_w[i] = label_w_host[i];      // class_weights.json "Label", read by the caller at run time (reference trainer.py:822-825)
     p.class_w = class_w;
     p.row_num = e->loss_rows; p.row_den = e->loss_rows + M * 7; p.row_lse = e->loss_rows + 2 * M * 7; p.row_arg = e->loss_arg;
     p.loss_out = e->loss_small; p.scales = e->loss_small + 16; p.metrics = e->loss_metrics;
@@ -843,11 +873,12 @@ static void fill_loss_params(vcad_engine* e, LossParams& p, const float* cmds, c
 }
 
 int vcad_loss(vcad_engine* e, const float* cmds, const float* pars, const float* targets, int B, int T, int use_mse,
-              const float* class_w, float* loss_out, int32_t* metrics_out, void* stream) {
+              const float* label_weights_host, const float* class_w, float* loss_out, int32_t* metrics_out, void* stream) {
     if (!e->ws || B != e->B || T != e->T) { vc_set_error("vcad_loss: call vcad_forward with the same (B,T) first"); return VC_ERR_ARG; }
     if (e->c.num_classes != 5 || e->c.num_params != 6 || e->c.num_params_values != 1000) { vc_set_error("vcad_loss: heads must be 5 + 6x1000 (reference autoregressive_transformer.py:218)"); return VC_ERR_UNSUPPORTED; }
     if (!use_mse && !class_w) { vc_set_error("vcad_loss: use_mse=0 needs class_weights"); return VC_ERR_ARG; }
-    LossParams p; fill_loss_params(e, p, cmds, pars, targets, B, T, use_mse, class_w);
+    if (!label_weights_host) { vc_set_error("vcad_loss: label_weights (class_weights.json \"Label\", 5 host floats) is required"); return VC_ERR_ARG; }
+    LossParams p; fill_loss_params(e, p, cmds, pars, targets, B, T, use_mse, label_weights_host, class_w);
     vc_stream_t s = (vc_stream_t)stream;
     CK(vc_loss_fwd(p, s));
     CK(vc_loss_bwd(p, s));
@@ -920,8 +951,142 @@ int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* 
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Incremental inference (reference model/autoregressive_transformer.py:222-275 `sequential_inference`).
+// The reference re-runs the whole forward on the prefix [0..t] for every step t: t+1 ViT passes and a full decoder pass per step,
+// O(T^2) frames encoded per clip.  The model is causal everywhere (causal / banded self-attention, banded cross-attention,
+// post-norm layers, per-frame ViT), so position t's activations never change once computed: each step here encodes ONE new frame
+// per clip, projects ONE row through every decoder layer and attends to the cached keys / values of the earlier steps.
+// ---------------------------------------------------------------------------------------------------------------
+static size_t infer_plan(vcad_engine* e, int B, int Tmax, char* base) {
+    const vcad_config& c = e->c;
+    size_t off = plan(e, B, 1, base);                     // one frame per clip in flight: the (B, T = 1) activation plan
+    e->ic_kv_s.assign(c.num_decoder_layers, nullptr); e->ic_kv_c.assign(c.num_decoder_layers, nullptr);
+    const size_t per = (size_t)B * Tmax * 2 * c.hidden_size * e->esz;
+    for (int L = 0; L < c.num_decoder_layers; ++L) {
+        off = (off + 255) & ~(size_t)255; e->ic_kv_s[L] = base + off; off += per;
+        off = (off + 255) & ~(size_t)255; e->ic_kv_c[L] = base + off; off += per;
+    }
+    return off + 256;
+}
+
+size_t vcad_infer_workspace_bytes(const vcad_engine* e, int B, int Tmax) {
+    vcad_engine tmp = *e;
+    return infer_plan(&tmp, B, Tmax, nullptr);
+}
+
+static int infer_begin_any(vcad_engine* e, const void* cad, int u8, int B, int Tmax, void* stream) {
+    if (!e->P) { vc_set_error("vcad_infer_begin: parameters not bound"); return VC_ERR_ARG; }
+    if (B < 1 || Tmax < 1 || Tmax > 192 || Tmax > e->c.max_ep_len) { vc_set_error("vcad_infer_begin: bad B=%d Tmax=%d (1 <= Tmax <= 192)", B, Tmax); return VC_ERR_ARG; }
+    if (!e->ws) { vc_set_error("vcad_infer_begin: no workspace"); return VC_ERR_WORKSPACE; }
+    { vcad_engine tmp = *e; const size_t need = infer_plan(&tmp, B, Tmax, nullptr);
+      if (need > e->ws_bytes) { vc_set_error("vcad_infer_begin: workspace %zu < %zu bytes", e->ws_bytes, need); return VC_ERR_WORKSPACE; } }
+    infer_plan(e, B, Tmax, e->ws);
+    e->B = B; e->T = 1; e->planned_ws = e->ws; e->fwd_valid = false;
+    e->infer_T = Tmax; e->infer_t = 0; e->infer_u8 = u8; e->in_u8 = u8; e->in_cad = cad;
+    const float keep_p = e->drop_p; e->drop_p = 0.f;       // inference = model.eval()
+    vc_stream_t s = (vc_stream_t)stream; Ctx cx{e, s}; const vcad_config& c = e->c;
+    const int H = c.hidden_size, D = c.vit_dim;
+    int rc = vit_forward(cx, 1, cad, 1, (long)c.image_size * c.image_size);
+    if (!rc) { Epi ep; ep.bias = cx.Pf(e->o_ei_b); rc = cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep); }
+    if (!rc && c.enable_past_actions && c.enable_past_states) {
+        Epi ep; ep.bias = cx.Pf(e->o_ip_b);
+        rc = cx.lin_fwd(cx.AT(e->cadE, H), cx.W(e->o_ip_w + H, 2 * H), cx.A32(e->cadterm, H), B, H, H, ep);
+    }
+    e->drop_p = keep_p;
+    if (rc) return rc;
+    if (vc_last_launch_error()) { vc_set_error("vcad_infer_begin: kernel launch failed"); return VC_ERR_LAUNCH; }
+    return 0;
+}
+int vcad_infer_begin(vcad_engine* e, const float* cad, int B, int Tmax, void* stream) { return infer_begin_any(e, cad, 0, B, Tmax, stream); }
+int vcad_infer_begin_u8(vcad_engine* e, const uint8_t* cad, int B, int Tmax, void* stream) {
+    if ((uintptr_t)cad & 3) { vc_set_error("vcad_infer_begin_u8: cad must be 4-byte aligned"); return VC_ERR_ARG; }
+    return infer_begin_any(e, cad, 1, B, Tmax, stream);
+}
+
+// one cached attention: the single query row of step t against rows [lo(t) .. t] of this layer's cache
+static int infer_attn(const Ctx& cx, const void* q, void* kv_cache, void* o, float* lse, int t, int window) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c; const int H = c.hidden_size;
+    AttnParams p; memset(&p, 0, sizeof(p));
+    p.q = q; p.ldq = H; p.k = kv_cache; p.v = (char*)kv_cache + (size_t)H * e->esz; p.ldk = p.ldv = 2 * H; p.o = o; p.ldo = H; p.lse = lse;
+    p.B = e->B; p.H = c.nhead; p.Tq = 1; p.Tk = t + 1; p.window = window; p.causal = 1; p.qpos = t; p.kv_rows = e->infer_T;
+    const int hd = H / c.nhead; p.scale = 1.0f / sqrtf((float)hd);
+    return vc_attn_fwd(e->dt, hd, p, cx.s);
+}
+
+int vcad_infer_step(vcad_engine* e, int t, const void* frame, int64_t frame_bstride, const float* action_norm, float* cmds_out, float* pars_out,
+                    void* stream) {
+    if (!e->infer_T || e->planned_ws != e->ws || e->T != 1) { vc_set_error("vcad_infer_step: call vcad_infer_begin first"); return VC_ERR_ARG; }
+    if (t != e->infer_t || t >= e->infer_T) { vc_set_error("vcad_infer_step: step %d out of order (next is %d of %d)", t, e->infer_t, e->infer_T); return VC_ERR_ARG; }
+    const vcad_config& c = e->c;
+    const bool pa = c.enable_past_actions, ps = c.enable_past_states;
+    if (ps && !frame) { vc_set_error("vcad_infer_step: frame is null"); return VC_ERR_ARG; }
+    if (pa && !action_norm) { vc_set_error("vcad_infer_step: action is null"); return VC_ERR_ARG; }
+    if (e->infer_u8 && (((uintptr_t)frame | (uintptr_t)frame_bstride) & 3)) { vc_set_error("vcad_infer_step: uint8 frames must be 4-byte aligned"); return VC_ERR_ARG; }
+    vc_stream_t s = (vc_stream_t)stream; Ctx cx{e, s};
+    const int B = e->B, H = c.hidden_size, D = c.vit_dim, ff = c.dim_feedforward, Tmax = e->infer_T; const long M = B;
+    const size_t es = e->esz;
+    const float keep_p = e->drop_p; e->drop_p = 0.f;
+    const float* ts = c.enable_timestep_embedding ? cx.Pf(e->o_ts) + (long)t * H : nullptr;     // row t of the timestep table
+    e->in_frames = frame; e->in_fbstride = frame_bstride; e->in_actions = action_norm; e->in_u8 = e->infer_u8;
+    auto body = [&]() -> int {
+        if (ps) {
+            CK(vit_forward(cx, 0, frame, 1, frame_bstride));
+            Epi ep; ep.bias = cx.Pf(e->o_es_b); ep.rowadd = ts; ep.rdiv = 1; ep.rmod = 1; ep.ldrow = H; ep.act = VC_ACT_TANH;
+            CK(cx.lin_fwd(cx.AT(e->va[0].e, D), cx.W(e->o_es_w, D), cx.A32(e->ui, H), B, H, D, ep));
+        }
+        if (pa && ps) {
+            Epi ep; ep.rowadd = e->cadterm; ep.rdiv = 1; ep.rmod = 0; ep.ldrow = H; ep.act = VC_ACT_TANH;
+            CK(cx.lin_fwd(cx.A32(e->ui, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->mem, H), B, H, H, ep));
+        } else {
+            CK(vc_bcast_tanh(e->dt, e->cadE, e->mem, M, H, 1, s));
+        }
+        if (pa) CK(vc_embed_action(VC_F32, action_norm, cx.Pf(e->o_ea_w), cx.Pf(e->o_ea_b), ts, e->act, nullptr, M, H, c.act_dim, 1, s));
+        const float* x = pa ? e->act : (ps ? e->ui : e->mem);
+        const int sa_window = pa ? Tmax : c.window_size;
+        const long cld = (long)Tmax * 2 * H;                                   // cache row stride between clips, in elements
+        for (int L = 0; L < c.num_decoder_layers; ++L) {
+            const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
+            char* kvs = (char*)e->ic_kv_s[L]; char* kvc = (char*)e->ic_kv_c[L];
+            { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, H), B, H, H, ep)); }
+            { Epi ep; ep.bias = cx.Pf(w.sa_b + H);
+              CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w + (long)H * H, H), cx.AT(kvs + (size_t)t * 2 * H * es, cld), B, 2 * H, H, ep)); }
+            CK(infer_attn(cx, d.qkv_s, kvs, d.ao_s, d.lse_s, t, sa_window));
+            { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), B, H, H, ep)); }
+            CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, nullptr, 0, d.st1, M, H));
+            { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), B, H, H, ep)); }
+            { Epi ep; ep.bias = cx.Pf(w.ca_b + H);
+              CK(cx.lin_fwd(cx.A32(e->mem, H), cx.W(w.ca_w + (long)H * H, H), cx.AT(kvc + (size_t)t * 2 * H * es, cld), B, 2 * H, H, ep)); }
+            CK(infer_attn(cx, d.q_c, kvc, d.ao_c, d.lse_c, t, c.window_size));
+            { Epi ep; ep.bias = cx.Pf(w.ca_ob); ep.residual = d.x1; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.ao_c, H), cx.W(w.ca_ow, H), cx.A32(d.s2, H), B, H, H, ep)); }
+            CK(cx.ln_fwd(VC_F32, d.s2, H, w.n2w, w.n2b, d.x2, H, nullptr, 0, d.st2, M, H));
+            { Epi ep; ep.bias = cx.Pf(w.b1); ep.act = VC_ACT_RELU; CK(cx.lin_fwd(cx.A32(d.x2, H), cx.W(w.w1, H), cx.AT(d.f1, ff), B, ff, H, ep)); }
+            { Epi ep; ep.bias = cx.Pf(w.b2); ep.residual = d.x2; ep.ldr = H; CK(cx.lin_fwd(cx.AT(d.f1, ff), cx.W(w.w2, ff), cx.A32(d.s3, H), B, H, ff, ep)); }
+            CK(cx.ln_fwd(VC_F32, d.s3, H, w.n3w, w.n3b, d.x3, H, nullptr, 0, d.st3, M, H));
+            x = d.x3;
+        }
+        const int n5 = c.num_classes, n6 = c.num_params * c.num_params_values;
+        { Epi ep; ep.bias = cx.Pf(e->o_h5_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(e->o_h5_w, H), cx.A32(cmds_out, n5), B, n5, H, ep)); }
+        { Epi ep; ep.bias = cx.Pf(e->o_h6_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(e->o_h6_w, H), cx.A32(pars_out, n6), B, n6, H, ep)); }
+        return 0;
+    };
+    const int rc = body();
+    e->drop_p = keep_p;
+    if (rc) return rc;
+    if (vc_last_launch_error()) { vc_set_error("vcad_infer_step: kernel launch failed"); return VC_ERR_LAUNCH; }
+    e->infer_t = t + 1;
+    return 0;
+}
+
 int vcad_optimizer_step(vcad_engine* e, float lr, float b1, float b2, float eps, float max_norm, int step, float gscale,
                         float* norm_out, void* stream) {
+    const float lr4[NB_BUCKETS] = {lr, lr, lr, lr};
+    return vcad_optimizer_step_groups(e, lr4, b1, b2, eps, max_norm, step, gscale, norm_out, stream);
+}
+int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1, float b2, float eps, float max_norm, int step, float gscale,
+                               float* norm_out, void* stream) {
+    if (!lr_bucket) { vc_set_error("vcad_optimizer_step_groups: lr_per_bucket is null"); return VC_ERR_ARG; }
     if (!e->P || !e->G || !e->Mm || !e->Vv) { vc_set_error("vcad_optimizer_step: buffers not bound"); return VC_ERR_ARG; }
     if (!e->ws) { vc_set_error("vcad_optimizer_step: no workspace"); return VC_ERR_WORKSPACE; }
     if (step < 1) { vc_set_error("vcad_optimizer_step: step must be >= 1"); return VC_ERR_ARG; }
@@ -929,11 +1094,18 @@ int vcad_optimizer_step(vcad_engine* e, float lr, float b1, float b2, float eps,
     vc_stream_t s = (vc_stream_t)stream;
     // the norm the reference clips against is that of the (already averaged) gradients
     CK(vc_grad_norm(e->G, e->ptotal, max_norm, gscale, e->norm_part, e->norm_out, s));
-    AdamParams a; memset(&a, 0, sizeof(a));
-    a.p = e->P; a.g = e->G; a.m = e->Mm; a.v = e->Vv; a.n = e->ptotal; a.lr = lr; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
-    a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
-    a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S;
-    CK(vc_adam(a, s));
+    // one launch per run of buckets that share a learning rate (the reference's `frozen` mode, trainer.py:237-251, gives the CAD ViT,
+    // the frame ViT and everything else their own lr: exactly buckets 1, 2-3 and 0 of the flat layout); the clip norm stays global
+    for (int b0 = 0; b0 < NB_BUCKETS;) {
+        int b1i = b0; while (b1i + 1 < NB_BUCKETS && lr_bucket[b1i + 1] == lr_bucket[b0]) ++b1i;
+        const long lo = e->buckets[b0].first, hi = e->buckets[b1i].second;
+        AdamParams a; memset(&a, 0, sizeof(a));
+        a.p = e->P + lo; a.g = e->G + lo; a.m = e->Mm + lo; a.v = e->Vv + lo; a.n = hi - lo; a.lr = lr_bucket[b0]; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
+        a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
+        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr;
+        CK(vc_adam(a, s));
+        b0 = b1i + 1;
+    }
     e->wT_fresh = false;                  // the bf16 shadow just changed: its transposed copies are rebuilt before the next backward
     if (norm_out) CK(vc_memcpy_d2d_async(norm_out, e->norm_out, 2 * 4, s));
     return 0;

@@ -50,17 +50,26 @@ VC_DEV void row_stats(const float (&v)[VPL], float eps, float& mean, float& rstd
 // patch p of frame n: vector index e = p1*32 + p2 (c = 1) <- frame[n][ph*32+p1][pw*32+p2]
 // ('b c (h p1) (w p2) -> b (h w) (p1 p2 c)', reference model/trajectory_model.py:54-65 via vit-pytorch)
 // image n = b*T + t lives at frames + b*bstride + t*img*img (so the [:, :-1] view of the loader batch needs no copy)
+// u8 = 1: the frames are the loader's uint8 grayscale pixels and the torchvision ToTensor + Normalize(0.5, 0.5) of the reference
+// (main.py:103-108; data_loader.py:441-447) happens here, in the same fp32 operations and order ((u / 255 - 0.5) / 0.5, correctly
+// rounded division), so the patch vectors are bit-identical to the fp32 path while PCIe and HBM carry 1 byte per pixel instead of 4.
+VC_DEV void quad_load_u8norm(const uint8_t* p, float* v) {
+    const uint32_t q = *reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((float)((q >> (8 * k)) & 0xFFu) / 255.0f - 0.5f) / 0.5f;
+}
 template <int VPL>
-VC_DEV void patch_load(const float* frames, long row, float (&v)[VPL], int lane, int img, int patch, int T, long bstride) {
+VC_DEV void patch_load(const void* frames_, int u8, long row, float (&v)[VPL], int lane, int img, int patch, int T, long bstride) {
     const int g_ = img / patch;
     const long n = row / (g_ * g_);
     const int pp = (int)(row % (g_ * g_)), ph = pp / g_, pw = pp % g_;
-    const float* base = frames + (n / T) * bstride + (n % T) * (long)img * img + (long)(ph * patch) * img + pw * patch;
+    const long off = (n / T) * bstride + (n % T) * (long)img * img + (long)(ph * patch) * img + pw * patch;
 #pragma unroll
     for (int g = 0; g < VPL / 4; ++g) {
         int e = g * 256 + lane * 4;
         int p1 = e / patch, p2 = e % patch;
-        quad_load<float>(base + (long)p1 * img + p2, &v[g * 4]);
+        if (u8) quad_load_u8norm((const uint8_t*)frames_ + off + (long)p1 * img + p2, &v[g * 4]);
+        else quad_load<float>((const float*)frames_ + off + (long)p1 * img + p2, &v[g * 4]);
     }
 }
 
@@ -71,7 +80,7 @@ struct LnFwdParams {
     void* yt; long ldyt;              // optional T output
     float* stats;                     // optional [rows][2] = mean, rstd
     long rows; float eps;
-    int img, patch;                   // PATCH mode
+    int img, patch; int u8;           // PATCH mode (u8: uint8 pixels, normalised on load)
     // EMBED mode: input row r = n*P + p  ->  output row n*(P+1) + p + 1, plus pos[p+1]; extra rows write cls+pos[0]
     const float* pos; const float* cls; int P;
     vc_drop drop;                     // EMBED mode: emb_dropout on the finished token rows (idx = out_row * C + col)
@@ -102,7 +111,7 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
         }
         in_row = n * p.P + (t - 1);
     }
-    if constexpr (MODE == 1) patch_load<VPL>((const float*)p.x, row, v, lane, p.img, p.patch, p.P, p.ldx);   // P = T, ldx = batch stride
+    if constexpr (MODE == 1) patch_load<VPL>(p.x, p.u8, row, v, lane, p.img, p.patch, p.P, p.ldx);   // P = T, ldx = batch stride
     else row_load<TX, VPL>((const TX*)p.x + in_row * p.ldx, v, lane);
     float mean, rstd;
     row_stats<VPL>(v, p.eps, mean, rstd);
@@ -136,7 +145,7 @@ struct LnBwdParams {
     vc_drop drop;                     //   gradient the next (dropped) Linear's wgrad / dgrad consume, fused here instead of a separate pass
     float* partial;                   // [gridDim.x][2][C] dgamma / dbeta partial sums (fixed order => deterministic)
     long rows;
-    int img, patch; int P;            // PATCH / EMBED mapping (EMBED: dy row = n*(P+1)+p+1 for x row n*P+p)
+    int img, patch; int P; int u8;    // PATCH / EMBED mapping (EMBED: dy row = n*(P+1)+p+1 for x row n*P+p); u8 as in LnFwdParams
 };
 
 template <typename TD, typename TX, typename TY, int VPL, int MODE>
@@ -152,7 +161,7 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
         float x[VPL], dy[VPL];
         long dy_row = row;
         if constexpr (MODE == 2) dy_row = (row / p.P) * (p.P + 1) + (row % p.P) + 1;
-        if constexpr (MODE == 1) patch_load<VPL>((const float*)p.x, row, x, lane, p.img, p.patch, p.P, p.ldx);
+        if constexpr (MODE == 1) patch_load<VPL>(p.x, p.u8, row, x, lane, p.img, p.patch, p.P, p.ldx);
         else row_load<TX, VPL>((const TX*)p.x + row * p.ldx, x, lane);
         row_load<TD, VPL>((const TD*)p.dy + dy_row * p.lddy, dy, lane);
         const float mean = p.stats[row * 2], rstd = p.stats[row * 2 + 1];

@@ -2,7 +2,7 @@
 #include "ops.h"
 #include "attn_mfma.h"
 
-static int clampw(const AttnParams& p) { int mx = p.Tq > p.Tk ? p.Tq : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
+static int clampw(const AttnParams& p) { int mx = (p.Tq + p.qpos) > p.Tk ? (p.Tq + p.qpos) : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
 static int max_keys(const AttnParams& p) { int w = clampw(p); return w < p.Tk ? w : p.Tk; }        // visible keys per query
 static int max_queries(const AttnParams& p) { int w = clampw(p); return w < p.Tq ? w : p.Tq; }     // queries per key
 
@@ -11,7 +11,9 @@ static int attn_fwd_t(int D, AttnParams p, vc_stream_t s) {
     const long waves = (long)p.B * p.H * p.Tq;
     dim3 g((unsigned)VC_CEIL_DIV(waves, 4));
     const int np = VC_CEIL_DIV(max_keys(p), 64);
-    if (D == 64 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 1, 1>), g, dim3(256), 0, s, p);
+    if (D == 128 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 2, 1>), g, dim3(256), 0, s, p);
+    else if (D == 128 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 2, 3>), g, dim3(256), 0, s, p);
+    else if (D == 64 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 1, 1>), g, dim3(256), 0, s, p);
     else if (D == 256 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 4, 1>), g, dim3(256), 0, s, p);
     else if (D == 256 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 4, 3>), g, dim3(256), 0, s, p);
     else if (D == 64 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 1, 3>), g, dim3(256), 0, s, p);
@@ -22,17 +24,26 @@ template <typename T>
 static int attn_bwd_t(int D, AttnParams p, vc_stream_t s) {
     dim3 gq((unsigned)VC_CEIL_DIV((long)p.B * p.H * p.Tq, 4)), gk((unsigned)VC_CEIL_DIV((long)p.B * p.H * p.Tk, 4));
     const int npk = VC_CEIL_DIV(max_keys(p), 64), npq = VC_CEIL_DIV(max_queries(p), 64);
-    if (D == 64 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 1>), gq, dim3(256), 0, s, p);
+    if (D == 128 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 2, 1>), gq, dim3(256), 0, s, p);
+    else if (D == 128 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 2, 3>), gq, dim3(256), 0, s, p);
+    else if (D == 64 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 1>), gq, dim3(256), 0, s, p);
     else if (D == 256 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 1>), gq, dim3(256), 0, s, p);
     else if (D == 256 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 3>), gq, dim3(256), 0, s, p);
     else if (D == 64 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 3>), gq, dim3(256), 0, s, p);
     else { vc_set_error("attn_bwd_q: D=%d keys=%d unsupported", D, max_keys(p)); return VC_ERR_UNSUPPORTED; }
-    if (D == 64 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 1>), gk, dim3(256), 0, s, p);
+    if (D == 128 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 2, 1>), gk, dim3(256), 0, s, p);
+    else if (D == 128 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 2, 3>), gk, dim3(256), 0, s, p);
+    else if (D == 64 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 1>), gk, dim3(256), 0, s, p);
     else if (D == 256 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 1>), gk, dim3(256), 0, s, p);
     else if (D == 256 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 3>), gk, dim3(256), 0, s, p);
     else if (D == 64 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 3>), gk, dim3(256), 0, s, p);
     else { vc_set_error("attn_bwd_kv: D=%d queries=%d unsupported", D, max_queries(p)); return VC_ERR_UNSUPPORTED; }
     return VC_OK;
+}
+// algorithmic HBM bytes: forward reads q, k, v and writes o (+ the log-sum-exp); backward reads q, k, v, dO and writes dq, dk, dv
+static double attn_bytes(const AttnParams& p, int D, int t, bool bwd) {
+    const double es = t == VC_BF16 ? 2.0 : 4.0, hd = (double)p.B * p.H * D * es;
+    return bwd ? hd * (3.0 * p.Tq + 4.0 * p.Tk) + 8.0 * p.B * p.H * p.Tq : hd * (2.0 * p.Tq + 2.0 * p.Tk) + 4.0 * p.B * p.H * p.Tq;
 }
 static double attn_flops(const AttnParams& p, int D) {      // 2 GEMM-like contractions over the visible keys
     return 4.0 * p.B * p.H * (double)p.Tq * max_keys(p) * D;
@@ -40,7 +51,7 @@ static double attn_flops(const AttnParams& p, int D) {      // 2 GEMM-like contr
 // MFMA path: bf16, 64-dim heads, <= 64 tokens, full (non-causal) attention, 16-byte-aligned head slices (the ViT)
 static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
-    bool ok = t == VC_BF16 && D == AM_D && p.Tq == p.Tk && p.Tq <= AM_T && !p.causal && clampw(p) >= p.Tk &&
+    bool ok = t == VC_BF16 && D == AM_D && p.Tq == p.Tk && p.Tq <= AM_T && !p.causal && clampw(p) >= p.Tk && !p.qpos && !p.kv_rows &&
               al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
@@ -48,14 +59,14 @@ static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
 // decoder attention on the matrix cores (attn_mfma.h): bf16, head dim 256, causal (+ window band), T <= 64
 static bool dec_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
-    bool ok = t == VC_BF16 && D == 4 * AM_D && p.Tq == p.Tk && p.Tq <= AM_T && p.causal && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    bool ok = t == VC_BF16 && (D == 4 * AM_D || D == 2 * AM_D) && p.Tq == p.Tk && p.Tq <= AM_T && p.causal && !p.qpos && !p.kv_rows && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
 }
 // ... and for 64 < T <= 192 (key-block loop)
 static bool dec_long_ok(int t, int D, const AttnParams& p, bool bwd) {
     auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
-    bool ok = t == VC_BF16 && D == 4 * AM_D && p.Tq == p.Tk && p.Tq > AM_T && p.Tq <= AM_MAXB * AM_T && p.causal && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    bool ok = t == VC_BF16 && (D == 4 * AM_D || D == 2 * AM_D) && p.Tq == p.Tk && p.Tq > AM_T && p.Tq <= AM_MAXB * AM_T && p.causal && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.delta && p.dq && p.dk && p.dv;
 }
@@ -78,21 +89,22 @@ static int check_rows_aligned(int t, const AttnParams& p, bool bwd) {
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     if (int rc = check_rows_aligned(t, p, false)) return rc;
-    ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), 0, s);
+    ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), attn_bytes(p, D, t, false), s);
     if (mfma_ok(t, D, p, false)) {
         if (p.drop.key) VC_LAUNCH((attn_vit_fwd_mfma_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         else VC_LAUNCH((attn_vit_fwd_mfma_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         return VC_OK;
     }
     if (dec_mfma_ok(t, D, p, false)) {
-        if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
-        else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
+        const dim3 g((unsigned)((long)p.B * p.H));
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
+        else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 2>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 2>), g, dim3(64), 0, s, p); }
         return VC_OK;
     }
     if (dec_long_ok(t, D, p, false)) {
-        const unsigned g = (unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T));
-        if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 4>), dim3(g), dim3(64), 0, s, p);
-        else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 4>), dim3(g), dim3(64), 0, s, p);
+        const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
+        else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 2>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 2>), g, dim3(64), 0, s, p); }
         return VC_OK;
     }
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
@@ -100,7 +112,7 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     if (int rc = check_rows_aligned(t, p, true)) return rc;
-    ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), 0, s);
+    ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), attn_bytes(p, D, t, true), s);
     if (p.Tq == 1 && !p.causal && p.Tk <= 64 && D == 64 && p.window >= p.Tk) {     // cls-only query (last ViT layer)
         dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4));
         if (t == VC_BF16) VC_LAUNCH((attn_bwd_single_query_kernel<vc_bf16, 1>), g, dim3(256), 0, s, p);
@@ -113,8 +125,9 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         return VC_OK;
     }
     if (dec_mfma_ok(t, D, p, true)) {
-        if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
-        else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 4>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        const dim3 g((unsigned)((long)p.B * p.H));
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 4>), g, dim3(128), 0, s, p); else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 4>), g, dim3(128), 0, s, p); }
+        else               { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 2>), g, dim3(128), 0, s, p); else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 2>), g, dim3(128), 0, s, p); }
         return VC_OK;
     }
     if (dec_long_ok(t, D, p, true)) {
@@ -124,16 +137,18 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
             if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 4>, AM_LONG_Q_LDS)) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 4>, AM_LONG_KV_LDS)) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<false, 4>, AM_LONG_KV_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<true, 2>, AM_LONG_Q_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 2>, AM_LONG_Q_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 2>, AM_LONG_KV_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<false, 2>, AM_LONG_KV_LDS)) return rc;
             attr = true;
         }
-        const unsigned g = (unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T));
-        if (p.drop.key) {
-            VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<true, 4>), dim3(g), dim3(64), AM_LONG_Q_LDS, s, p);
-            VC_LAUNCH((attn_dec_bwd_kv_long_mfma_kernel<true, 4>), dim3(g), dim3(64), AM_LONG_KV_LDS, s, p);
-        } else {
-            VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<false, 4>), dim3(g), dim3(64), AM_LONG_Q_LDS, s, p);
-            VC_LAUNCH((attn_dec_bwd_kv_long_mfma_kernel<false, 4>), dim3(g), dim3(64), AM_LONG_KV_LDS, s, p);
-        }
+        const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
+#define VC_LONG_BWD(DROP_, NCH_) do { VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<DROP_, NCH_>), g, dim3(64), AM_LONG_Q_LDS, s, p); \
+                                      VC_LAUNCH((attn_dec_bwd_kv_long_mfma_kernel<DROP_, NCH_>), g, dim3(64), AM_LONG_KV_LDS, s, p); } while (0)
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LONG_BWD(true, 4); else VC_LONG_BWD(false, 4); }
+        else               { if (p.drop.key) VC_LONG_BWD(true, 2); else VC_LONG_BWD(false, 2); }
+#undef VC_LONG_BWD
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);

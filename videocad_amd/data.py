@@ -1,0 +1,148 @@
+"""Frame batching into pinned host memory and on to HBM (north_star "image_loader.py frame batching into
+pinned HBM").  Everything here is host-side plumbing around ONE contract, the collated batch of the reference loader:
+
+    frames [B,S,1,224,224], actions [B,S,7] f32, cad_image [B,1,224,224], timesteps [B,S] i64, multiview_images None
+
+  * `pad_array` / `collate_with_padding` — twins of reference data_loader/data_loader.py:313-366 (pad every clip to the batch
+    maximum with -1, `timesteps = arange(max_len)`), writing straight into PINNED buffers (the reference gets pinning from
+    `DataLoader(pin_memory=True)`, :186-196, through one more copy).
+  * uint8 mode — the stored frames are uint8 (pkl `frames uint8 [N,224,224,3]`, reference :434-447); the reference converts
+    every frame to fp32 on the host (PIL Grayscale -> ToTensor -> Normalize(0.5, 0.5)) and ships 4 bytes per pixel over PCIe
+    (trainer.py:308).  Here the host only does the integer part — `pil_grayscale_u8`, PIL's exact ITU-R 601-2 integer luma —
+    and the batch stays uint8: 1 byte per pixel over PCIe and in HBM; `(u/255 - 0.5)/0.5` happens inside the patchify kernel
+    (csrc/norm.h, `vcad_forward_u8`) with the same fp32 operations, so the patch vectors are bit-identical.  Padding value
+    -1.0 is pixel 0 in that encoding ((0/255 - 0.5)/0.5 == -1.0 exactly).
+  * `DeviceStager` — double-buffered H2D staging on its own stream: batch i+1 is copied while step i computes.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, List, Optional
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------------ pixel conversions (host, integer)
+def pil_grayscale_u8(rgb: np.ndarray) -> np.ndarray:
+    """PIL `Image.convert('L')` / torchvision `Grayscale()` on uint8 [..., 3] (reference data_loader.py:444-445, main.py:105):
+    L = (R*19595 + G*38470 + B*7471 + 0x8000) >> 16  (ITU-R 601-2 luma in 16.16 fixed point; verified bit-exact against PIL)."""
+    a = rgb.astype(np.uint32)
+    return ((a[..., 0] * 19595 + a[..., 1] * 38470 + a[..., 2] * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def cv2_bgr2gray_u8(bgr: np.ndarray) -> np.ndarray:
+    """OpenCV `cvtColor(COLOR_BGR2GRAY)` on uint8 [..., 3] (the CAD image path, reference data_loader.py:471): OpenCV's published
+    14-bit fixed-point form Y = (B*1868 + G*9617 + R*4899 + (1 << 13)) >> 14.  (cv2 is not in this image: restated, not probed.)"""
+    a = bgr.astype(np.uint32)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def normalize_u8(gray_u8: torch.Tensor) -> torch.Tensor:
+    """ToTensor + Normalize(0.5, 0.5) (reference main.py:103-108) — what the patchify kernel applies to uint8 pixels."""
+    return (gray_u8.to(torch.float32) / 255.0 - 0.5) / 0.5
+
+
+def frames_from_rgb(frames_rgb_u8: np.ndarray, as_uint8: bool = True) -> torch.Tensor:
+    """pkl frames uint8 [N,H,W,3] -> [N,1,H,W]: uint8 gray (as_uint8) or the reference's normalised fp32."""
+    g = torch.from_numpy(pil_grayscale_u8(frames_rgb_u8)).unsqueeze(1)
+    return g if as_uint8 else normalize_u8(g)
+
+
+# ------------------------------------------------------------------------------------------------ collate
+def _pad_value(dtype: torch.dtype):
+    return 0 if dtype == torch.uint8 else -1           # pixel 0 == -1.0 after normalisation
+
+
+def pad_array(max_len: int, array: torch.Tensor) -> torch.Tensor:
+    """reference data_loader.py:313-318"""
+    pad = max_len - array.shape[0]
+    if pad > 0:
+        array = torch.cat([array, torch.full((pad, *array.shape[1:]), _pad_value(array.dtype), dtype=array.dtype)], dim=0)
+    return array
+
+
+def collate_with_padding(batch: List[dict], pin: bool = True) -> dict:
+    """reference data_loader.py:321-366, writing into pinned buffers (one copy instead of cat + stack + pin).
+    Items: {'frames' [S_i,1,H,W] f32|u8, 'actions' [S_i,7], 'cad_image' [1,H,W] f32|u8, optional 'multiview_images'}."""
+    B = len(batch)
+    max_len = max(int(it["frames"].shape[0]) for it in batch)
+    f0, a0, c0 = batch[0]["frames"], batch[0]["actions"], batch[0]["cad_image"]
+    pin = bool(pin and torch.cuda.is_available())
+
+    def buf(shape, dtype, fill=None):
+        t = torch.empty(shape, dtype=dtype, pin_memory=pin)
+        if fill is not None:
+            t.fill_(fill)
+        return t
+
+    frames = buf((B, max_len, *f0.shape[1:]), f0.dtype, _pad_value(f0.dtype))
+    actions = buf((B, max_len, *a0.shape[1:]), torch.float32, -1)
+    cad = buf((B, *c0.shape), c0.dtype)
+    for b, it in enumerate(batch):
+        n = int(it["frames"].shape[0])
+        frames[b, :n].copy_(it["frames"]); actions[b, :n].copy_(it["actions"]); cad[b].copy_(it["cad_image"])
+    out = {"frames": frames, "actions": actions, "cad_image": cad,
+           "timesteps": torch.arange(max_len).repeat(B, 1)}                     # :337 — fresh arange, whatever the items carried
+    mv = [it.get("multiview_images", None) for it in batch]
+    out["multiview_images"] = torch.stack(mv) if all(m is not None for m in mv) else None
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ H2D staging
+class DeviceStager:
+    """Wraps a loader of collated (ideally pinned) batches: yields device-resident batch dicts, the NEXT batch's H2D copy running
+    on a private stream while the caller computes on the current one (reference trainer.py:307-311 copies synchronously on the
+    compute stream).  Two device buffer sets alternate; a batch's buffers are handed back to the copy stream only after the
+    compute stream has passed the point where the following batch was requested."""
+
+    KEYS = ("frames", "actions", "cad_image", "timesteps", "multiview_images")
+
+    def __init__(self, loader: Iterable, device, frames_dtype: Optional[torch.dtype] = None):
+        self.loader, self.device = loader, torch.device(device)
+        self.frames_dtype = frames_dtype
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch: dict) -> dict:
+        out = {}
+        for k in self.KEYS:
+            v = batch.get(k, None)
+            if v is None:
+                continue
+            if k == "timesteps":
+                out[k] = v.to(self.device, dtype=torch.long, non_blocking=True)
+            elif v.dtype == torch.uint8:
+                out[k] = v.to(self.device, non_blocking=True)                     # stays uint8: normalised in the patchify kernel
+            else:
+                out[k] = v.to(self.device, dtype=torch.float, non_blocking=True)
+        return out
+
+    def __iter__(self) -> Iterator[dict]:
+        it = iter(self.loader)
+        if self.copy_stream is None:
+            for b in it:
+                yield self._stage(b)
+            return
+        cur = torch.cuda.current_stream(self.device)
+
+        def fetch():
+            try:
+                b = next(it)
+            except StopIteration:
+                return None
+            self.copy_stream.wait_stream(cur)          # buffers freed by the allocator are reused in stream order of `cur`
+            with torch.cuda.stream(self.copy_stream):
+                d = self._stage(b)
+            ev = torch.cuda.Event(); ev.record(self.copy_stream)
+            return d, ev, b                            # keep the pinned source alive until the copy has been waited for
+
+        nxt = fetch()
+        while nxt is not None:
+            d, ev, _src = nxt
+            cur.wait_event(ev)
+            for v in d.values():
+                v.record_stream(cur)
+            nxt = fetch()                              # enqueue the next copy before the caller starts computing on `d`
+            yield d

@@ -30,8 +30,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class NativeEngine:
-    def __init__(self, cfg: L.Config, device, lib=None):
-        self.lib = lib if lib is not None else L.load()
+    def __init__(self, cfg: L.Config, device):
+        self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
         h = C.c_void_p()
@@ -98,27 +98,68 @@ class NativeEngine:
 
     # ------------------------------------------------------------------ hot path
     def forward(self, frames: torch.Tensor, actions_norm: torch.Tensor, cad: torch.Tensor):
-        """frames [B,T,1,S,S] fp32 (any batch stride, frames contiguous within a clip), actions_norm [B,T,7], cad [B,1,S,S]."""
+        """frames [B,T,1,S,S] (any batch stride, frames contiguous within a clip), actions_norm [B,T,7], cad [B,1,S,S].
+        frames / cad are either fp32 (already normalised, the reference loader's contract) or BOTH uint8 grayscale pixels
+        (normalised inside the patchify kernel: vcad_forward_u8)."""
         B, T = int(actions_norm.shape[0]), int(actions_norm.shape[1])
         S = self.cfg.image_size
-        assert frames.dtype == torch.float32 and frames.shape[1] == T and tuple(frames.shape[2:]) == (1, S, S)
+        u8 = frames.dtype == torch.uint8
+        assert frames.dtype in (torch.float32, torch.uint8) and frames.shape[1] == T and tuple(frames.shape[2:]) == (1, S, S)
         if frames.stride()[1:] != (S * S, S * S, S, 1):
             frames = frames.contiguous()
         fb = frames.stride(0) if B > 1 else T * S * S
-        actions_norm = actions_norm.contiguous().float(); cad = cad.contiguous().float()
+        actions_norm = actions_norm.contiguous().float()
+        cad = cad.contiguous() if u8 else cad.contiguous().float()
+        assert cad.dtype == frames.dtype, "frames and cad_image must both be fp32 or both be uint8"
         self.ensure_workspace(B, T)
         cmds = torch.empty(B, T, self.cfg.num_classes, device=self.device)
         pars = torch.empty(B, T, self.cfg.num_params, self.cfg.num_params_values, device=self.device)
         self._keep = (frames, actions_norm, cad)          # backward re-reads the inputs (patch-LN grads, embed_action wgrad)
-        L.check(self.lib, self.lib.vcad_forward(self.h, _ptr(frames), fb, _ptr(actions_norm), _ptr(cad), B, T, _ptr(cmds), _ptr(pars),
-                                                self.stream()), "forward")
+        fn = self.lib.vcad_forward_u8 if u8 else self.lib.vcad_forward
+        L.check(self.lib, fn(self.h, _ptr(frames), fb, _ptr(actions_norm), _ptr(cad), B, T, _ptr(cmds), _ptr(pars), self.stream()), "forward")
         return cmds, pars
 
-    def loss(self, cmds, pars, targets, use_mse=True, class_weights: Optional[torch.Tensor] = None):
+    # ------------------------------------------------------------------ incremental inference (include/vcad.h: vcad_infer_*)
+    def infer_begin(self, cad: torch.Tensor, B: int, Tmax: int):
+        need = max(int(self.lib.vcad_infer_workspace_bytes(self.h, B, Tmax)), self.ws.numel() if self.ws is not None else 0)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = None
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            L.check(self.lib, self.lib.vcad_set_workspace(self.h, _ptr(self.ws), need), "set_workspace")
+        u8 = cad.dtype == torch.uint8
+        cad = cad.contiguous() if u8 else cad.contiguous().float()
+        self._keep_i = cad
+        fn = self.lib.vcad_infer_begin_u8 if u8 else self.lib.vcad_infer_begin
+        L.check(self.lib, fn(self.h, _ptr(cad), B, Tmax, self.stream()), "infer_begin")
+        self._infer_u8 = u8
+
+    def infer_step(self, t: int, frame: Optional[torch.Tensor], action_norm: Optional[torch.Tensor]):
+        """frame [B,1,S,S] (view of clip frames is fine: only the batch stride matters), action_norm [B,7] -> (cmds [B,5], params [B,6,1000])"""
+        S = self.cfg.image_size
+        B = int(frame.shape[0]) if frame is not None else int(action_norm.shape[0])
+        fb = 0
+        if frame is not None:
+            assert (frame.dtype == torch.uint8) == self._infer_u8
+            if not self._infer_u8:
+                frame = frame.float()
+            if frame.stride()[1:] != (S * S, S, 1):
+                frame = frame.contiguous()
+            fb = frame.stride(0) if B > 1 else S * S
+        if action_norm is not None:
+            action_norm = action_norm.contiguous().float()
+        cmds = torch.empty(B, self.cfg.num_classes, device=self.device)
+        pars = torch.empty(B, self.cfg.num_params, self.cfg.num_params_values, device=self.device)
+        self._keep_s = (frame, action_norm)
+        L.check(self.lib, self.lib.vcad_infer_step(self.h, t, _ptr(frame), fb, _ptr(action_norm), _ptr(cmds), _ptr(pars), self.stream()), "infer_step")
+        return cmds, pars
+
+    def loss(self, cmds, pars, targets, label_weights, use_mse=True, class_weights: Optional[torch.Tensor] = None):
+        """label_weights: the 5 floats of class_weights.json["Label"] (host; the trainer reads the file like reference trainer.py:822)."""
         B, T = cmds.shape[0], cmds.shape[1]
         targets = targets.reshape(B * T, 7).contiguous().float()
         out = torch.empty(8, device=self.device); met = torch.empty(L.NMETRIC, dtype=torch.int32, device=self.device)
-        L.check(self.lib, self.lib.vcad_loss(self.h, _ptr(cmds), _ptr(pars), _ptr(targets), B, T, int(use_mse), _ptr(class_weights),
+        lw = (C.c_float * 5)(*[float(x) for x in label_weights])
+        L.check(self.lib, self.lib.vcad_loss(self.h, _ptr(cmds), _ptr(pars), _ptr(targets), B, T, int(use_mse), C.byref(lw), _ptr(class_weights),
                                              _ptr(out), _ptr(met), self.stream()), "loss")
         self._keep_t = targets
         return out, met
@@ -148,12 +189,19 @@ class NativeEngine:
         L.check(self.lib, self.lib.vcad_join_side(self.h, self.stream()), "join_side")
 
     def optimizer_step(self, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0):
+        """lr: one float, or one float per gradient bucket (the reference's `frozen` parameter groups)."""
         self.step_count += 1
         if self.ws is None:
             self.ensure_workspace(1, 1)
         norm = torch.empty(2, device=self.device)
-        L.check(self.lib, self.lib.vcad_optimizer_step(self.h, lr, betas[0], betas[1], eps, max_norm, self.step_count, grad_scale,
-                                                       _ptr(norm), self.stream()), "optimizer_step")
+        if isinstance(lr, (list, tuple)):
+            assert len(lr) == len(self.buckets)
+            lrs = (C.c_float * len(lr))(*[float(x) for x in lr])
+            L.check(self.lib, self.lib.vcad_optimizer_step_groups(self.h, lrs, betas[0], betas[1], eps, max_norm, self.step_count, grad_scale,
+                                                                  _ptr(norm), self.stream()), "optimizer_step")
+        else:
+            L.check(self.lib, self.lib.vcad_optimizer_step(self.h, lr, betas[0], betas[1], eps, max_norm, self.step_count, grad_scale,
+                                                           _ptr(norm), self.stream()), "optimizer_step")
         return norm
 
     def __del__(self):

@@ -46,18 +46,26 @@ PROTOTYPES = {
     "vcad_set_dropout": (_i, [_vp, _f, C.c_uint64]),
     "vcad_debug_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "vcad_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "vcad_forward_u8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "vcad_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float * 5), _vp, _vp, _vp, _vp]),
     "vcad_dlogits_offsets": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "vcad_backward": (_i, [_vp, _vp, _vp, _vp]),
     "vcad_backward_stage": (_i, [_vp, _i, _vp, _vp, _vp]),
     "vcad_backward_stage_side": (_i, [_vp, _i, _vp, _vp, _vp]),
     "vcad_join_side": (_i, [_vp, _vp]),
     "vcad_optimizer_step": (_i, [_vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    "vcad_optimizer_step_groups": (_i, [_vp, C.POINTER(_f), _f, _f, _f, _f, _i, _f, _vp, _vp]),
+    "vcad_infer_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "vcad_infer_begin": (_i, [_vp, _vp, _i, _i, _vp]),
+    "vcad_infer_begin_u8": (_i, [_vp, _vp, _i, _i, _vp]),
+    "vcad_infer_step": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "vcad_profile_begin": (None, []),
     "vcad_profile_end": (_i, [C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_int * 8)]),
     "vcad_debug_force_gemm_tile": (None, [_i]),
     "vcad_debug_gemm_dma": (None, [_i]),
     "vcad_debug_gemm_dma_launches": (C.c_long, []),
+    "vcad_debug_gemm_stagger": (None, [_i]),
+    "vcad_debug_gemm_skip": (None, [_i]),
     "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, _vp]),
     "vcad_op_layernorm_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
     "vcad_op_layernorm_bwd": (_i, [_i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),

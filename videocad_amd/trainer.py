@@ -1,22 +1,29 @@
 """Trainer with the reference's surface (reference trainer.py:193-1385): `create_trainer(...)`, `.train(epochs)`,
-`._process_batch(batch, noise=False) -> (loss, metrics)`, `.compute_loss(action_preds, actions)`, `.evaluate(model, mode)`.
+`._process_batch(batch, noise=False) -> (loss, metrics)`, `.compute_loss(action_preds, actions)`, `.evaluate(model, mode)`,
+`.sample(...)`, `.find_first_mistake(...)`, `.save_checkpoint(...)`.
 
 The hot loop (`_process_batch`, reference :480-496) is ONE pass through the C ABI:
     vcad_forward -> vcad_loss (loss + ~45 metric counters + dlogits, no host sync) -> vcad_backward_stage x4
     (gradient all-reduce of each finished bucket over RCCL on a side stream, world_size > 1) -> vcad_optimizer_step
     (global-norm clip 1.0 + Adam, reference :493-494).
-Epoch loop / logging / checkpoints are plain Python plumbing kept deliberately small (out of scope).
+The epoch loop keeps the reference's contract — per-epoch validation (`val_frequency`), checkpoints every `save_frequency`
+epochs in the reference's on-disk format, early stopping with the all-ranks-agree flag, metric JSON dumps under logs/ — on top
+of that step; evaluation accumulates the fused counters on the device and (unlike the reference, quirk 6) reduces them over ranks.
 """
 from __future__ import annotations
 
+import csv
+import datetime
 import json
 import os
+import random
 import time
 from typing import Optional
 
 import torch
 
 from . import lib as L
+from .data import DeviceStager
 from .model_factory import ModelType
 
 TOLERANCE = 3                                                   # reference trainer.py:20
@@ -39,19 +46,147 @@ def metrics_from_counters(m) -> dict:
     return d
 
 
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+# ------------------------------------------------------------------------------------------------ logs / checkpoints
+class MetricsHandler:
+    """logs/<experiment>/<ext>.json on rank 0 (reference trainer.py:86-131)."""
+
+    def __init__(self, experiment_name, rank=0):
+        self.experiment_name, self.is_master = experiment_name, rank == 0
+        self.dir = os.path.join("logs", experiment_name)
+        if self.is_master:
+            os.makedirs(self.dir, exist_ok=True)
+
+    def save_metrics(self, metrics, ext=""):
+        if not self.is_master:
+            return
+        os.makedirs(self.dir, exist_ok=True)
+        name = ext if ext else datetime.datetime.now().strftime("%Y%m%d_%H%M%S")
+        with open(os.path.join(self.dir, f"{name}.json"), "w") as f:
+            json.dump(metrics, f, indent=4)
+
+    def print_metrics(self, metrics, mode=""):
+        if not self.is_master:
+            return
+        tot = metrics.get("total_predictions", 0)
+        acc = 100.0 * metrics.get("correct_predictions", 0) / tot if tot else 0.0
+        print(f"{mode}: CMD accuracy: {metrics.get('cmd_accuracy', 0):.2f}%, Params accuracy: {metrics.get('params_accuracy', 0):.2f}%, "
+              f"Overall: {acc:.2f}%, Top-30 CMD accuracy: {metrics.get('cmd_accuracy_topk', 0):.2f}%, "
+              f"Top-30 Params accuracy: {metrics.get('param_accuracy_topk', 0):.2f}%")
+        for i in range(6):
+            print(f"  Parameter {i}: {metrics.get(f'param_accuracy_{i}', 0):.2f}%")
+
+
+class NativeAdam:
+    """What `trainer.optimizer` is here: the handle on the fused clip + Adam kernel's state (flat m / v buffers + step count).
+    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (state indexed by position in `model.parameters()`,
+    one param_group per learning rate), so `checkpoint['optimizer_state_dict']` (reference trainer.py:146-151) round-trips and
+    also loads into a `torch.optim.Adam(model.parameters())` built on this model.  (Indices are over THIS model's 309 live
+    tensors: the reference's list also counts its 77.6 M dead GPT-2 parameters, which never get optimiser state.)"""
+
+    def __init__(self, model, lr, groups=None, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.engine = model, model._engine
+        self.betas, self.eps = betas, eps
+        self.names = [n for n, _ in model.named_parameters()]      # torch.optim.Adam(model.parameters()) indexes state in this order
+        self.bucket_lr = None                  # one lr per gradient bucket when the reference's `frozen` groups are used
+        if groups is None:
+            self.param_groups = [self._group(lr, list(range(len(self.names))))]
+        else:                                   # reference :237-251: cad ViT, state ViT, everything else
+            idx = {"cad": [], "state": [], "rest": []}
+            for i, n in enumerate(self.names):
+                idx["cad" if n.startswith("cad_embedding_model.") else "state" if n.startswith("state_embedding_model.") else "rest"].append(i)
+            self.param_groups = [self._group(groups["lr_cad"], idx["cad"]), self._group(groups["lr_state"], idx["state"]), self._group(lr, idx["rest"])]
+            self.bucket_lr = [lr, groups["lr_cad"], groups["lr_state"], groups["lr_state"]]
+
+    def _group(self, lr, params):
+        return {"lr": lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
+                "capturable": False, "differentiable": False, "fused": None, "params": params}
+
+    @property
+    def lr(self):
+        if self.bucket_lr is not None:
+            g = self.param_groups
+            return [g[2]["lr"], g[0]["lr"], g[1]["lr"], g[1]["lr"]]
+        return self.param_groups[0]["lr"]
+
+    def zero_grad(self, set_to_none=True):
+        pass                                    # the engine WRITES its gradient buffer on every backward
+
+    def state_dict(self):
+        eng, state = self.engine, {}
+        if eng.step_count > 0:
+            for i, n in enumerate(self.names):
+                state[i] = {"step": torch.tensor(float(eng.step_count)), "exp_avg": eng.view(n, eng.m), "exp_avg_sq": eng.view(n, eng.v)}
+        return {"state": state, "param_groups": [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        eng = self.engine
+        steps = set()
+        with torch.no_grad():
+            for i, st in sd.get("state", {}).items():
+                n = self.names[int(i)]
+                eng.view(n, eng.m).copy_(st["exp_avg"].to(eng.device, torch.float32))
+                eng.view(n, eng.v).copy_(st["exp_avg_sq"].to(eng.device, torch.float32))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("NativeAdam.load_state_dict: per-parameter step counts differ (the fused kernel keeps one)")
+        eng.step_count = steps.pop() if steps else 0
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            g["lr"] = src["lr"]
+
+
+class CheckpointHandler:
+    """checkpoints/<experiment>/epoch_N.pt | best_model.pt = {'epoch','model_state_dict','optimizer_state_dict','loss'}, rank 0 only
+    (reference trainer.py:133-180; loaded by experiment.py:61-71 / test.py through ModelFactory.create_model(state_dict=...))."""
+
+    def __init__(self, experiment_name, rank=0, dir_name="checkpoints"):
+        self.is_master = rank == 0
+        self.checkpoint_dir = os.path.join(dir_name, experiment_name)
+        if self.is_master:
+            os.makedirs(self.checkpoint_dir, exist_ok=True)
+
+    def build_checkpoint(self, epoch, loss, model, optimizer):
+        return {"epoch": epoch + 1, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "loss": loss}
+
+    def save_checkpoint(self, epoch, loss, model, optimizer, is_best=False):
+        if not self.is_master:
+            return None
+        ckpt = self.build_checkpoint(epoch, loss, model, optimizer)
+        path = os.path.join(self.checkpoint_dir, "best_model.pt" if is_best else f"epoch_{epoch + 1}.pt")
+        torch.save(ckpt, path)
+        print(f"Saved {'best ' if is_best else ''}model checkpoint for epoch {epoch + 1}")
+        return ckpt
+
+
 class GradSync:
     """Data-parallel gradient exchange (replaces the DDP wrap at reference experiment.py:104-109).
 
+    Construction does what the DDP constructor did for the reference: rank 0's parameters (and optimiser state) are broadcast,
+    so every replica starts from the same weights whatever each process's RNG drew.
     Each backward stage finalises one contiguous bucket of the flat gradient buffer (heads+decoder+stem first — 75 % of the
     bytes — then CAD ViT, then the two halves of the frame ViT); its all-reduce(SUM) is issued on a side stream right away
     so it runs over xGMI underneath the next stage's kernels.  The 1/world mean is folded into the Adam kernel.
     Only live parameters travel (508 MB fp32 instead of the reference's 818 MB incl. dead GPT-2 zeros)."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, on_params_changed=None):
         import torch.distributed as dist
         self.eng, self.dist, self.group = engine, dist, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.stream = torch.cuda.Stream(device=engine.device) if (self.world > 1 and engine.device.type == "cuda") else None
+        self.skip_comm = False                                    # diagnostic only (bench: exposed communication time)
+        if self.world > 1:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            for buf in (engine.params, engine.m, engine.v):
+                dist.broadcast(buf, src=src, group=group)
+            sc = torch.tensor([engine.step_count], dtype=torch.int64, device=engine.device)
+            dist.broadcast(sc, src=src, group=group)
+            engine.step_count = int(sc.item())
+            if on_params_changed is not None:
+                on_params_changed()
 
     def backward(self, dcmds=None, dpars=None):
         eng = self.eng
@@ -66,6 +201,8 @@ class GradSync:
         cur = torch.cuda.current_stream(eng.device)
 
         def reduce_bucket(st):
+            if self.skip_comm:
+                return
             lo, hi = eng.buckets[st]
             ev = torch.cuda.Event(); ev.record(cur)
             with torch.cuda.stream(self.stream):
@@ -82,35 +219,67 @@ class GradSync:
         cur.wait_stream(self.stream)
 
 
+# ------------------------------------------------------------------------------------------------ trainer
 class BaseTrainer:
     def __init__(self, train_packet, val_packet, test_packet, model, training_config, device, rank=0):
         self.device, self.rank, self.is_master = device, rank, rank == 0
         self.training_config = training_config
+        cfg = training_config.get
+        self.checkpoint = cfg("checkpoint", False)
+        self.early_stopping_enabled = cfg("early_stopping_enabled", False)          # reference :212-217
+        self.early_stopping_patience = cfg("early_stopping_patience", 100)
+        self.early_stopping_min_delta = cfg("early_stopping_min_delta", 0.0)
+        self.early_stopping_metric = cfg("early_stopping_metric", "accuracy")
+        self.early_stopping_mode = cfg("early_stopping_mode", "max")
+        self.frozen = cfg("frozen", False)
+        self.experiment_name = cfg("experiment_name", "default_" + datetime.datetime.now().strftime("%Y%m%d_%H%M%S"))
+        self.metrics_handler = MetricsHandler(self.experiment_name, rank)
+        self.checkpoint_handler = CheckpointHandler(self.experiment_name, rank, cfg("checkpoint_dir", "checkpoints"))
         self.train_loader, self.val_loader, self.test_loader = train_packet["loader"], val_packet["loader"], test_packet["loader"]
         self.train_sampler, self.val_sampler, self.test_sampler = train_packet["sampler"], val_packet["sampler"], test_packet["sampler"]
         self.model = model
         self.native = getattr(model, "module", model)            # tolerate a DDP-style wrapper
         self.engine = self.native._engine
-        self.lr = training_config.get("lr", 1e-3)                 # reference :235
-        if training_config.get("frozen", False):
-            raise NotImplementedError("per-group learning rates ('frozen', reference :237-251) are not on the native path yet")
-        self.use_mse = training_config.get("use_mse", False)
-        self.experiment_name = training_config.get("experiment_name", "default_" + time.strftime("%Y%m%d_%H%M%S"))
-        self.early_stopping_enabled = training_config.get("early_stopping_enabled", False)
-        self.early_stopping_patience = training_config.get("early_stopping_patience", 100)
-        self.gradsync = GradSync(self.engine)
-        self.action_mask = self.native.action_mask
+        self.lr = cfg("lr", 1e-3)                                 # reference :235
+        groups = {"lr_cad": cfg("lr_cad", 1e-3), "lr_state": cfg("lr_state", 1e-3)} if self.frozen else None
+        self.optimizer = NativeAdam(self.native, self.lr, groups)
+        self.use_mse = cfg("use_mse", False)
+        self.reduce_eval_metrics = cfg("reduce_eval_metrics", True)
+        self.stage_inputs = cfg("stage_inputs", True)             # double-buffered H2D staging of the train loader (data.DeviceStager)
+        self.native._drop_rank = rank                             # every rank draws its own dropout masks
+        self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed)
+        self.action_mask = self.native.action_mask.to(device) if hasattr(self.native.action_mask, "to") else self.native.action_mask
+        self._best_params = None
+
+    def _params_changed(self):
+        self.native._shadow_fresh = False
 
     def log(self, message):
         if self.is_master:
             print(message)
 
-    # ---- reference trainer.py:291-324
+    def apply_action_mask(self, cmd_pred, param_pred):
+        return self.native.apply_action_mask(cmd_pred, param_pred)
+
+    def save_checkpoint(self, epoch, loss, is_best=False):
+        return self.checkpoint_handler.save_checkpoint(epoch, loss, self.native, self.optimizer, is_best)
+
+    def load_checkpoint(self, path_or_dict):
+        """Resume: model weights + fused-Adam state (+ returns the stored epoch)."""
+        ck = torch.load(path_or_dict, map_location="cpu") if isinstance(path_or_dict, (str, os.PathLike)) else path_or_dict
+        from .model_factory import strip_prefixes
+        self.native.load_state_dict(strip_prefixes(ck["model_state_dict"]), strict=False)
+        if ck.get("optimizer_state_dict"):
+            self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        return ck.get("epoch", 0)
+
+    # ---- reference trainer.py:291-324 (uint8 frame batches stay uint8: they are normalised inside the patchify kernel)
     def prepare_batch(self, batch):
-        out = {"frames": batch["frames"].to(self.device, dtype=torch.float, non_blocking=True),
-               "actions": batch["actions"].to(self.device, dtype=torch.float, non_blocking=True),
-               "cad_image": batch["cad_image"].to(self.device, dtype=torch.float, non_blocking=True)}
-        if "timesteps" not in batch:
+        def to_dev(t):
+            return t.to(self.device, non_blocking=True) if t.dtype == torch.uint8 else t.to(self.device, dtype=torch.float, non_blocking=True)
+        out = {"frames": to_dev(batch["frames"]), "actions": batch["actions"].to(self.device, dtype=torch.float, non_blocking=True),
+               "cad_image": to_dev(batch["cad_image"])}
+        if "timesteps" not in batch or batch["timesteps"] is None:
             out["timesteps"] = torch.zeros((out["frames"].size(0), 1), dtype=torch.long, device=self.device)
         else:
             out["timesteps"] = batch["timesteps"].to(self.device, dtype=torch.long)
@@ -150,8 +319,6 @@ class BaseTrainer:
         loss, counters = self.train_step(bd)
         return loss, metrics_from_counters(counters.tolist())      # single D2H copy (the reference does ~40 .item() syncs)
 
-    train_step_name = "train_step"
-
     def train_step(self, bd):
         """device tensors in, device tensors out (no host sync): returns (loss 0-d tensor, int32[32] counters)."""
         eng = self.engine
@@ -160,72 +327,288 @@ class BaseTrainer:
             eng.sync_shadow()
         self.native._arm_dropout()                               # model.train() -> dropout active, like the reference's train loop
         cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"])
-        out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], use_mse=self.use_mse, class_weights=self._class_w())
+        out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
         self.gradsync.backward()
-        eng.optimizer_step(lr=self.lr, max_norm=1.0, grad_scale=1.0 / self.gradsync.world)
+        eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
+                           grad_scale=1.0 / self.gradsync.world)
         self.native.mark_shadow_fresh()
         return out[0], met
 
     def _class_w(self):
         return None
 
+    def _label_w(self):
+        raise NotImplementedError
+
     def compute_loss(self, action_preds, actions):
         raise NotImplementedError("Subclasses must implement compute_loss")
 
-    # ---- plumbing: reference trainer.py:337-478 reduced to its contract
+    def init_metrics(self):
+        return {}
+
+    def update_metrics(self, metrics, batch_metrics):
+        pass
+
+    def log_epoch_metrics(self, epoch, epochs, avg_loss, metrics):
+        pass
+
+    def print_metrics(self, metrics, mode=""):
+        self.metrics_handler.print_metrics(metrics, mode)
+
+    def save_metrics(self, metrics, ext=""):
+        self.metrics_handler.save_metrics(metrics, ext)
+
+    # ---- reference trainer.py:337-382
     def train(self, epochs, sequential=False, noise=False):
         self.model.train()
-        best = None
+        best_value = float("inf") if self.early_stopping_mode == "min" else float("-inf")
+        best_state, patience = None, 0
+        t0 = time.time()
         for epoch in range(epochs):
             if self.train_sampler is not None and hasattr(self.train_sampler, "set_epoch"):
                 self.train_sampler.set_epoch(epoch)
-            t0, running, n, agg = time.time(), 0.0, 0, {}
-            for batch in self.train_loader:
-                loss, metrics = self._process_batch(batch, noise)
-                running += float(loss.item()); n += 1
-                for k, v in metrics.items():
-                    if isinstance(v, int):
-                        agg[k] = agg.get(k, 0) + v
-            acc = 100.0 * agg.get("correct_predictions", 0) / max(agg.get("total_predictions", 0), 1)
-            self.log(f"Epoch [{epoch + 1}/{epochs}] loss {running / max(n, 1):.4f} acc {acc:.2f}% ({time.time() - t0:.1f}s)")
-            best = running / max(n, 1) if best is None else min(best, running / max(n, 1))
+            avg_loss, metrics = self._train_epoch(epoch, noise)
+            self.log_epoch_metrics(epoch, epochs, avg_loss, metrics)
+            if (epoch + 1) % self.training_config.get("save_frequency", 10 ** 9) == 0:
+                self.save_checkpoint(epoch, avg_loss)
+            val_metrics = self._run_validation(epoch)
+            d = _dist()
+            if d is not None:
+                d.barrier()
+            best_value, patience, best_state, stop = self._handle_early_stopping(epoch, avg_loss, val_metrics, best_value, patience, best_state)
+            if stop:
+                self.log(f"Early stopping triggered after {epoch + 1} epochs")
+                self._restore_best(best_state)
+                break
+            self.log(f"Epoch {epoch + 1} took {time.time() - t0:.2f} seconds")
+            t0 = time.time()
+        else:
+            if self.early_stopping_enabled and best_state is not None and patience < self.early_stopping_patience:
+                self._restore_best(best_state)
         return self.model
 
+    def _restore_best(self, best_state):
+        """The reference reloads `best_model_state['model_state_dict']` (:371), whose tensors alias the live parameters (a no-op there);
+        here the best weights are a device-side copy of the flat buffer taken when the checkpoint was written."""
+        if best_state is None or self._best_params is None:
+            return
+        with torch.no_grad():
+            self.engine.params.copy_(self._best_params)
+        self._params_changed()
+        self.log(f"Loaded best model from epoch {best_state['epoch']}")
+
+    # ---- reference trainer.py:384-478 (torch.profiler hook omitted: rocprofv3 / vcad_profile_* are the tools here)
+    def _train_epoch(self, epoch, noise=False):
+        self.model.train()
+        metrics = self.init_metrics()
+        loader = DeviceStager(self.train_loader, self.device) if (self.stage_inputs and torch.device(self.device).type == "cuda") else self.train_loader
+        running = torch.zeros((), device=self.device)
+        counters = torch.zeros(L.NMETRIC, dtype=torch.int64, device=self.device)
+        n, log_every = 0, self.training_config.get("log_frequency", 0)
+        for batch_idx, batch in enumerate(loader):
+            bd = self.prepare_batch(batch)
+            if noise:
+                bd["actions"] = self._add_noise_to_actions(bd["actions"])
+            loss, met = self.train_step(bd)
+            running += loss.detach(); counters += met; n += 1      # stays on the device: no per-step host sync
+            if log_every and (batch_idx + 1) % log_every == 0:
+                m = self.init_metrics(); self.update_metrics(m, metrics_from_counters(counters.tolist()))
+                self.log_metrics(epoch, self.training_config.get("epochs", 0), batch_idx, len(self.train_loader), float(loss), metrics=m)
+        self.update_metrics(metrics, metrics_from_counters(counters.tolist()))
+        return (float(running) / n if n else 0.0), metrics
+
+    def _run_validation(self, epoch):
+        val_metrics = None
+        if (epoch + 1) % self.training_config.get("val_frequency", 10 ** 9) == 0:
+            val_metrics = self.evaluate(self.model, mode="val", epoch=epoch)
+            self.print_metrics(val_metrics, mode="Validation")
+            self.model.train()
+        return val_metrics
+
+    def _handle_early_stopping(self, epoch, avg_loss, val_metrics, best_value, patience, best_state):
+        if not self.early_stopping_enabled:
+            return best_value, patience, best_state, False
+        cur = avg_loss
+        if self.early_stopping_metric == "accuracy" and val_metrics and val_metrics.get("total_predictions", 0):
+            cur = val_metrics["correct_predictions"] / val_metrics["total_predictions"]
+        improved = cur < best_value - self.early_stopping_min_delta if self.early_stopping_mode == "min" else cur > best_value + self.early_stopping_min_delta
+        if improved:
+            self.log(f"Validation {self.early_stopping_metric} improved from {best_value:.4f} to {cur:.4f}")
+            best_value, patience = cur, 0
+            ck = self.save_checkpoint(epoch, avg_loss, is_best=True)
+            best_state = {"epoch": epoch + 1} if ck is None else {"epoch": ck["epoch"]}
+            self._best_params = self.engine.params.clone()
+        else:
+            patience += 1
+            self.log(f"Validation {self.early_stopping_metric} did not improve. Patience: {patience}/{self.early_stopping_patience}")
+        stop = patience >= self.early_stopping_patience
+        d = _dist()
+        if d is not None:                                          # reference :559-563: stop only when every rank wants to
+            flag = torch.tensor([int(stop)], device=self.device)
+            d.all_reduce(flag, op=d.ReduceOp.MIN)
+            stop = bool(flag.item())
+        return best_value, patience, best_state, stop
+
+    # ---- reference trainer.py:713-750
     @torch.no_grad()
     def evaluate(self, model, mode="test", ablation=False, epoch=-1):
-        loader = {"train": self.train_loader, "val": self.val_loader, "test": self.test_loader}[mode]
+        loader = {"train": self.train_loader, "val": self.val_loader}.get(mode, self.test_loader)
         model.eval()
-        agg, total_loss, n = {}, 0.0, 0
+        metrics = self.init_metrics()
+        native = getattr(model, "module", model)
+        counters = torch.zeros(L.NMETRIC, dtype=torch.int64, device=self.device)
+        loss_sum = torch.zeros(2, dtype=torch.float64, device=self.device)           # [sum of batch losses, batches]
+        fused = hasattr(native, "_engine")
         for batch in loader:
             bd = self.prepare_batch(batch)
-            preds = model(self._prepare_model_inputs(bd, False))
-            loss, metrics = self.compute_loss(preds, bd["actions"][:, 1:])
-            total_loss += float(loss.item()); n += 1
-            for k, v in metrics.items():
-                if isinstance(v, int):
-                    agg[k] = agg.get(k, 0) + v
-        agg["loss"] = total_loss / max(n, 1)
-        agg["accuracy"] = 100.0 * agg.get("correct_predictions", 0) / max(agg.get("total_predictions", 0), 1)
-        return agg
+            inputs = self._prepare_model_inputs(bd, False)
+            if ablation:
+                inputs["cad_image"] = torch.zeros_like(inputs["cad_image"])
+            if fused:                                               # fused path: counters stay on the device
+                cmds, pars = native(inputs)
+                out, met = native._engine.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
+                counters += met; loss_sum[0] += out[0].double(); loss_sum[1] += 1
+            else:
+                loss, bm = self.compute_loss(model(inputs), bd["actions"][:, 1:])
+                counters += torch.tensor([bm["cmd_corrects"][i] for i in range(5)] + [bm["cmd_counts"][i] for i in range(5)] +
+                                         [bm["param_corrects"][i] for i in range(6)] + [bm["param_counts"][i] for i in range(6)] +
+                                         [bm["cmd_correct_topk"], bm["cmd_counts_topk"], bm["param_correct_topk"], bm["param_counts_topk"],
+                                          bm["correct_predictions"], bm["total_predictions"], 0, 0, 0, 0], dtype=torch.int64, device=self.device)
+                loss_sum[0] += float(loss); loss_sum[1] += 1
+        d = _dist()
+        if d is not None and self.reduce_eval_metrics:              # the reference reports per-rank numbers (quirk 6); here: the whole split
+            d.all_reduce(counters); d.all_reduce(loss_sum)
+        self.update_metrics(metrics, metrics_from_counters(counters.tolist()))
+        metrics["loss"] = float(loss_sum[0] / loss_sum[1]) if float(loss_sum[1]) else 0.0
+        if self.is_master:
+            self.save_metrics(metrics, f"{mode}_epoch_{epoch + 1}" if epoch != -1 else mode)
+        return metrics
+
+    def _predict_actions(self, model, inputs):
+        cmds, pars = model(inputs)
+        pred_cmd = torch.argmax(cmds, dim=-1)
+        pred_params = self.apply_action_mask(pred_cmd, torch.argmax(pars, dim=-1)).long()
+        return pred_cmd.long(), pred_params
+
+    # ---- reference trainer.py:1066-1128: argmax predictions of n random clips as CSV next to the ground truth
+    @torch.no_grad()
+    def sample(self, model, n=10, folder="outputs", mode="test", ablation=False):
+        model.eval()
+        loader = {"train": self.train_loader, "val": self.val_loader}.get(mode, self.test_loader)
+        dataset = loader.dataset
+        os.makedirs(folder, exist_ok=True)
+        for idx in random.sample(range(len(dataset)), n):
+            item = dataset[idx]
+            files = getattr(dataset, "data_files", None)
+            sample_id = os.path.basename(files[idx]).split("_")[0] if files is not None else str(idx)
+            out_path = os.path.join(folder, f"pred_actions_{sample_id}.csv")
+            if os.path.exists(out_path):
+                continue
+            bd = self.prepare_batch({k: v for k, v in item.items() if v is not None})
+            if ablation:
+                bd["cad_image"] = torch.zeros_like(bd["cad_image"])
+            inputs = {"frames": bd["frames"].unsqueeze(0)[:, :-1], "actions": self.normalize_actions(bd["actions"].unsqueeze(0))[:, :-1],
+                      "timesteps": bd["timesteps"].unsqueeze(0), "cad_image": bd["cad_image"].unsqueeze(0)}
+            pred_cmd, pred_params = self._predict_actions(model, inputs)
+            pred = torch.cat((pred_cmd.unsqueeze(-1), pred_params), dim=-1)[0].cpu().numpy()
+            with open(out_path, "w", newline="") as f:
+                csv.writer(f).writerows(row.tolist() for row in pred)
+            with open(os.path.join(folder, f"actions_{sample_id}.csv"), "w", newline="") as f:
+                csv.writer(f).writerows(row.tolist() for row in bd["actions"][1:].cpu().numpy())
+            try:                                                     # the reference saves the CAD image with torchvision.utils.save_image
+                from PIL import Image
+                img = bd["cad_image"][0].float().cpu()
+                if bd["cad_image"].dtype != torch.uint8:
+                    img = (img.clamp(0, 1) * 255 + 0.5)
+                Image.fromarray(img.clamp(0, 255).to(torch.uint8).numpy()).save(os.path.join(folder, f"images_{sample_id}.png"))
+            except Exception:
+                pass
+
+    # ---- reference trainer.py:1131-1260
+    @staticmethod
+    def _param_error(diff, k, tolerance):
+        if k in (0, 1, 5):
+            return abs(diff) > tolerance
+        return diff < 0 or diff >= {2: 50, 3: 200, 4: 500}[k]
+
+    def _sequence_mistakes(self, a_cmd, a_par, p_cmd, p_par, tolerance):
+        n = len(a_cmd)
+        rec = {"First Mistakes": {**{f"cmd_{i}": [] for i in range(5)}, **{f"param_{i}": [] for i in range(6)}},
+               "Memory": {"cmd": [], **{f"param_{i}": [] for i in range(6)}}, "Sequence Lengths": [], "Number of Mistakes": []}
+        mistakes, first, noted = [0] * n, False, False
+        for j in range(n):
+            bad = False
+            gt, pd = int(a_cmd[j]), int(p_cmd[j])
+            rec["Memory"]["cmd"].append([gt, pd])
+            if gt != pd:
+                mistakes[j], bad = 1, True
+                if not first:
+                    rec["First Mistakes"][f"cmd_{gt}"].append(f"cmd_{pd}"); first = True
+            for k in range(a_par.shape[-1]):
+                g = int(a_par[j][k])
+                if g == -1:
+                    continue
+                q = int(p_par[j][k])
+                rec["Memory"][f"param_{k}"].append([g, q])
+                err = self._param_error(q - g, k, tolerance)
+                if err and not bad:
+                    mistakes[j], bad = 1, True
+                if err and not first:
+                    rec["First Mistakes"][f"param_{k}"].append(f"param_{q}"); first = True
+            if first and not noted:
+                rec["Sequence Lengths"], noted = [j, n], True
+        if not noted:
+            rec["Sequence Lengths"] = [n, n]
+        rec["Number of Mistakes"] = mistakes
+        return rec
+
+    @torch.no_grad()
+    def find_first_mistake(self, model, mode="test", tol=3, ablation=False):
+        model.eval()
+        blank = lambda: {"First Mistakes": {**{f"cmd_{i}": [] for i in range(5)}, **{f"param_{i}": [] for i in range(6)}},
+                         "Memory": {"cmd": [], **{f"param_{i}": [] for i in range(6)}}, "Sequence Lengths": [], "Number of Mistakes": []}
+        data = [blank() for _ in range(tol)]
+        loader = {"train": self.train_loader, "val": self.val_loader}.get(mode, self.test_loader)
+        for batch in loader:
+            bd = self.prepare_batch(batch)
+            inputs = self._prepare_model_inputs(bd, False)
+            if ablation:
+                inputs["cad_image"] = torch.zeros_like(inputs["cad_image"])
+            pred_cmd, pred_params = self._predict_actions(model, inputs)
+            # one D2H of the arg-max predictions; the per-step bookkeeping is host work (it builds Python lists)
+            a_cmd = bd["actions"][:, 1:, 0].long().cpu().numpy(); a_par = bd["actions"][:, 1:, 1:].long().cpu().numpy()
+            p_cmd = pred_cmd.cpu().numpy(); p_par = pred_params.cpu().numpy()
+            for t in range(tol):
+                for i in range(len(a_cmd)):
+                    rec = self._sequence_mistakes(a_cmd[i], a_par[i], p_cmd[i], p_par[i], t)
+                    for key in rec["First Mistakes"]:
+                        data[t]["First Mistakes"][key].extend(rec["First Mistakes"][key])
+                    for key in rec["Memory"]:
+                        data[t]["Memory"][key].extend(rec["Memory"][key])
+                    data[t]["Sequence Lengths"].append(rec["Sequence Lengths"])
+                    data[t]["Number of Mistakes"].append(rec["Number of Mistakes"])
+        return data
 
 
 class MultiClassesTrainer(BaseTrainer):
     def __init__(self, train_loader, val_loader, test_loader, model, training_config, device, rank):
         super().__init__(train_loader, val_loader, test_loader, model, training_config, device, rank=rank)
+        # ./class_weights.json, CWD-relative and unconditional like the reference (:822-825): "Label" holds the 5 command-CE class
+        # weights, which are also the six per-head loss multipliers through [0,0,1,1,2,3] (:962); the other six keys are the
+        # per-class weights of the parameter heads (use_mse = False)
+        with open(training_config.get("class_weights_path", "class_weights.json"), "r") as f:
+            self.weights = json.load(f)
+        self.cmd_weights = [float(x) for x in self.weights["Label"]]
+        if len(self.cmd_weights) != 5:
+            raise ValueError("class_weights.json: 'Label' must hold 5 weights")
         self.param_to_label = [0, 0, 1, 1, 2, 3]
         self.tolerances = [TOLERANCE - 1, TOLERANCE - 1, 50, 200, 500, TOLERANCE - 1]
         self.above = [False, False, True, True, True, False]
         self.param_names = PARAM_NAMES
         self._cw = None
-        path = "class_weights.json"                               # CWD-relative like the reference (:822)
-        if os.path.exists(path):
-            with open(path) as f:
-                self.weights = json.load(f)
-            self.cmd_weights = self.weights["Label"]
-        else:
-            self.weights, self.cmd_weights = None, None
-            if not self.use_mse:
-                raise FileNotFoundError("class_weights.json (needed for use_mse=False) not found in the working directory")
+
+    def _label_w(self):
+        return self.cmd_weights
 
     def _class_w(self):
         if self.use_mse:
@@ -238,12 +621,65 @@ class MultiClassesTrainer(BaseTrainer):
         """reference trainer.py:935-1063 on the fused loss kernels: (loss, metrics dict).  The loss tensor is a plain device
         scalar; when the predictions carry autograd history the gradient is attached through the engine's own dlogits."""
         cmds, pars = action_preds
-        out, met = self.engine.loss(cmds.detach(), pars.detach(), actions, use_mse=self.use_mse, class_weights=self._class_w())
+        out, met = self.engine.loss(cmds.detach(), pars.detach(), actions, self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
         loss = out[0]
         if cmds.requires_grad:
             B, T = cmds.shape[:2]
             loss = _LossWithGrad.apply(cmds, pars, loss.clone(), self.engine.dl_views(B, T))
         return loss, metrics_from_counters(met.tolist())
+
+    # ---- reference trainer.py:1265-1340: running totals + derived percentages
+    def init_metrics(self):
+        m = {k: 0 for k in ("correct_predictions", "total_predictions", "cmd_accuracy", "params_accuracy", "cmd_corrects", "cmd_counts",
+                            "param_corrects", "param_counts", "cmd_correct_topk", "param_correct_topk", "cmd_counts_topk", "param_counts_topk",
+                            "cmd_accuracy_topk", "param_accuracy_topk", "perfect_sequences", "total_sequences", "perfect_commands",
+                            "perfect_command_accuracy", "perfect_sequence_accuracy")}
+        for i in range(6):
+            m[f"param_accuracy_{i}"] = m[f"param_corrects_{i}"] = m[f"param_counts_{i}"] = 0
+        for i in range(5):
+            m[f"cmd_accuracy_{i}"] = m[f"cmd_corrects_{i}"] = m[f"cmd_counts_{i}"] = 0
+        return m
+
+    def update_metrics(self, metrics, bm):
+        pct = lambda a, b: 100 * a / b
+        for k in ("cmd_correct_topk", "param_correct_topk", "cmd_counts_topk", "param_counts_topk", "correct_predictions", "total_predictions",
+                  "perfect_sequences", "perfect_commands", "total_sequences"):
+            metrics[k] += bm[k]
+        for i in range(6):
+            metrics[f"param_corrects_{i}"] += bm[f"param_corrects_{i}"]; metrics[f"param_counts_{i}"] += bm[f"param_counts_{i}"]
+            if metrics[f"param_counts_{i}"] > 0:
+                metrics[f"param_accuracy_{i}"] = pct(metrics[f"param_corrects_{i}"], metrics[f"param_counts_{i}"])
+        for i in range(5):
+            metrics[f"cmd_corrects_{i}"] += bm[f"cmd_corrects_{i}"]; metrics[f"cmd_counts_{i}"] += bm[f"cmd_counts_{i}"]
+            if metrics[f"cmd_counts_{i}"] > 0:
+                metrics[f"cmd_accuracy_{i}"] = pct(metrics[f"cmd_corrects_{i}"], metrics[f"cmd_counts_{i}"])
+        if metrics["cmd_counts_topk"] > 0:
+            metrics["cmd_accuracy_topk"] = pct(metrics["cmd_correct_topk"], metrics["cmd_counts_topk"])
+        if metrics["param_counts_topk"] > 0:
+            metrics["param_accuracy_topk"] = pct(metrics["param_correct_topk"], metrics["param_counts_topk"])
+        tc, tp = sum(metrics[f"cmd_counts_{i}"] for i in range(5)), sum(metrics[f"param_counts_{i}"] for i in range(6))
+        if tc > 0:
+            metrics["cmd_accuracy"] = pct(sum(metrics[f"cmd_corrects_{i}"] for i in range(5)), tc)
+        if tp > 0:
+            metrics["params_accuracy"] = pct(sum(metrics[f"param_corrects_{i}"] for i in range(6)), tp)
+        if metrics["total_predictions"] > 0:
+            metrics["overall_accuracy"] = pct(metrics["correct_predictions"], metrics["total_predictions"])
+        if metrics["total_sequences"] > 0:
+            metrics["perfect_sequence_accuracy"] = pct(metrics["perfect_sequences"], metrics["total_sequences"])
+            metrics["perfect_command_accuracy"] = pct(metrics["perfect_commands"], metrics["total_sequences"])
+
+    def log_metrics(self, epoch, epochs, batch_idx, loader_len, loss, **kwargs):
+        m = kwargs.get("metrics", {})
+        self.save_metrics(m, ext=f"epoch_{epoch + 1}")
+        self.log(f"Epoch [{epoch + 1}/{epochs}], Batch [{batch_idx + 1}/{loader_len}], Loss: {loss:.4f}, CMD Accuracy: {m['cmd_accuracy']:.2f}%, "
+                 f"Params Accuracy: {m['params_accuracy']:.2f}%")
+
+    def log_epoch_metrics(self, epoch, epochs, avg_loss, metrics):
+        tot = metrics["total_predictions"]                       # (the reference divides unguarded and raises on an empty epoch, quirk 11)
+        acc = 100 * metrics["correct_predictions"] / tot if tot else 0.0
+        self.log(f"Epoch [{epoch + 1}/{epochs}] Average Loss: {avg_loss:.4f}, Average Accuracy: {acc:.2f}%, CMD Accuracy: {metrics['cmd_accuracy']:.2f}%, "
+                 f"Params Accuracy: {metrics['params_accuracy']:.2f}%, Top-30 CMD Accuracy: {metrics['cmd_accuracy_topk']:.2f}%, "
+                 f"Top-30 Params Accuracy: {metrics['param_accuracy_topk']:.2f}%")
 
 
 class _LossWithGrad(torch.autograd.Function):
