@@ -64,6 +64,13 @@ def test_gemm_dma_kernel(emu, gemm_tile, tra, trb, to):
         U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, act=(0 if tra else 1),
                      residual=(to == F32), splitk=bool(tra))
         assert emu.vcad_debug_gemm_dma_launches() == n0 + 1, "the GEMM did not take the DMA kernel"
+        # the same problems without the activation: the ping-pong kernel (gemm_pp.h) — and, switched back, the lockstep one
+        for variant in (1, 0):
+            emu.vcad_debug_gemm_variant(variant)
+            U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, residual=(to == F32), splitk=bool(tra))
+            U.check_gemm(emu, "cpu", M, 128, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
+        assert emu.vcad_debug_gemm_dma_launches() == n0 + 5
+        emu.vcad_debug_gemm_variant(0)
     finally:
         emu.vcad_debug_gemm_dma(-1)
 

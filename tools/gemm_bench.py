@@ -65,6 +65,29 @@ if len(sys.argv) > 1 and sys.argv[1] == "nn":
     run("dqkv dgrad as NN [reg]", R, 512, 3072)
     run("dqkv dgrad NT [reg]", R, 512, 3072, trb=1)
     sys.exit(0)
+def three(name, *a, **k):
+    """forced through the persistent kernels: r01 lockstep kernel vs the ping-pong kernel (same launch, same data)"""
+    lib.vcad_debug_gemm_dma(1)
+    lib.vcad_debug_gemm_variant(0); run(name + " [lockstep]", *a, **k)
+    lib.vcad_debug_gemm_variant(1); run(name + " [ping-pong]", *a, **k)
+    lib.vcad_debug_gemm_dma(-1)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "pp":
+    for rep in range(2):
+        three("vit qkv fwd", R, 3072, 512)
+        three("vit qkv fwd + bias", R, 3072, 512, bias=True)
+        three("patch embed fwd (f32 out)", 101920, 512, 1024, to=F32, bias=True)
+        three("vit dqkv dgrad via W^T (NN)", R, 512, 3072)
+        three("vit dao dgrad via W^T (NN)", R, 1024, 512)
+        three("vit dz/dh dgrad via W^T (NN)", R, 512, 512)
+        three("vit dqkv dgrad NT", R, 512, 3072, trb=1)
+        three("vit qkv wgrad", 3072, 512, R, to=F32, tra=1, trb=1)
+        three("vit out wgrad", 512, 1024, R, to=F32, tra=1, trb=1)
+        three("vit mlp wgrad", 512, 512, R, to=F32, tra=1, trb=1)
+        three("square 4096", 4096, 4096, 4096)
+        three("square 8192", 8192, 8192, 8192)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "dma":
     both("vit qkv fwd", R, 3072, 512, bias=True)
     both("vit out fwd (+res, f32 out)", R, 512, 1024, to=F32, bias=True, res=True)

@@ -2,8 +2,12 @@
 // compiles in parallel with the register-staged kernels of ops_gemm.hip.
 #include "ops.h"
 #include "gemm_dma.h"
+#include "gemm_pp.h"
 
 static long g_dma_launches = 0;
+static int g_variant = 0;        // 0 = the lockstep kernel (gemm_dma.h, default), 1 = ping-pong wave groups (gemm_pp.h): measured SLOWER, kept for the A/B
+                                 // (profiles/r02_gemm_pingpong_ab.txt: both are bound by the ~20 B/clk/CU L2->LDS DMA rate, not by MFMA issue)
+extern "C" void vcad_debug_gemm_variant(int v) { g_variant = v ? 1 : 0; }
 extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
 template <typename TO, bool TRA, bool TRB>
@@ -21,6 +25,18 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     const int tiles_n = c.p.N / GD_BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
     ++g_dma_launches;
     const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
+    // the ping-pong kernel carries the plain epilogue (bias, k-slice slabs); per-element side inputs stay on the lockstep kernel
+    if (g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
+#ifndef VC_EMU
+        static bool attr_pp = false;
+        if (!attr_pp) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP_LDS_BYTES);
+            if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+            attr_pp = true;
+        }
+#endif
+        VC_LAUNCH((gemm_pp_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GP_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
+    } else
     VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GD_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;

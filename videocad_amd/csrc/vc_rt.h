@@ -70,6 +70,9 @@ VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) {
 }
 VC_DEV float vc_expf_fast(float x) { return __expf(x); }
 VC_DEV int vc_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }     // x is known to be wave-uniform: keep it in an SGPR
+VC_DEV uint64_t vc_uniform64(uint64_t x) {     // 64-bit value known to be wave-uniform: both halves into SGPRs
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
 template <int N> VC_DEV void vc_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // workgroup barrier that does NOT drain vmcnt (DMA stays in flight across it); LDS reads/writes are ordered around it
 VC_DEV void vc_barrier_raw() {
@@ -77,6 +80,32 @@ VC_DEV void vc_barrier_raw() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// pins the instruction order at this point (register-only MFMAs are otherwise free to float across the asm waits / barriers)
+VC_DEV void vc_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+template <int P> VC_DEV void vc_setprio() { __builtin_amdgcn_s_setprio(P); }
+// "hidden" register loads: issued from inline asm so that hipcc does not see them — beside LDS-DMA traffic hipcc answers the first
+// use of ANY compiler-visible load with vmcnt(0), draining the whole DMA ring (probed: tools/probe_waitcnt.hip).  The caller counts
+// the wave's VMEM operations itself and, before the first use, issues vc_hwait<N>() naming every destination register
+// (cdna_hip_programming.md §5.7 form (ii)): address = uniform base (SGPR pair) + 32-bit per-lane byte offset.
+VC_DEV uint32_t vc_hload_b32(const void* sbase, uint32_t voff) {
+    uint32_t v; asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory"); return v;
+}
+VC_DEV uint32_t vc_hload_u16(const void* sbase, uint32_t voff) {
+    uint32_t v; asm volatile("global_load_ushort %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory"); return v;
+}
+// stores in the same addressing form (uniform base in an SGPR pair + one 32-bit lane offset): hipcc materialises a 64-bit VGPR address
+// per store for `base + uniform + lane` pointer arithmetic; from asm the per-row base is 3 SALU instructions and no VGPR
+VC_DEV void vc_hstore_b32(void* sbase, uint32_t voff, uint32_t data) { asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(data), "s"(sbase) : "memory"); }
+VC_DEV void vc_hstore_b16(void* sbase, uint32_t voff, uint32_t data) { asm volatile("global_store_short %0, %1, %2" :: "v"(voff), "v"(data), "s"(sbase) : "memory"); }
+template <int N> VC_DEV void vc_hwait16(uint32_t (&r)[16]) {
+    asm volatile("s_waitcnt vmcnt(%16)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                 "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) : "n"(N) : "memory");
+}
+VC_DEV void vc_hpin2(uint32_t& a, uint32_t& b) { asm volatile("" : "+v"(a), "+v"(b) :: "memory"); }
+template <int N> VC_DEV void vc_hwait2(uint32_t& a, uint32_t& b) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory"); }
+// "this register's value is dead from here on": ends the live range of a loop-carried register (array element) at no cost — hipcc
+// cannot see that e.g. MFMA fragments are never read again once the next LOAD segment starts, and would keep them allocated
+template <typename T> VC_DEV void vc_undef(T& x) { asm volatile("" : "=v"(x)); }
 // D(32x32) += A(32x2) * B(2x32), exact f32.  lane l: A[i=l&31][k=l>>5], B[k=l>>5][n=l&31]; D as above.
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -158,7 +187,18 @@ struct vc_s16x4 { short v[4]; short& operator[](int i) { return v[i]; } const sh
 VC_DEV vc_s16x4 vc_ds_read_tr16(const void* p) { vc_s16x4 r; vcemu::ds_read_tr16(p, r.v); return r; }
 VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) { vcemu::dma16(gsrc, lds_piece); }
 VC_DEV float vc_expf_fast(float x) { return expf(x); }
+VC_DEV void vc_sched_fence() {}
+template <int P> VC_DEV void vc_setprio() {}
+VC_DEV uint32_t vc_hload_b32(const void* sbase, uint32_t voff) { uint32_t v; memcpy(&v, (const char*)sbase + voff, 4); return v; }
+VC_DEV uint32_t vc_hload_u16(const void* sbase, uint32_t voff) { uint16_t v; memcpy(&v, (const char*)sbase + voff, 2); return v; }
+VC_DEV void vc_hstore_b32(void* sbase, uint32_t voff, uint32_t data) { memcpy((char*)sbase + voff, &data, 4); }
+VC_DEV void vc_hstore_b16(void* sbase, uint32_t voff, uint32_t data) { uint16_t h = (uint16_t)data; memcpy((char*)sbase + voff, &h, 2); }
+template <int N> VC_DEV void vc_hwait16(uint32_t (&)[16]) {}
+VC_DEV void vc_hpin2(uint32_t&, uint32_t&) {}
+template <int N> VC_DEV void vc_hwait2(uint32_t&, uint32_t&) {}
+template <typename T> VC_DEV void vc_undef(T&) {}
 VC_DEV int vc_uniform(int x) { return x; }
+VC_DEV uint64_t vc_uniform64(uint64_t x) { return x; }
 template <int N> VC_DEV void vc_wait_vmcnt() {}
 VC_DEV void vc_barrier_raw() { vcemu::sync_block(); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
@@ -246,3 +286,4 @@ VC_HD void vc_drop_mul4(const vc_drop& d, uint32_t idx, float (&m)[4]) {
 }
 
 #define VC_CEIL_DIV(a, b) (((a) + (b) - 1) / (b))
+#define VC_INLINE_LAMBDA __attribute__((always_inline))
