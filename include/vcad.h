@@ -148,6 +148,8 @@ void vcad_debug_force_gemm_tile(int tile);
 /* -1 automatic, 0 never, 1 whenever legal: routes bf16 GEMMs through the persistent DMA-fed kernel (tests, bench A/B) */
 void vcad_debug_gemm_dma(int mode);
 long vcad_debug_gemm_dma_launches(void);
+/* 256 x 256 tile of the persistent kernel (plain epilogues): -1 automatic, 0 never, 1 whenever legal */
+void vcad_debug_gemm_wide(int mode);
 /* which persistent DMA-fed kernel: 0 = lockstep (default), 1 = ping-pong wave groups + line-coalesced epilogue (A/B experiment, slower) */
 void vcad_debug_gemm_variant(int v);
 /* ablation (tools/gemm_ablate*.py): start-offset of the first wave / bit mask of pipeline stages to skip; 0 = off */

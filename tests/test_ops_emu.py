@@ -75,6 +75,22 @@ def test_gemm_dma_kernel(emu, gemm_tile, tra, trb, to):
         emu.vcad_debug_gemm_dma(-1)
 
 
+@pytest.mark.parametrize("tra,trb,to", [(0, 0, BF16), (0, 0, F32), (1, 1, F32)])
+def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
+    """the 256 x 256 tile of the persistent kernel (two 64 KiB stages, 64 x 128 per wave): plain epilogues — bias, k-slice slabs"""
+    if gemm_tile != 128:
+        pytest.skip("tile-size fixture does not apply to the DMA kernel")
+    emu.vcad_debug_gemm_dma(1); emu.vcad_debug_gemm_wide(1)
+    n0 = emu.vcad_debug_gemm_dma_launches()
+    try:
+        M = 520 if tra else 600                       # three rows of items, ragged last one
+        U.check_gemm(emu, "cpu", M, 512, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=not tra, splitk=bool(tra))
+        U.check_gemm(emu, "cpu", 264, 256, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
+        assert emu.vcad_debug_gemm_dma_launches() == n0 + 2, "the GEMM did not take the DMA kernel"
+    finally:
+        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1)
+
+
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16)])
 def test_layernorm(emu, C_, dt):
     U.check_layernorm(emu, "cpu", 11, C_, dt)

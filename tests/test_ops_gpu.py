@@ -78,6 +78,24 @@ def test_gemm_dma_kernel(hip):
     assert hip.vcad_debug_gemm_dma_launches() == n0 + 18
 
 
+def test_gemm_dma_kernel_wide_tile(hip):
+    """256 x 256 tile (automatic for the plain big GEMMs): QKV-forward-, dgrad-through-W^T- and wgrad-like problems, three times each
+    (a mis-counted vmcnt of the two-stage ring shows up as sporadic wrong tiles), ragged M tail, short last k-slice"""
+    n0 = hip.vcad_debug_gemm_dma_launches()
+    hip.vcad_debug_gemm_dma(1); hip.vcad_debug_gemm_wide(1)
+    try:
+        for rep in range(3):
+            U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=rep)
+            U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, seed=rep)
+            U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, seed=rep)
+            U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep)
+            U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep)
+        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, pad=8)
+    finally:
+        hip.vcad_debug_gemm_dma(-1); hip.vcad_debug_gemm_wide(-1)
+    assert hip.vcad_debug_gemm_dma_launches() == n0 + 16, "a GEMM did not take the DMA kernel"
+
+
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16), (1024, BF16)])
 def test_layernorm(hip, C_, dt):
     U.check_layernorm(hip, DEV, 5003, C_, dt)

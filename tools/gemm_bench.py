@@ -73,6 +73,28 @@ def three(name, *a, **k):
     lib.vcad_debug_gemm_dma(-1)
 
 
+def wide(name, *a, **k):
+    """persistent kernel, 256 x 128 tile vs 256 x 256 tile (same launch, same data)"""
+    lib.vcad_debug_gemm_dma(1)
+    lib.vcad_debug_gemm_wide(0); run(name + " [256x128]", *a, **k)
+    lib.vcad_debug_gemm_wide(1); run(name + " [256x256]", *a, **k)
+    lib.vcad_debug_gemm_dma(-1); lib.vcad_debug_gemm_wide(-1)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "wide":
+    for rep in range(2):
+        wide("vit qkv fwd", R, 3072, 512)
+        wide("patch embed fwd (f32 out)", 101920, 512, 1024, to=F32, bias=True)
+        wide("vit dqkv dgrad via W^T (NN)", R, 512, 3072)
+        wide("vit dao dgrad via W^T (NN)", R, 1024, 512)
+        wide("vit dz/dh dgrad via W^T (NN)", R, 512, 512)
+        wide("vit qkv wgrad", 3072, 512, R, to=F32, tra=1, trb=1)
+        wide("vit out wgrad", 512, 1024, R, to=F32, tra=1, trb=1)
+        wide("vit mlp wgrad", 512, 512, R, to=F32, tra=1, trb=1)
+        wide("square 4096", 4096, 4096, 4096)
+        wide("square 8192", 8192, 8192, 8192)
+        wide("square 8192 TT", 8192, 8192, 8192, to=F32, tra=1, trb=1)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "pp":
     for rep in range(2):
         three("vit qkv fwd", R, 3072, 512)

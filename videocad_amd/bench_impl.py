@@ -195,7 +195,10 @@ def run(args):
     model, tr = build_trainer(args.dtype, args.dropout, device, rank)
     eng = model._engine
     eng.lib.vcad_debug_gemm_dma(getattr(args, "gemm_dma", -1))
+    eng.lib.vcad_debug_gemm_wide(getattr(args, "gemm_wide", -1))
     bd = synthetic_batch(B, T, 1000 * 2 + rank, device, uint8=args.uint8_frames)
+    # logit parity of this build against the committed fp32 goldens — BEFORE any optimiser step (the goldens are for the hash-init weights)
+    parity = logit_parity(model, device) if (rank == 0 and not getattr(args, "no_parity", False)) else None
 
     for _ in range(args.warmup):
         tr.train_step(bd)
@@ -265,8 +268,6 @@ def run(args):
             pcie = pcie_inclusive(tr, B, T, device)
         except Exception as ex:
             pcie = {"error": repr(ex)}
-
-    parity = logit_parity(model, device) if (rank == 0 and not getattr(args, "no_parity", False)) else None
 
     if rank == 0:
         out = {"metric": "training frames/sec (224x224 grayscale frames, canonical AutoRegressiveTransformer)",

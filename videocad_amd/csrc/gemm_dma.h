@@ -31,6 +31,22 @@ constexpr size_t GD_LDS_BYTES = GD_RING_BYTES + 3 * GD_BN * sizeof(float);      
 constexpr int GD_PIECES_A = GD_A_ELEMS * 2 / 1024, GD_PIECES_B = GD_B_ELEMS * 2 / 1024;   // 32, 16 (1 KiB each)
 constexpr int GD_PW = (GD_PIECES_A + GD_PIECES_B) / 4;                          // DMA instructions per issuing wave per stage (12)
 constexpr int GD_NS = 16;                                                       // epilogue store instructions per wave per tile (2x2x4 quads)
+// The same kernel with a 256 x 256 tile (GdTile<256>): what bounds the 256 x 128 kernel on every large shape is the L2 -> LDS DMA
+// rate of a CU (~20 B/clk measured: 48 KiB per k-tile against 1 024 MFMA cycles caps it at ~40 % — 998 TF/s at 8192^3, r02
+// profiles), not MFMA issue, so the lever is fewer operand bytes per MFMA: 64 KiB per 2 048 MFMA cycles.  Two 64 KiB stages fill
+// the LDS (one stage in flight while the other is consumed); each wave owns 64 x 128 outputs (128 accumulator registers), which
+// leaves no room for the 128 side-input registers a fused residual / activation-derivative epilogue would need: plain epilogues
+// (bias, k-slice slabs) only — the QKV forward, every dgrad through W^T, the split-K weight gradients.
+template <int BN> struct GdTile {
+    static constexpr int STAGES = BN == 128 ? 3 : 2;
+    static constexpr int NJ = BN / 64;                                          // 32-column accumulator tiles per wave (2 or 4)
+    static constexpr int B_ELEMS = BN * GD_BK, STAGE_ELEMS = GD_A_ELEMS + B_ELEMS;
+    static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_ELEMS * 2;
+    static constexpr size_t LDS_BYTES = RING_BYTES + 3 * BN * sizeof(float);
+    static constexpr int PIECES_B = B_ELEMS * 2 / 1024;
+    static constexpr int PW = (GD_PIECES_A + PIECES_B) / 4;                     // 12 / 16
+    static constexpr int NS = 2 * NJ * 4;                                       // 16 / 32
+};
 
 // Per-lane byte offsets of this wave's NP pieces of one operand tile (computed once per item; the k position of a stage is a
 // wave-uniform base added by the scalar unit, so issuing a stage costs ~3 instructions per piece).
@@ -81,12 +97,13 @@ VC_DEV vc_s16x8 gd_frag(const vc_bf16* tile, int row0, int ks, int lane) {
 struct GdCursor { int item, kt, ntc, seq, z, tm, tn; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile row, tile column)
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
+template <int PW, int NS>
 VC_DEV void gd_wait_le(int n) {
-    if (n >= GD_PW + 2 * GD_NS) vc_wait_vmcnt<GD_PW + 2 * GD_NS>();
-    else if (n >= 2 * GD_NS) vc_wait_vmcnt<2 * GD_NS>();
-    else if (n >= GD_PW + GD_NS) vc_wait_vmcnt<GD_PW + GD_NS>();
-    else if (n >= GD_NS) vc_wait_vmcnt<GD_NS>();
-    else if (n >= GD_PW) vc_wait_vmcnt<GD_PW>();
+    if constexpr (PW + 2 * NS <= 63) { if (n >= PW + 2 * NS) { vc_wait_vmcnt<PW + 2 * NS>(); return; } }
+    if constexpr (2 * NS <= 63) { if (n >= 2 * NS) { vc_wait_vmcnt<2 * NS>(); return; } }
+    if (n >= PW + NS) vc_wait_vmcnt<PW + NS>();
+    else if (n >= NS) vc_wait_vmcnt<NS>();
+    else if (n >= PW) vc_wait_vmcnt<PW>();
     else vc_wait_vmcnt<0>();
 }
 
@@ -123,10 +140,12 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
     quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
 }
 
-template <typename TO, bool TRA, bool TRB>
+template <typename TO, bool TRA, bool TRB, int BN>
 VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total) {
+    using TL = GdTile<BN>;
+    constexpr int NJ = TL::NJ, STAGES = TL::STAGES, STAGE_ELEMS = TL::STAGE_ELEMS, PIECES_B = TL::PIECES_B, HALF_N = BN / 2;
     VC_DYN_SHARED(vc_bf16, lds);
-    float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + GD_RING_BYTES);
+    float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + TL::RING_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned char* Ag = (const unsigned char*)p.A;
@@ -143,11 +162,11 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     const int first = cs + j, last = cs + cn;                    // items first, first + nbx, ... < last
     const int nt = p.k_per_split / GD_BK, ktiles = p.K / GD_BK;  // k-tiles per slice (the last slice may be shorter)
     const bool use_bias = p.bias && !p.partial;
-    const bool use_side = (p.residual || p.dact_src) && !p.partial;
+    const bool use_side = NJ == 2 && (p.residual || p.dact_src) && !p.partial;   // (the 256-wide tile has no registers for side inputs)
     // The two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) take turns issuing a WHOLE stage (12 pieces per wave):
     // the group whose turn it is stalls ~0.3 us in the address path while the other group is already on the matrix cores,
     // then runs its own MFMAs while the first group waits at the next barrier — issue time no longer adds to MFMA time.
-    constexpr int NPA = GD_PIECES_A / 4, NPB = GD_PIECES_B / 4;
+    constexpr int NPA = GD_PIECES_A / 4, NPB = PIECES_B / 4;
     const int grp = wave >> 2, wq = wave & 3;
     // bytes one k-tile advances the (wave-uniform) operand base
     const long kstepA = TRA ? (long)GD_BK * p.lda * 2 : (long)GD_BK * 2, kstepB = TRB ? (long)GD_BK * p.ldb * 2 : (long)GD_BK * 2;
@@ -166,13 +185,13 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     uint32_t offA[NPA], offB[NPB];
     auto retarget = [&](const GdCursor& c) {
         gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.tm * GD_BM, p.M, wq * NPA, lane);
-        gd_offsets<TRB, GD_BN, NPB>(offB, p.ldb, c.tn * GD_BN, p.N, wq * NPB, lane);
+        gd_offsets<TRB, BN, NPB>(offB, p.ldb, c.tn * BN, p.N, wq * NPB, lane);
     };
     auto issue = [&](const GdCursor& c, int slot) {
         const long kt_abs = (long)c.z * nt + c.kt;
-        vc_bf16* st = lds + slot * GD_STAGE_ELEMS;
-        // the tile's 128 bias values: issued AHEAD of the item's first stage, so the wait that retires that stage covers them
-        if (use_bias && c.kt == 0 && wq == 0 && lane < GD_BN / 4) vc_dma16(p.bias + c.tn * GD_BN + lane * 4, bias_lds + (c.seq % 3) * GD_BN);
+        vc_bf16* st = lds + slot * STAGE_ELEMS;
+        // the tile's bias values: issued AHEAD of the item's first stage, so the wait that retires that stage covers them
+        if (use_bias && c.kt == 0 && wq == 0 && lane < BN / 4) vc_dma16(p.bias + c.tn * BN + lane * 4, bias_lds + (c.seq % 3) * BN);
         gd_issue<NPA>(Ag + kt_abs * kstepA, offA, st, wq * NPA);
         gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS, wq * NPB);
     };
@@ -181,9 +200,9 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     if (first < last) { locate(pf); retarget(pf); }
     GdCursor cp = pf;
     int turn = 0;                                                // parity of the stage being consumed == the group that issued it
-    for (int s0 = 0; s0 < GD_STAGES - 1 && pf.item < last; ++s0) { if (grp == (s0 & 1)) issue(pf, s0); if (advance(pf) && pf.item < last) retarget(pf); }
+    for (int s0 = 0; s0 < STAGES - 1 && pf.item < last; ++s0) { if (grp == (s0 & 1)) issue(pf, s0); if (advance(pf) && pf.item < last) retarget(pf); }
 
-    vc_f32x16 acc[2][2];
+    vc_f32x16 acc[2][NJ];
     int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
     const int dbg = p.debug_skip;
 
@@ -197,7 +216,9 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         // could still be in flight), so only guaranteed stores (interior tile, the C quads) are counted.
         // (a wave only ever waits for the stages its own group issued: on its turn the stage being consumed is its oldest DMA
         // and nothing younger of its own is in flight yet — the stage after next is issued below, after the barrier)
-        if (grp == turn) gd_wait_le(young_prev + young_cur);
+        // (3 stages: the stage was issued two k-tiles ago, after that k-tile's barrier and before its epilogue — the stores of the
+        // last two epilogues are younger; 2 stages: issued one k-tile ago — only the last epilogue's stores are)
+        if (grp == turn) gd_wait_le<TL::PW, TL::NS>(STAGES == 3 ? young_prev + young_cur : young_cur);
         young_prev = young_cur; young_cur = 0;
         vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
     };
@@ -207,28 +228,28 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     // 1024-cycle MFMA phase — is what this tile shape saturates first; see DESIGN.md.)
     auto ktile_prefetch = [&]() {
         if (pf.item < last) {
-            if (grp == turn) issue(pf, slot == 0 ? GD_STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
+            // stage s is issued by group s & 1: during k-tile t (turn = t & 1) that is stage t + STAGES - 1
+            if (grp == (STAGES == 3 ? turn : turn ^ 1)) issue(pf, slot == 0 ? STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
             if (advance(pf) && pf.item < last) retarget(pf);
         }
         turn ^= 1;
     };
     auto ktile_mfma = [&]() {
-        const vc_bf16* a_tile = lds + slot * GD_STAGE_ELEMS;
+        const vc_bf16* a_tile = lds + slot * STAGE_ELEMS;
         const vc_bf16* b_tile = a_tile + GD_A_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < GD_BK / 16; ++ks) {
-            vc_s16x8 af[2], bf[2];
+            vc_s16x8 af[2], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * 64 + i * 32, ks, lane);
-                bf[i] = gd_frag<TRB, GD_BN>(b_tile, wn * 64 + i * 32, ks, lane);
-            }
+            for (int i = 0; i < 2; ++i) af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * 64 + i * 32, ks, lane);
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) bf[jn] = gd_frag<TRB, BN>(b_tile, wn * HALF_N + jn * 32, ks, lane);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);   // swapped: D[n][m]
+                for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);   // swapped: D[n][m]
         }
-        slot = slot == GD_STAGES - 1 ? 0 : slot + 1;
+        slot = slot == STAGES - 1 ? 0 : slot + 1;
     };
 
 
@@ -241,7 +262,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
+            for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
         for (int kt = 0; kt < cp.ntc - 1; ++kt) { ktile_begin(); ktile_prefetch(); ktile_mfma(); }
@@ -249,13 +270,13 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         // ---- last k-tile of the item: the epilogue's side input is requested before the MFMA phase that hides its latency
         ktile_begin();
         vc_u32x4 side[2][2][4];
-        if (use_side) {
+        if constexpr (NJ == 2) if (use_side) {
             // the residual / dact choice is hoisted around the whole unrolled batch (a per-load select makes hipcc branch and
             // drain around every load)
             int mrow[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) { const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31); mrow[i] = m < p.M ? m : p.M - 1; }
-            const int ncol = tn * GD_BN + wn * 64 + 4 * (lane >> 5);
+            const int ncol = tn * BN + wn * HALF_N + 4 * (lane >> 5);
             if (p.residual) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -285,7 +306,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
             }
         }
         ktile_prefetch();
-        const float* brow = bias_lds + (cp.seq % 3) * GD_BN + wn * 64 + 4 * (lane >> 5);
+        const float* brow = bias_lds + (cp.seq % 3) * BN + wn * HALF_N + 4 * (lane >> 5);
         ktile_mfma();
 
         // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3
@@ -295,10 +316,10 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
             const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31);
             if (m < p.M) {
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
+                for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int n = tn * GD_BN + wn * 64 + jn * 32 + 8 * q + 4 * (lane >> 5);
+                        const int n = tn * BN + wn * HALF_N + jn * 32 + 8 * q + 4 * (lane >> 5);
                         float v[4] = {acc[i][jn][4 * q], acc[i][jn][4 * q + 1], acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]};
                         if (p.partial) {
                             quad_st<float>(p.partial + ((long)z * p.M + m) * p.N + n, v);
@@ -309,12 +330,12 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) v[k] += b4[k];
                                 quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
-                            } else gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
+                            } else if constexpr (NJ == 2) gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
                         }
                     }
             }
         }
-        if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = GD_NS;
+        if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = TL::NS;
     }
     vc_wait_vmcnt<0>();            // no DMA may still be writing this workgroup's LDS when it is handed to the next one
 }

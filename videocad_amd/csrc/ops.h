@@ -34,7 +34,7 @@ struct GemmCall {
 bool vc_profile_on();       // the HIP-event profiler is recording: per-kernel times must not overlap, so no side stream
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s);
 int vc_gemm_prepare(GemmCall& c);                                   // validation + per-problem legality flags (ops_gemm.hip)
-int vc_gemm_dma_launch(GemmCall c, int nsplit, vc_stream_t s);      // persistent DMA-fed kernel (ops_gemm_dma.hip); c already prepared
+int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s);   // persistent DMA-fed kernel (ops_gemm_dma.hip), tile 256 x BN; c already prepared
 // grouped launch of many same-signature problems in one grid (see ops_gemm.hip)
 int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start);
 int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s);

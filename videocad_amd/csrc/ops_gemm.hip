@@ -76,6 +76,8 @@ static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
 
 static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal (tests run small problems through it)
 extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
+static int g_dma_wide = -1;     // 256 x 256 tile of the persistent kernel: -1 = automatic, 0 = never, 1 = whenever legal
+extern "C" void vcad_debug_gemm_wide(int mode) { g_dma_wide = mode; }
 static int g_stagger = -1;      // -1 = automatic
 extern "C" void vcad_debug_gemm_stagger(int n) { g_stagger = n; }
 static int g_debug_skip = 0;
@@ -113,12 +115,19 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     { int rc = vc_gemm_prepare(c); if (rc) return rc; }
     GemmParams& p = c.p;
     const int lay = c.tra * 2 + c.trb;
-    // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad)
-    if (c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && lay != 2 && g_dma_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
-        p.N % GD_BN == 0 && p.K % GD_BK == 0 && (!c.tra || p.M % 8 == 0) && (lay != 3 || c.to == VC_F32) && p.M >= 8 && !p.rowadd &&
-        (double)p.lda * (c.tra ? p.K : p.M) * 2 < 2.0e9 && (double)p.ldb * (c.trb ? p.K : p.N) * 2 < 2.0e9) {
-        const long tiles = (long)VC_CEIL_DIV(p.M, GD_BM) * (p.N / GD_BN);
+    // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad): 256 x 256 tile where
+    // the epilogue is plain (bias / k-slice slabs: QKV forward, dgrads through W^T, split-K wgrads), else 256 x 128
+    const bool plain_epi = !p.act && !p.dact_src && !p.aux && !p.residual && !p.drop.key && p.alpha == 1.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int BN = pass == 0 ? 256 : GD_BN;
+        if (pass == 0 && (!plain_epi || g_dma_wide == 0)) continue;
+        if (!(c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && lay != 2 && g_dma_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
+              p.N % BN == 0 && p.K % GD_BK == 0 && (!c.tra || p.M % 8 == 0) && (lay != 3 || c.to == VC_F32) && p.M >= 8 && !p.rowadd &&
+              (double)p.lda * (c.tra ? p.K : p.M) * 2 < 2.0e9 && (double)p.ldb * (c.trb ? p.K : p.N) * 2 < 2.0e9)) continue;
+        if (pass == 0 && lay == 1) continue;                        // (no 256-wide instantiation of the tr-read B layout: the hot dgrads go through W^T)
+        const long tiles = (long)VC_CEIL_DIV(p.M, GD_BM) * (p.N / BN);
         const int ktiles = p.K / GD_BK;
+        const double kt_us = BN == 256 ? 0.42 : 0.25;               // one k-tile of one item, microseconds
         // k-slices: model time as (rounds over the 256 CUs) x (k-tiles per item) + the fp32 slab round trip of a split
         int best = 1; double bestc = 1e30;
         const size_t per = (size_t)p.M * p.N * sizeof(float);
@@ -127,7 +136,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
             const int nt = VC_CEIL_DIV(ktiles, ns);
             if (VC_CEIL_DIV(ktiles, nt) != ns) continue;
             const double rounds = (double)VC_CEIL_DIV(tiles * ns, 256);
-            const double cost = rounds * (nt * 0.25 + 1.5) + (ns > 1 ? ns * (double)per * 2 / 3.0e6 + 3.0 : 0.0);   // microseconds
+            const double cost = rounds * (nt * kt_us + 1.5) + (ns > 1 ? ns * (double)per * 2 / 3.0e6 + 3.0 : 0.0);   // microseconds
             if (cost < bestc) { bestc = cost; best = ns; }
         }
         const int nt = VC_CEIL_DIV(ktiles, best);
@@ -136,10 +145,14 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         // register-staged kernel's second co-resident workgroup hides that), on the long-K dgrad through ds_read_b64_tr_b16
         // (K >= 2048), and on wgrads with fewer than 16 output tiles (the k-slice slabs dominate).
         const bool wins = tiles * best >= 200 && !p.act && !p.dact_src && !(lay == 1 && p.K >= 2048) && !(lay == 3 && tiles < 16);
-        if (g_dma_mode == 1 || wins) {
+        // the wide tile halves the item count: with few, short items (N = 512, K = 512: 814 items of 8 k-tiles = 3.2 rounds) the last,
+        // partly filled round costs more than the tile saves (measured: profiles/r02_gemm_wide_ab.txt) — long items amortise it
+        const double fill = (double)(tiles * best) / (256.0 * VC_CEIL_DIV(tiles * best, 256));
+        const bool wide_ok = BN == GD_BN || g_dma_wide == 1 || fill >= 0.85 || nt >= 16;
+        if ((g_dma_mode == 1 || wins) && wide_ok) {
             p.k_per_split = nt * GD_BK;
             p.partial = best > 1 ? scratch : nullptr;
-            return vc_gemm_dma_launch(c, best, s);
+            return vc_gemm_dma_launch(c, best, BN, s);
         }
     }
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;

@@ -10,23 +10,23 @@ static int g_variant = 0;        // 0 = the lockstep kernel (gemm_dma.h, default
 extern "C" void vcad_debug_gemm_variant(int v) { g_variant = v ? 1 : 0; }
 extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
-template <typename TO, bool TRA, bool TRB>
+template <typename TO, bool TRA, bool TRB, int BN>
 static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #ifndef VC_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
         attr_set = true;
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
                  (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s);
-    const int tiles_n = c.p.N / GD_BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
+    const int tiles_n = c.p.N / BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
     ++g_dma_launches;
     const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
     // the ping-pong kernel carries the plain epilogue (bias, k-slice slabs); per-element side inputs stay on the lockstep kernel
-    if (g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
+    if (BN == GD_BN && g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
 #ifndef VC_EMU
         static bool attr_pp = false;
         if (!attr_pp) {
@@ -37,7 +37,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #endif
         VC_LAUNCH((gemm_pp_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GP_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
     } else
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GD_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN>), dim3(grid), dim3(GD_THREADS), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;
         if (c.p.vecC && c.p.N % 4 == 0) VC_LAUNCH((gemm_splitk_reduce4_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot / 4, 256)), dim3(256), 0, s, c.p, nsplit);
@@ -47,9 +47,14 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 }
 
 
-int vc_gemm_dma_launch(GemmCall c, int nsplit, vc_stream_t s) {
+int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
     const int lay = c.tra * 2 + c.trb;
-    if (lay == 3) return gemm_launch_dma<float, true, true>(c, nsplit, s);
-    if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false>(c, nsplit, s);
-    return c.to == VC_F32 ? gemm_launch_dma<float, false, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, true>(c, nsplit, s);
+    if (BN == 256) {                       // plain epilogues only (checked by the dispatcher); no tr-read B instantiation
+        if (lay == 3) return gemm_launch_dma<float, true, true, 256>(c, nsplit, s);
+        if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256>(c, nsplit, s);
+        vc_set_error("vc_gemm_dma_launch: no 256-wide kernel for layout %d", lay); return VC_ERR_UNSUPPORTED;
+    }
+    if (lay == 3) return gemm_launch_dma<float, true, true, GD_BN>(c, nsplit, s);
+    if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, GD_BN>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, GD_BN>(c, nsplit, s);
+    return c.to == VC_F32 ? gemm_launch_dma<float, false, true, GD_BN>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, true, GD_BN>(c, nsplit, s);
 }
