@@ -150,6 +150,10 @@ void vcad_debug_gemm_dma(int mode);
 long vcad_debug_gemm_dma_launches(void);
 /* 256 x 256 tile of the persistent kernel (plain epilogues): -1 automatic, 0 never, 1 whenever legal */
 void vcad_debug_gemm_wide(int mode);
+/* XCD column groups of the persistent kernel's forward-layout launches: -1 automatic, 0 never, 2 / 4 / 8 forced */
+void vcad_debug_gemm_xcd_cols(int xn);
+/* epilogue form of the persistent kernel's k-contiguous-B launches: -1 automatic, 0 row-per-lane (r01), 1 column-per-lane */
+void vcad_debug_gemm_epilogue(int mode);
 /* which persistent DMA-fed kernel: 0 = lockstep (default), 1 = ping-pong wave groups + line-coalesced epilogue (A/B experiment, slower) */
 void vcad_debug_gemm_variant(int v);
 /* ablation (tools/gemm_ablate*.py): start-offset of the first wave / bit mask of pipeline stages to skip; 0 = off */

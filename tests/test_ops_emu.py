@@ -71,6 +71,11 @@ def test_gemm_dma_kernel(emu, gemm_tile, tra, trb, to):
             U.check_gemm(emu, "cpu", M, 128, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
         assert emu.vcad_debug_gemm_dma_launches() == n0 + 5
         emu.vcad_debug_gemm_variant(0)
+        if not tra and not trb:      # XCD column groups: 4 tile columns over 4 / 2 XCD columns, 9 tile rows over 2 / 4 XCD rows
+            for xn in (4, 2):
+                emu.vcad_debug_gemm_xcd_cols(xn)
+                U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, residual=(to == F32), splitk=False)
+            emu.vcad_debug_gemm_xcd_cols(-1)
     finally:
         emu.vcad_debug_gemm_dma(-1)
 
@@ -87,8 +92,12 @@ def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
         U.check_gemm(emu, "cpu", M, 512, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=not tra, splitk=bool(tra))
         U.check_gemm(emu, "cpu", 264, 256, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
         assert emu.vcad_debug_gemm_dma_launches() == n0 + 2, "the GEMM did not take the DMA kernel"
+        if not tra:      # XCD column groups (forward layout): 2 x 4 and 4 x 2 XCD grids over 3 tile rows x 2 tile columns
+            for xn in (2, 1):
+                emu.vcad_debug_gemm_xcd_cols(xn if xn > 1 else -1)
+                U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, splitk=False)
     finally:
-        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1)
+        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1); emu.vcad_debug_gemm_xcd_cols(-1)
 
 
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16)])

@@ -81,6 +81,53 @@ def wide(name, *a, **k):
     lib.vcad_debug_gemm_dma(-1); lib.vcad_debug_gemm_wide(-1)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "epi2":
+    # interleaved A/B (rule: perf deltas come from within-process interleaved rounds): per shape, 3 rounds of row / col
+    lib.vcad_debug_gemm_dma(1)
+    shapes = [("qkv fwd wide", 1, (R, 3072, 512), {}), ("dao dgrad W^T wide", 1, (R, 1024, 512), {}), ("dh dgrad W^T wide", 1, (R, 512, 512), {}),
+              ("dh dgrad W^T narrow", 0, (R, 512, 512), {}), ("dqkv dgrad W^T wide", 1, (R, 512, 3072), {}),
+              ("patch embed f32 wide", 1, (101920, 512, 1024), dict(to=F32, bias=True)),
+              ("out fwd +res f32 narrow", 0, (R, 512, 1024), dict(to=F32, bias=True, res=True)),
+              ("mlp2 fwd +res f32 narrow", 0, (R, 512, 512), dict(to=F32, bias=True, res=True))]
+    for name, w, dims, kw in shapes:
+        lib.vcad_debug_gemm_wide(w)
+        for rnd in range(3):
+            for e in (0, 1):
+                lib.vcad_debug_gemm_epilogue(e)
+                run(f"{name} [{'col' if e else 'row'} #{rnd}]", *dims, **kw)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "epi":
+    lib.vcad_debug_gemm_dma(1)
+    for rep in range(2):
+        for w in (0, 1):
+            lib.vcad_debug_gemm_wide(w)
+            for e in (0, 1):
+                lib.vcad_debug_gemm_epilogue(e)
+                tag = f"[wide={w} {'col' if e else 'row'}]"
+                run("vit qkv fwd " + tag, R, 3072, 512)
+                run("vit dqkv dgrad W^T (bf16 out) " + tag, R, 512, 3072)
+                run("vit dao dgrad W^T (bf16 out) " + tag, R, 1024, 512)
+                run("vit dh dgrad W^T (bf16 out) " + tag, R, 512, 512)
+                run("patch embed fwd (f32 out) " + tag, 101920, 512, 1024, to=F32, bias=True)
+                if not w:
+                    run("vit out fwd (+res, f32 out) " + tag, R, 512, 1024, to=F32, bias=True, res=True)
+                    run("vit mlp2 fwd (+res, f32 out) " + tag, R, 512, 512, to=F32, bias=True, res=True)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "xcd":
+    lib.vcad_debug_gemm_dma(1)
+    for rep in range(2):
+        for w in (0, 1):
+            lib.vcad_debug_gemm_wide(w)
+            for xn in (0, 2, 4, 8):
+                lib.vcad_debug_gemm_xcd_cols(xn)
+                run(f"vit qkv fwd [wide={w} xcd-cols={xn}]", R, 3072, 512)
+            for xn in (0, 2, 4):
+                lib.vcad_debug_gemm_xcd_cols(xn)
+                run(f"vit dao dgrad W^T N=1024 [wide={w} xcd-cols={xn}]", R, 1024, 512)
+            for xn in (0, 2):
+                lib.vcad_debug_gemm_xcd_cols(xn)
+                run(f"vit dqkv dgrad W^T K=3072 [wide={w} xcd-cols={xn}]", R, 512, 3072)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "wide":
     for rep in range(2):
         wide("vit qkv fwd", R, 3072, 512)

@@ -50,7 +50,10 @@ template <int BN> struct GdTile {
 
 // Per-lane byte offsets of this wave's NP pieces of one operand tile (computed once per item; the k position of a stage is a
 // wave-uniform base added by the scalar unit, so issuing a stage costs ~3 instructions per piece).
-template <bool TR, int EXT, int NP>
+// PERM = NJ > 0 (B operand of the column-per-lane epilogue): inside every panel of NJ * 32 rows, LDS row rho holds operand row
+// NJ * (rho % 32) + rho / 32, so the fragment of accumulator tile jn (LDS rows 32 jn .. 32 jn + 31, conflict-free as before)
+// carries output columns NJ c + jn for lane c: a lane ends up with NJ ADJACENT output columns.
+template <bool TR, int EXT, int NP, int PERM = 0>
 VC_DEV void gd_offsets(uint32_t (&off)[NP], long ld, int r0, int R, int p0, int lane) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -58,7 +61,9 @@ VC_DEV void gd_offsets(uint32_t (&off)[NP], long ld, int r0, int R, int p0, int 
         if constexpr (!TR) {                       // piece = 8 rows x 128 B
             const int row = pc * 8 + (lane >> 3);
             const int slot = (lane & 7) ^ ((row >> 1) & 7);
-            int rg = r0 + row; rg = rg < R ? rg : R - 1;                       // tail rows: re-read the last row (never stored)
+            int grow = row;
+            if constexpr (PERM > 0) { const int w = row % (PERM * 32); grow = row - w + PERM * (w % 32) + w / 32; }
+            int rg = r0 + grow; rg = rg < R ? rg : R - 1;                      // tail rows: re-read the last row (never stored)
             off[i] = (uint32_t)(((long)rg * ld + slot * 8) * 2);
         } else {                                   // piece = 1024/(2*EXT) k-rows of EXT elements
             constexpr int SPR = EXT / 8, KPP = 64 / SPR;                        // slots per k-row, k-rows per piece
@@ -92,6 +97,18 @@ VC_DEV vc_s16x8 gd_frag(const vc_bf16* tile, int row0, int ks, int lane) {
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
         return r;
     }
+}
+
+// NJ (2 or 4) adjacent columns of one row: one 4 / 8 / 16-byte access
+template <typename T, int NJ> VC_DEV void gd_vec_st(T* q, const float (&v)[NJ]) {
+    if constexpr (sizeof(T) == 4 && NJ == 4) { vc_u32x4 t; t.x = vc_f32_bits(v[0]); t.y = vc_f32_bits(v[1]); t.z = vc_f32_bits(v[2]); t.w = vc_f32_bits(v[3]); *reinterpret_cast<vc_u32x4*>(q) = t; }
+    else if constexpr (sizeof(T) == 4) { vc_u32x2 t; t.x = vc_f32_bits(v[0]); t.y = vc_f32_bits(v[1]); *reinterpret_cast<vc_u32x2*>(q) = t; }
+    else if constexpr (NJ == 4) { vc_u32x2 t; t.x = vc_pack_bf16x2(v[0], v[1]); t.y = vc_pack_bf16x2(v[2], v[3]); *reinterpret_cast<vc_u32x2*>(q) = t; }
+    else *reinterpret_cast<uint32_t*>(q) = vc_pack_bf16x2(v[0], v[1]);
+}
+template <int NJ> VC_DEV void gd_vec_ld_f32(const float* q, float (&v)[NJ]) {
+    if constexpr (NJ == 4) { const vc_u32x4 t = *reinterpret_cast<const vc_u32x4*>(q); v[0] = vc_bits_f32(t.x); v[1] = vc_bits_f32(t.y); v[2] = vc_bits_f32(t.z); v[3] = vc_bits_f32(t.w); }
+    else { const vc_u32x2 t = *reinterpret_cast<const vc_u32x2*>(q); v[0] = vc_bits_f32(t.x); v[1] = vc_bits_f32(t.y); }
 }
 
 struct GdCursor { int item, kt, ntc, seq, z, tm, tn; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile row, tile column)
@@ -140,10 +157,17 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
     quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
 }
 
-template <typename TO, bool TRA, bool TRB, int BN>
-VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total) {
+template <typename TO, bool TRA, bool TRB, int BN, bool COLW>
+VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn) {
     using TL = GdTile<BN>;
     constexpr int NJ = TL::NJ, STAGES = TL::STAGES, STAGE_ELEMS = TL::STAGE_ELEMS, PIECES_B = TL::PIECES_B, HALF_N = BN / 2;
+    // COL: column-per-lane accumulators (MFMA issued A x B; a lane owns NJ ADJACENT output columns of 16 rows).  r01's epilogue was
+    // row-per-lane (swapped MFMA): every store / side-load instruction touched 32-64 different cache lines with 8-16 bytes each and
+    // ran at ~7 B/clk per CU — a third of the QKV forward.  Here an instruction covers 2 rows x 32 lanes x NJ adjacent columns
+    // (128-512 contiguous bytes per row).  Needs the B rows permuted on their way into LDS (gd_offsets<PERM>), which the DMA's
+    // per-lane source address gives for free for a k-contiguous B; the tr-read B layouts (wgrad, dgrad through W) keep the r01 form.
+    constexpr bool COL = !TRB && COLW;
+    constexpr int NS_ITEM = COL ? 32 : TL::NS;                                  // epilogue stores per wave per interior item
     VC_DYN_SHARED(vc_bf16, lds);
     float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + TL::RING_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
@@ -154,12 +178,26 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     // this workgroup's items: XCD x (= block id & 7, the hardware's round-robin) owns one contiguous chunk of the item list
     // (items ordered k-slice major, then tile_m, tile_n fastest), and its workgroups sweep that chunk interleaved — at any
     // moment one XCD's L2 serves neighbouring tiles that share A panels / the same k-slice.
+    // xn > 1 (forward GEMMs with a weight matrix larger than an XCD's L2 share, e.g. the QKV projection: 3 MiB of weights against a
+    // 4 MiB L2 that also streams A and C): the XCDs form an (8 / xn) x xn grid, XCD (gy, gx) owns tile rows gy and tile COLUMNS gx
+    // only, so the 1 / xn of the weights it touches stays L2-resident instead of being re-fetched by every item (r01 counters: 1 075
+    // MB fetched for 110 MB of operands); the price — A is read by xn XCDs — is paid out of the Infinity Cache.
     const int G = gridDim.x, b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int nbx = (G + 7 - xcd) >> 3;
-    const int q8 = total >> 3, r8 = total & 7;
-    const int cs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int cn = xcd < r8 ? q8 + 1 : q8;
-    const int first = cs + j, last = cs + cn;                    // items first, first + nbx, ... < last
+    int tm0 = 0, tn0 = 0, tnc = tiles_n, tmn = tiles_mn, first, last;
+    if (xn > 1) {
+        const int xm = 8 / xn, gx = xcd % xn, gy = xcd / xn, tiles_m = tiles_mn / tiles_n;
+        tnc = tiles_n / xn; tn0 = gx * tnc;
+        const int qm = tiles_m / xm, rm = tiles_m % xm;
+        tm0 = gy < rm ? gy * (qm + 1) : rm * (qm + 1) + (gy - rm) * qm;
+        tmn = (gy < rm ? qm + 1 : qm) * tnc;                       // tiles of this XCD per k-slice
+        first = j; last = tmn * nsplit;
+    } else {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int cs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        const int cn = xcd < r8 ? q8 + 1 : q8;
+        first = cs + j; last = cs + cn;                          // items first, first + nbx, ... < last
+    }
     const int nt = p.k_per_split / GD_BK, ktiles = p.K / GD_BK;  // k-tiles per slice (the last slice may be shorter)
     const bool use_bias = p.bias && !p.partial;
     const bool use_side = NJ == 2 && (p.residual || p.dact_src) && !p.partial;   // (the 256-wide tile has no registers for side inputs)
@@ -172,8 +210,9 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     const long kstepA = TRA ? (long)GD_BK * p.lda * 2 : (long)GD_BK * 2, kstepB = TRB ? (long)GD_BK * p.ldb * 2 : (long)GD_BK * 2;
 
     auto locate = [&](GdCursor& c) {            // integer divisions: once per item, never per k-tile
-        c.z = c.item / tiles_mn; const int rem = c.item - c.z * tiles_mn;
-        c.tm = rem / tiles_n; c.tn = rem - c.tm * tiles_n;
+        c.z = c.item / tmn; const int rem = c.item - c.z * tmn;
+        const int rm_ = rem / tnc;
+        c.tm = tm0 + rm_; c.tn = tn0 + rem - rm_ * tnc;
         const int rest = ktiles - c.z * nt; c.ntc = rest < nt ? rest : nt;
     };
     auto advance = [&](GdCursor& c) -> bool {   // true when the cursor moved on to a new item
@@ -185,7 +224,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     uint32_t offA[NPA], offB[NPB];
     auto retarget = [&](const GdCursor& c) {
         gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.tm * GD_BM, p.M, wq * NPA, lane);
-        gd_offsets<TRB, BN, NPB>(offB, p.ldb, c.tn * BN, p.N, wq * NPB, lane);
+        gd_offsets<TRB, BN, NPB, COL ? NJ : 0>(offB, p.ldb, c.tn * BN, p.N, wq * NPB, lane);
     };
     auto issue = [&](const GdCursor& c, int slot) {
         const long kt_abs = (long)c.z * nt + c.kt;
@@ -218,7 +257,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         // and nothing younger of its own is in flight yet — the stage after next is issued below, after the barrier)
         // (3 stages: the stage was issued two k-tiles ago, after that k-tile's barrier and before its epilogue — the stores of the
         // last two epilogues are younger; 2 stages: issued one k-tile ago — only the last epilogue's stores are)
-        if (grp == turn) gd_wait_le<TL::PW, TL::NS>(STAGES == 3 ? young_prev + young_cur : young_cur);
+        if (grp == turn) gd_wait_le<TL::PW, NS_ITEM>(STAGES == 3 ? young_prev + young_cur : young_cur);
         young_prev = young_cur; young_cur = 0;
         vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
     };
@@ -247,7 +286,10 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);   // swapped: D[n][m]
+                for (int jn = 0; jn < NJ; ++jn) {
+                    if constexpr (COL) acc[i][jn] = vc_mfma_32x32x16_bf16(af[i], bf[jn], acc[i][jn]);      // D[m][n]: lane = column
+                    else acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);                    // swapped, D[n][m]: lane = row
+                }
         }
         slot = slot == STAGES - 1 ? 0 : slot + 1;
     };
@@ -269,6 +311,86 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
 
         // ---- last k-tile of the item: the epilogue's side input is requested before the MFMA phase that hides its latency
         ktile_begin();
+        // ---------------------------------------------------------------- column-per-lane form (k-contiguous B)
+        if constexpr (COL) {
+            const int cl = lane & 31;
+            const int nb = tn * BN + wn * HALF_N + NJ * cl;                        // first of this lane's NJ adjacent columns
+            const int mb = tm * GD_BM + wm * 64 + 4 * (lane >> 5);                 // row of (i = 0, r = 0); row(i, r) = mb + 32 i + (r & 3) + 8 (r >> 2)
+            vc_u32x2 sd[2][16];                                                    // side input of (i, r): NJ = 2 columns (fp32 pair / packed bf16 pair in .x)
+            if constexpr (NJ == 2) if (use_side) {
+                if (p.residual) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
+                            sd[i][r] = *reinterpret_cast<const vc_u32x2*>(p.residual + (long)m * p.ldr + nb);
+                        }
+                } else if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
+                            sd[i][r].x = *reinterpret_cast<const uint32_t*>(((const TO*)p.dact_src) + (long)m * p.lddact + nb);
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
+                            sd[i][r] = *reinterpret_cast<const vc_u32x2*>(((const TO*)p.dact_src) + (long)m * p.lddact + nb);
+                        }
+                }
+            }
+            ktile_prefetch();
+            ktile_mfma();
+            if (dbg & 64) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
+            float bv[NJ];
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) bv[jn] = 0.0f;
+            if (use_bias) gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % 3) * BN + wn * HALF_N + NJ * cl, bv);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < p.M) {
+                        float v[NJ];
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn) v[jn] = acc[i][jn][r];
+                        if (p.partial) {
+                            gd_vec_st<float, NJ>(p.partial + ((long)z * p.M + m) * p.N + nb, v);
+                        } else if (plain) {
+#pragma unroll
+                            for (int jn = 0; jn < NJ; ++jn) v[jn] += bv[jn];
+                            gd_vec_st<TO, NJ>(((TO*)p.C) + (long)m * p.ldc + nb, v);
+                        } else if constexpr (NJ == 2) {
+                            // fused epilogue on the lane's two adjacent columns: alpha, bias, pre-activation output, activation, dropout,
+                            // activation derivative, residual (order of gemm.h: gemm_epilogue_quad)
+                            v[0] = p.alpha * v[0] + bv[0]; v[1] = p.alpha * v[1] + bv[1];
+                            if (p.aux) gd_vec_st<TO, 2>(((TO*)p.aux) + (long)m * p.ldaux + nb, v);
+                            if (p.act) { v[0] = vc_apply_act(v[0], p.act); v[1] = vc_apply_act(v[1], p.act); }
+                            if (p.drop.key) {                                      // nb is even: both columns share one hash (vc_drop_mul's pairing)
+                                const uint32_t h = vc_drop_hash(p.drop, (uint32_t)(((long)m * p.N + nb) >> 1));
+                                v[0] *= vc_drop_keep_lo(p.drop, h) ? p.drop.scale : 0.0f; v[1] *= vc_drop_keep_hi(p.drop, h) ? p.drop.scale : 0.0f;
+                            }
+                            if (p.dact_src) {
+                                float s0, s1;
+                                if constexpr (sizeof(TO) == 2) { s0 = vc_bits_f32(sd[i][r].x << 16); s1 = vc_bits_f32(sd[i][r].x & 0xffff0000u); }
+                                else { s0 = vc_bits_f32(sd[i][r].x); s1 = vc_bits_f32(sd[i][r].y); }
+                                v[0] = vc_apply_dact(v[0], s0, p.dact_kind); v[1] = vc_apply_dact(v[1], s1, p.dact_kind);
+                            }
+                            if (p.residual) { v[0] += vc_bits_f32(sd[i][r].x); v[1] += vc_bits_f32(sd[i][r].y); }
+                            gd_vec_st<TO, 2>(((TO*)p.C) + (long)m * p.ldc + nb, v);
+                        }
+                    }
+                }
+            if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = NS_ITEM;
+            continue;
+        }
+        // ---------------------------------------------------------------- row-per-lane form (tr-read B layouts), as in r01
         vc_u32x4 side[2][2][4];
         if constexpr (NJ == 2) if (use_side) {
             // the residual / dact choice is hoisted around the whole unrolled batch (a per-load select makes hipcc branch and
@@ -335,7 +457,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                     }
             }
         }
-        if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = TL::NS;
+        if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = NS_ITEM;
     }
     vc_wait_vmcnt<0>();            // no DMA may still be writing this workgroup's LDS when it is handed to the next one
 }

@@ -148,7 +148,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         // the wide tile halves the item count: with few, short items (N = 512, K = 512: 814 items of 8 k-tiles = 3.2 rounds) the last,
         // partly filled round costs more than the tile saves (measured: profiles/r02_gemm_wide_ab.txt) — long items amortise it
         const double fill = (double)(tiles * best) / (256.0 * VC_CEIL_DIV(tiles * best, 256));
-        const bool wide_ok = BN == GD_BN || g_dma_wide == 1 || fill >= 0.85 || nt >= 16;
+        const bool wide_ok = BN == GD_BN || g_dma_wide == 1 || lay == 0 || fill >= 0.85 || nt >= 16;   // (forward layout: the column-per-lane epilogue of the wide tile wins even then)
         if ((g_dma_mode == 1 || wins) && wide_ok) {
             p.k_per_split = nt * GD_BK;
             p.partial = best > 1 ? scratch : nullptr;

@@ -5,17 +5,21 @@
 #include "gemm_pp.h"
 
 static long g_dma_launches = 0;
+static int g_xn = -1;            // XCD column groups of the forward-layout launches: -1 = automatic, 0 = never, 2 / 4 / 8 = forced (A/B)
+extern "C" void vcad_debug_gemm_xcd_cols(int xn) { g_xn = (xn == 2 || xn == 4 || xn == 8) ? xn : (xn == 0 ? 0 : -1); }
 static int g_variant = 0;        // 0 = the lockstep kernel (gemm_dma.h, default), 1 = ping-pong wave groups (gemm_pp.h): measured SLOWER, kept for the A/B
                                  // (profiles/r02_gemm_pingpong_ab.txt: both are bound by the ~20 B/clk/CU L2->LDS DMA rate, not by MFMA issue)
 extern "C" void vcad_debug_gemm_variant(int v) { g_variant = v ? 1 : 0; }
 extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
-template <typename TO, bool TRA, bool TRB, int BN>
+static int g_epi = -1;           // epilogue form of the k-contiguous-B launches: -1 = automatic, 0 = row-per-lane (r01), 1 = column-per-lane
+extern "C" void vcad_debug_gemm_epilogue(int m) { g_epi = m; }
+template <typename TO, bool TRA, bool TRB, int BN, bool COLW>
 static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #ifndef VC_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN, COLW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
         attr_set = true;
     }
@@ -36,8 +40,21 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
         }
 #endif
         VC_LAUNCH((gemm_pp_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GP_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
-    } else
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN>), dim3(grid), dim3(GD_THREADS), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
+    } else {
+    // XCD column groups (see the kernel): only for k-contiguous forward-layout GEMMs whose weight matrix would not stay in one XCD's L2
+    int xn = 1;
+    if (!TRA && !TRB && g_xn != 0 && grid >= 8) {
+        const double b_bytes = (double)c.p.N * c.p.K * 2, a_bytes = (double)c.p.M * c.p.K * 2, slice = (double)BN * c.p.K * 2;
+        const int tiles_m = tiles_mn / tiles_n;
+        if (g_xn > 0) { xn = g_xn; if (tiles_n % xn || tiles_m < 8 / xn) xn = 1; }         // forced (tests, A/B): any grid
+        else if (grid == 256 && b_bytes >= 2.0e6) {
+            xn = 2; while (xn < 8 && b_bytes / xn > 1.6e6) xn *= 2;
+            // worth it only if the extra A reads (xn XCD columns) stay well below the weight re-fetches they remove, and every XCD keeps rows to sweep
+            if (tiles_n % xn || a_bytes * xn > 0.5 * (double)tiles_mn * slice || tiles_m < 8 * 8 / xn) xn = 1;
+        }
+    }
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW>), dim3(grid), dim3(GD_THREADS), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total, xn);
+    }
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;
         if (c.p.vecC && c.p.N % 4 == 0) VC_LAUNCH((gemm_splitk_reduce4_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(tot / 4, 256)), dim3(256), 0, s, c.p, nsplit);
@@ -47,14 +64,24 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 }
 
 
+// column-per-lane epilogue?  Interleaved A/B on the C2 shapes (profiles/r02_gemm_epilogue_ab.txt): with the 256-wide tile a lane owns 4
+// adjacent columns (8-byte bf16 / 16-byte fp32 stores, full lines) and the plain epilogues gain 5-23 % (QKV forward 459 -> 370 us, dh
+// dgrad 87 -> 67 us); with the 128-wide tile it owns 2 (twice the store / side-load instructions of the row form's 16-byte quads) and the
+// fused residual epilogues LOSE 45-60 % (out-proj forward 196 -> 286 us) — those keep r01's row-per-lane form.
+static bool use_col(const GemmCall& c, int BN) {
+    if (g_epi >= 0) return g_epi != 0;
+    return BN == 256;
+}
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
     const int lay = c.tra * 2 + c.trb;
     if (BN == 256) {                       // plain epilogues only (checked by the dispatcher); no tr-read B instantiation
-        if (lay == 3) return gemm_launch_dma<float, true, true, 256>(c, nsplit, s);
-        if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256>(c, nsplit, s);
+        if (lay == 3) return gemm_launch_dma<float, true, true, 256, false>(c, nsplit, s);
+        if (lay == 0 && c.to == VC_F32) return use_col(c, BN) ? gemm_launch_dma<float, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<float, false, false, 256, false>(c, nsplit, s);
+        if (lay == 0) return use_col(c, BN) ? gemm_launch_dma<vc_bf16, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, false>(c, nsplit, s);
         vc_set_error("vc_gemm_dma_launch: no 256-wide kernel for layout %d", lay); return VC_ERR_UNSUPPORTED;
     }
-    if (lay == 3) return gemm_launch_dma<float, true, true, GD_BN>(c, nsplit, s);
-    if (lay == 0) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, GD_BN>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, GD_BN>(c, nsplit, s);
-    return c.to == VC_F32 ? gemm_launch_dma<float, false, true, GD_BN>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, true, GD_BN>(c, nsplit, s);
+    if (lay == 3) return gemm_launch_dma<float, true, true, GD_BN, false>(c, nsplit, s);
+    if (lay == 0 && c.to == VC_F32) return use_col(c, BN) ? gemm_launch_dma<float, false, false, GD_BN, true>(c, nsplit, s) : gemm_launch_dma<float, false, false, GD_BN, false>(c, nsplit, s);
+    if (lay == 0) return use_col(c, BN) ? gemm_launch_dma<vc_bf16, false, false, GD_BN, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, GD_BN, false>(c, nsplit, s);
+    return c.to == VC_F32 ? gemm_launch_dma<float, false, true, GD_BN, false>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, true, GD_BN, false>(c, nsplit, s);
 }

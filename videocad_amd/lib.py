@@ -66,6 +66,8 @@ PROTOTYPES = {
     "vcad_debug_gemm_dma_launches": (C.c_long, []),
     "vcad_debug_gemm_variant": (None, [_i]),
     "vcad_debug_gemm_wide": (None, [_i]),
+    "vcad_debug_gemm_xcd_cols": (None, [_i]),
+    "vcad_debug_gemm_epilogue": (None, [_i]),
     "vcad_debug_gemm_stagger": (None, [_i]),
     "vcad_debug_gemm_skip": (None, [_i]),
     "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, _vp]),
