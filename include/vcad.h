@@ -164,6 +164,11 @@ void vcad_debug_gemm_skip(int mask);
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
                  const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, void* stream);
+/* MXFP8 (VCAD_FP8 mode): x [rows, cols] fp32 / bf16 (tx) -> q [rows, cols] OCP e4m3 bytes + scales [rows, cols/32] E8M0 bytes (one
+ * power-of-two scale per 32 consecutive elements); C (type `to`) = act(A8 B8^T + bias) + residual on the block-scaled fp8 MFMA */
+int vcad_op_quant_mx8(int tx, const void* x, int64_t ldx, void* q, void* scales, int64_t rows, int cols, void* stream);
+int vcad_op_gemm_mx8(int to, const void* A8, const void* sa, const void* B8, const void* sb, void* C, int M, int N, int K, int64_t ldc,
+                     const float* bias, int act, const float* residual, int64_t ldr, void* stream);
 int vcad_op_layernorm_fwd(int tx, int ty, int C, const void* x, int64_t ldx, const float* gamma, const float* beta,
                           float* y32, void* yt, float* stats, int64_t rows, float eps, void* stream);
 int vcad_op_layernorm_bwd(int td, int ty, int C, const void* dy, const float* x, int64_t ldx, const float* stats,

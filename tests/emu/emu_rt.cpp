@@ -61,6 +61,7 @@ struct WaveState {
     float fslot[64];
     int islot[64];
     short a[64][8], b[64][8];
+    int a32[64][8], b32[64][8]; int sa[64], sb[64];
     short tr[64][4];
     float fa[64], fb[64];
 };
@@ -187,6 +188,30 @@ void dma16(const void* gsrc, void* lds_piece) {      // global_load_lds_dwordx4:
     memcpy((char*)lds_piece + 16 * (bs->cur & 63), gsrc, 16);
 }
 
+void mfma_mx8_32x32x64(const int* a8, const int* b8, float* c16, int sa_byte, int sb_byte) {
+    // layout probed on gfx950 (tools/probe_mx8_layout.hip): lane (row, half h): bytes 0-15 = k 16h.. of scale block 0, bytes 16-31 = k 32+16h..
+    // of scale block 1; the scale of block b of a row comes from lane row + 32 b
+    BlockState* bs = g_bs;
+    WaveState& w = bs->waves[bs->cur / 64];
+    int l = bs->cur & 63;
+    memcpy(w.a32[l], a8, 32); memcpy(w.b32[l], b8, 32); w.sa[l] = sa_byte; w.sb[l] = sb_byte;
+    wave_sync();
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float acc = c16[r];
+        for (int blk = 0; blk < 2; ++blk) {
+            const float sc = ldexpf(1.0f, w.sa[row + 32 * blk] - 127) * ldexpf(1.0f, w.sb[col + 32 * blk] - 127);
+            float part = 0.f;
+            for (int h = 0; h < 2; ++h) {
+                const uint8_t* ab = (const uint8_t*)w.a32[row + 32 * h] + 16 * blk; const uint8_t* bb = (const uint8_t*)w.b32[col + 32 * h] + 16 * blk;
+                for (int k = 0; k < 16; ++k) part += vc_e4m3_to_f32(ab[k]) * vc_e4m3_to_f32(bb[k]);
+            }
+            acc += part * sc;
+        }
+        c16[r] = acc;
+    }
+    wave_sync();
+}
 void mfma_32x32x2_f32(float a, float b, float* c16) {
     BlockState* bs = g_bs;
     WaveState& w = bs->waves[bs->cur / 64];

@@ -191,3 +191,55 @@ def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=
     tolb = 1e-5 if dt == torch.float32 else 1.5e-2
     for i, g in enumerate((qr.grad, kr.grad, vr.grad)):
         assert relerr(dqkv[:, :, i], g) < tolb, ("attn bwd", i, relerr(dqkv[:, :, i], g))
+
+
+# ------------------------------------------------------------------------------------------------ MXFP8 (csrc/gemm_mx8.h)
+def mx8_quant_ref(x):
+    """[rows, cols] float -> (e4m3 bytes [rows, cols] uint8, E8M0 scale bytes [rows, cols/32] uint8): the OCP MX rule the kernel
+    implements (shared exponent = floor(log2(block amax)) - 8, elements RNE to e4m3, saturating)."""
+    r, c = x.shape
+    xb = x.float().reshape(r, c // 32, 32)
+    am = xb.abs().amax(-1)
+    e = torch.where(am > 0, torch.floor(torch.log2(am.double())).float() - 8, torch.full_like(am, -127.0)).clamp(-127, 127)
+    q = (xb * torch.exp2(-e).unsqueeze(-1)).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).reshape(r, c), (e + 127).to(torch.uint8)
+
+
+def mx8_dequant(q, s):
+    r, c = q.shape
+    return (q.view(torch.float8_e4m3fn).float().reshape(r, c // 32, 32) * torch.exp2(s.float() - 127).unsqueeze(-1)).reshape(r, c).double()
+
+
+def check_mx8(lib, device, M, N, K, to, bias=False, act=0, residual=False, seed=0):
+    A = rnd((M, K), "cpu", torch.bfloat16, seed=seed + 1); W = rnd((N, K), "cpu", torch.bfloat16, seed=seed + 2, scale=0.05)
+    A[0, :32] = 0                                           # an all-zero block
+    A[1, 5] = 3000.0                                        # a block dominated by one outlier
+    out = {}
+    for name, x, dt in (("a", A, torch.bfloat16), ("w", W.float(), torch.float32)):       # both source types of the quantiser
+        xd = x.to(device)
+        q = torch.empty(x.shape, dtype=torch.uint8, device=device); sc = torch.empty(x.shape[0], K // 32, dtype=torch.uint8, device=device)
+        L.check(lib, lib.vcad_op_quant_mx8(TD[dt], ptr(xd), K, ptr(q), ptr(sc), x.shape[0], K, stream_of(device)), "quant_mx8")
+        qr, sr = mx8_quant_ref(x)
+        assert torch.equal(sc.cpu(), sr), (name, "scales differ")
+        assert torch.equal(q.cpu(), qr), (name, "e4m3 bytes differ", int((q.cpu() != qr).sum()))
+        out[name] = (q, sc)
+    bias_t = rnd((N,), device, seed=seed + 3) if bias else None
+    res_t = rnd((M, N), device, seed=seed + 4) if residual else None
+    Cbuf = torch.full((M, N), 7.0, dtype=to, device=device)
+    L.check(lib, lib.vcad_op_gemm_mx8(TD[to], ptr(out["a"][0]), ptr(out["a"][1]), ptr(out["w"][0]), ptr(out["w"][1]), ptr(Cbuf), M, N, K, N,
+                                      ptr(bias_t), act, ptr(res_t), N, stream_of(device)), "gemm_mx8")
+    ref = mx8_dequant(out["a"][0].cpu(), out["a"][1].cpu()) @ mx8_dequant(out["w"][0].cpu(), out["w"][1].cpu()).t()
+    exact = A.double() @ W.double().t()
+    if bias:
+        ref = ref + bias_t.double().cpu(); exact = exact + bias_t.double().cpu()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref); exact = torch.nn.functional.gelu(exact)
+    if residual:
+        ref = ref + res_t.double().cpu(); exact = exact + res_t.double().cpu()
+    err = relerr(Cbuf.float(), ref)
+    # fp32 out: the matrix core's own rounding of a 64-term block dot product (measured 1.5e-5 .. 6e-5 on gfx950; the emulator sums in fp32)
+    tol = 2e-4 if to == torch.float32 else 6e-3
+    assert err < tol, f"gemm_mx8 M{M} N{N} K{K} to={to}: rel err vs dequantised reference {err:.3e} > {tol}"
+    qerr = relerr(Cbuf.float(), exact)                       # what the 8-bit operands cost against the bf16 operands
+    assert qerr < 6e-2, qerr
+    return err, qerr

@@ -136,3 +136,11 @@ def test_attention_head_dim_128(emu, T, window, dt):
     """nhead = 8 at hidden 1024 (reference final_experiments.json / the *_large configs): head dim 128 = two 64-wide chunks in the
     matrix-core decoder kernels, DPL = 2 in the wave-per-row kernels"""
     U.check_attention(emu, "cpu", 1, 2, T, 128, window=window, causal=1, dt=dt)
+
+
+@pytest.mark.parametrize("to,bias,act,residual", [(F32, True, 0, True), (BF16, True, 1, False), (BF16, False, 0, False)])
+def test_gemm_mx8(emu, gemm_tile, to, bias, act, residual):
+    """MXFP8 quantiser (bit-exact against the OCP MX rule) + block-scaled fp8 GEMM (against its dequantised operands)"""
+    if gemm_tile != 128:
+        pytest.skip("tile-size fixture does not apply")
+    U.check_mx8(emu, "cpu", 200, 256, 384, to, bias=bias, act=act, residual=residual)

@@ -138,3 +138,11 @@ def test_attention_band(hip, window):
 def test_attention_head_dim_128(hip, T, window, dt):
     """nhead = 8 at hidden 1024 (reference final_experiments.json / *_large configs)"""
     U.check_attention(hip, DEV, 3, 8, T, 128, window=window, causal=1, dt=dt)
+
+
+@pytest.mark.parametrize("to,bias,act,residual", [(F32, True, 0, True), (BF16, True, 1, False), (BF16, False, 0, False)])
+def test_gemm_mx8(hip, to, bias, act, residual):
+    """VCAD_FP8 building blocks on the hardware: MXFP8 quantiser bit-exact against the OCP MX rule (incl. the non-saturating
+    v_cvt_pk_fp8_f32 behind a clamp), block-scaled fp8 MFMA GEMM against its dequantised operands; ragged M, several k-tiles"""
+    U.check_mx8(hip, DEV, 5000, 512, 1024, to, bias=bias, act=act, residual=residual)
+    U.check_mx8(hip, DEV, 300, 3072, 512, to, bias=bias, act=act, residual=residual, seed=5)

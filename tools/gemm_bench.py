@@ -81,6 +81,34 @@ def wide(name, *a, **k):
     lib.vcad_debug_gemm_dma(-1); lib.vcad_debug_gemm_wide(-1)
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "mx8":
+    def run8(name, M, N, K, to=BF, bias=False, res=False, iters=20):
+        A = torch.randn(M, K, device=dev).to(BF); W = (torch.randn(N, K, device=dev) * 0.05).to(BF)
+        qa = torch.empty(M, K, dtype=torch.uint8, device=dev); sa = torch.empty(M, K // 32, dtype=torch.uint8, device=dev)
+        qw = torch.empty(N, K, dtype=torch.uint8, device=dev); sw = torch.empty(N, K // 32, dtype=torch.uint8, device=dev)
+        Cm = torch.empty(M, N, dtype=to, device=dev)
+        bias_t = torch.randn(N, device=dev) if bias else None; res_t = torch.randn(M, N, device=dev) if res else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.vcad_op_quant_mx8(1, p(W), K, p(qw), p(sw), N, K, st) == 0
+        quant = lambda: lib.vcad_op_quant_mx8(1, p(A), K, p(qa), p(sa), M, K, st)
+        gemm = lambda: lib.vcad_op_gemm_mx8(TD[to], p(qa), p(sa), p(qw), p(sw), p(Cm), M, N, K, N, p(bias_t), 0, p(res_t), N, st)
+        for fn, what in ((quant, "quantise A"), (gemm, "gemm")):
+            for _ in range(3):
+                assert fn() == 0, lib.vcad_last_error()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            print(f"{name:28s} {what:10s} M={M:6d} N={N:5d} K={K:5d} {ms*1e3:8.1f} us" + (f"  {2.0*M*N*K/(ms*1e-3)/1e12:7.1f} TF/s" if what == "gemm" else f"  {M*K*3.03/(ms*1e-3)/1e9:7.1f} GB/s"), flush=True)
+    for rep in range(2):
+        run8("vit qkv fwd [mxfp8]", R, 3072, 512)
+        run8("vit out fwd +res f32 [mxfp8]", R, 512, 1024, to=F32, bias=True, res=True)
+        run8("vit mlp fwd [mxfp8]", R, 512, 512, bias=True)
+        run8("square 8192 [mxfp8]", 8192, 8192, 8192)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "epi2":
     # interleaved A/B (rule: perf deltas come from within-process interleaved rounds): per shape, 3 rounds of row / col
     lib.vcad_debug_gemm_dma(1)

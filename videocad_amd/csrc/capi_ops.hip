@@ -1,6 +1,7 @@
 // capi_ops.hip — single-op C entry points (include/vcad.h "vcad_op_*"): thin wrappers over the same launchers
 // the engine uses, so the parity tests exercise exactly the shipped kernels.
 #include "ops.h"
+#include "gemm_mx8.h"
 #include "../../include/vcad.h"
 #include <string.h>
 
@@ -15,6 +16,22 @@ int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A
     c.p.bias = bias; c.p.act = act; c.p.residual = residual; c.p.ldr = ldr; c.p.alpha = alpha; c.p.rowadd_div = 1;
     int rc = vc_gemm(c, scratch, scratch_bytes, (vc_stream_t)stream);
     if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_gemm: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
+
+int vcad_op_quant_mx8(int tx, const void* x, int64_t ldx, void* q, void* scales, int64_t rows, int cols, void* stream) {
+    int rc = vc_mx8_quant(tx, x, ldx, (uint8_t*)q, (uint8_t*)scales, rows, cols, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_quant_mx8: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
+int vcad_op_gemm_mx8(int to, const void* A8, const void* sa, const void* B8, const void* sb, void* C, int M, int N, int K, int64_t ldc,
+                     const float* bias, int act, const float* residual, int64_t ldr, void* stream) {
+    Mx8Params q; memset(&q, 0, sizeof(q));
+    q.g.A = A8; q.g.B = B8; q.g.C = C; q.g.M = M; q.g.N = N; q.g.K = K; q.g.lda = K; q.g.ldb = K; q.g.ldc = ldc; q.g.alpha = 1.0f;
+    q.g.bias = bias; q.g.act = act; q.g.residual = residual; q.g.ldr = ldr; q.g.rowadd_div = 1;
+    q.sa = (const uint8_t*)sa; q.ldsa = K / 32; q.sb = (const uint8_t*)sb; q.ldsb = K / 32;
+    int rc = vc_gemm_mx8(q, to, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_gemm_mx8: launch failed"); return VC_ERR_LAUNCH; }
     return rc;
 }
 

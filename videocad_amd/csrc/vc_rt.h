@@ -106,6 +106,21 @@ template <int N> VC_DEV void vc_hwait2(uint32_t& a, uint32_t& b) { asm volatile(
 // "this register's value is dead from here on": ends the live range of a loop-carried register (array element) at no cost — hipcc
 // cannot see that e.g. MFMA fragments are never read again once the next LOAD segment starts, and would keep them allocated
 template <typename T> VC_DEV void vc_undef(T& x) { asm volatile("" : "=v"(x)); }
+// D(32x32) += A(32x64) * B(64x32), OCP fp8 e4m3 operands with one E8M0 scale per (row, 32-k block) — the gfx950 block-scaled ("MX") MFMA,
+// twice the bf16 rate.  Layout probed on the hardware (tools/probe_mx8_layout.hip, profiles/r02_probe_mx8_layout.txt): lane l = (row l & 31,
+// half h = l >> 5) holds 32 bytes (8 VGPRs): bytes 0-15 = k 16h..16h+15 (scale block 0), bytes 16-31 = k 32+16h..32+16h+15 (scale block 1);
+// the scale of block b of row r is byte `opsel` of the scale dword of lane r + 32 b — i.e. a lane's scale covers 16 of its own k-values
+// and 16 of its partner lane's.  D as for bf16.
+typedef int vc_i32x8 __attribute__((ext_vector_type(8)));
+template <int OPA, int OPB>
+VC_DEV vc_f32x16 vc_mfma_mx8_32x32x64(vc_i32x8 a, vc_i32x8 b, vc_f32x16 c, int scale_a, int scale_b) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, OPA, scale_a, OPB, scale_b);
+}
+// two fp32 -> two OCP e4m3 bytes (RNE).  The instruction does NOT saturate (probed: |x| > 448 -> NaN), so clamp first.
+VC_DEV uint32_t vc_cvt_pk_e4m3(float a, float b) {
+    a = fminf(fmaxf(a, -448.0f), 448.0f); b = fminf(fmaxf(b, -448.0f), 448.0f);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xFFFFu;
+}
 // D(32x32) += A(32x2) * B(2x32), exact f32.  lane l: A[i=l&31][k=l>>5], B[k=l>>5][n=l&31]; D as above.
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -128,6 +143,7 @@ void mfma_32x32x16_bf16(const short* a8, const short* b8, float* c16);   // in-p
 void mfma_32x32x2_f32(float a, float b, float* c16);
 void ds_read_tr16(const void* p, short* out4);
 void dma16(const void* gsrc, void* lds_piece);
+void mfma_mx8_32x32x64(const int* a8, const int* b8, float* c16, int sa_byte, int sb_byte);
 void launch(void (*trampoline)(void*), void* args, dim3 grid, dim3 block, size_t shmem);
 }  // namespace vcemu
 using vcemu::dim3;
@@ -184,6 +200,11 @@ struct vc_s16x8 { short v[8]; short& operator[](int i) { return v[i]; } const sh
 VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) { vcemu::mfma_32x32x16_bf16(a.v, b.v, c.v); return c; }
 VC_DEV vc_f32x16 vc_mfma_32x32x2_f32(float a, float b, vc_f32x16 c) { vcemu::mfma_32x32x2_f32(a, b, c.v); return c; }
 struct vc_s16x4 { short v[4]; short& operator[](int i) { return v[i]; } const short& operator[](int i) const { return v[i]; } };
+struct vc_i32x8 { int v[8]; int& operator[](int i) { return v[i]; } const int& operator[](int i) const { return v[i]; } };
+template <int OPA, int OPB>
+VC_DEV vc_f32x16 vc_mfma_mx8_32x32x64(vc_i32x8 a, vc_i32x8 b, vc_f32x16 c, int scale_a, int scale_b) {
+    vcemu::mfma_mx8_32x32x64(a.v, b.v, c.v, (scale_a >> (8 * OPA)) & 0xFF, (scale_b >> (8 * OPB)) & 0xFF); return c;
+}
 VC_DEV vc_s16x4 vc_ds_read_tr16(const void* p) { vc_s16x4 r; vcemu::ds_read_tr16(p, r.v); return r; }
 VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) { vcemu::dma16(gsrc, lds_piece); }
 VC_DEV float vc_expf_fast(float x) { return expf(x); }
@@ -252,6 +273,34 @@ struct alignas(8) vc_u32x2 { uint32_t x, y; };
 VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
 VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+
+// ---- OCP fp8 e4m3 (no infinities, NaN = 0x7f / 0xff, max 448) — software codec for the emulator build and the host
+VC_HD float vc_e4m3_to_f32(uint8_t v) {
+    const int e = (v >> 3) & 15, m = v & 7;
+    float f = e ? ldexpf(1.0f + m * 0.125f, e - 7) : ldexpf(m * 0.125f, -6);
+    if (e == 15 && m == 7) f = NAN;
+    return (v & 0x80) ? -f : f;
+}
+VC_HD uint8_t vc_f32_to_e4m3_sw(float x) {           // round-to-nearest-even, saturating at +-448
+    const uint8_t s = x < 0.0f ? 0x80 : 0x00;
+    float a = fabsf(x);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0f) return s | 0x7e;
+    if (a < 0.0009765625f) return s;                                     // < half of the smallest subnormal (2^-9): rounds to zero (tie -> even = 0)
+    int e; const float fr = frexpf(a, &e);                               // a = fr * 2^e, fr in [0.5, 1)
+    int ex = e - 1; if (ex < -6) ex = -6;                                // exponent of the representable grid (subnormals share 2^-6)
+    const float q = ldexpf(a, 3 - ex);                                   // a in units of 2^(ex-3): [8, 16) for normals, [0, 8) for subnormals
+    float r = rintf(q);                                                  // RNE (default rounding mode)
+    int ri = (int)r;
+    if (ri == 16) { ri = 8; ++ex; }
+    (void)fr;
+    if (ex + 7 > 15 || (ex + 7 == 15 && ri - 8 > 6)) return s | 0x7e;
+    if (ri < 8) return s | (uint8_t)ri;                                  // subnormal (exponent field 0)
+    return s | (uint8_t)(((ex + 7) << 3) | (ri - 8));
+}
+#ifdef VC_EMU
+VC_DEV uint32_t vc_cvt_pk_e4m3(float a, float b) { return (uint32_t)vc_f32_to_e4m3_sw(a) | ((uint32_t)vc_f32_to_e4m3_sw(b) << 8); }
+#endif
 
 // ---- dropout: counter-based, stateless.  One 32-bit hash serves TWO consecutive elements (12-bit draws from bits 8..19 and
 // 20..31): keep-multiplier of element idx at a site = (draw(hash(key, idx >> 1), idx & 1) >= thr) ? scale : 0, so the backward

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "vcad_debug_gemm_stagger": (None, [_i]),
     "vcad_debug_gemm_skip": (None, [_i]),
     "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, _vp]),
+    "vcad_op_quant_mx8": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _vp]),
+    "vcad_op_gemm_mx8": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _i, _vp, _i64, _vp]),
     "vcad_op_layernorm_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
     "vcad_op_layernorm_bwd": (_i, [_i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "vcad_op_attention_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
