@@ -109,6 +109,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "mx8":
         run8("vit mlp fwd [mxfp8]", R, 512, 512, bias=True)
         run8("square 8192 [mxfp8]", 8192, 8192, 8192)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "abl":
+    # where does an item's time go?  full launch vs the same launch without its epilogue (debug bit 64: accumulators are dropped)
+    lib.vcad_debug_gemm_dma(1)
+    shapes = [("qkv fwd", (R, 3072, 512), {}), ("dqkv dgrad W^T", (R, 512, 3072), {}), ("dao dgrad W^T", (R, 1024, 512), {}), ("dh dgrad W^T", (R, 512, 512), {}),
+              ("patch embed f32", (101920, 512, 1024), dict(to=F32, bias=True)), ("out fwd +res f32", (R, 512, 1024), dict(to=F32, bias=True, res=True)),
+              ("mlp2 fwd +res f32", (R, 512, 512), dict(to=F32, bias=True, res=True)), ("qkv wgrad", (3072, 512, R), dict(to=F32, tra=1, trb=1)),
+              ("out wgrad", (512, 1024, R), dict(to=F32, tra=1, trb=1)), ("mlp wgrad", (512, 512, R), dict(to=F32, tra=1, trb=1)), ("square 8192", (8192, 8192, 8192), {})]
+    for name, dims, kw in shapes:
+        for rnd in range(2):
+            for sk in (0, 64):
+                lib.vcad_debug_gemm_skip(sk)
+                run(f"{name} [{'no epilogue' if sk else 'full'} #{rnd}]", *dims, **kw)
+    lib.vcad_debug_gemm_skip(0)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "epi2":
     # interleaved A/B (rule: perf deltas come from within-process interleaved rounds): per shape, 3 rounds of row / col
     lib.vcad_debug_gemm_dma(1)

@@ -78,6 +78,8 @@ static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal
 extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
 static int g_dma_wide = -1;     // 256 x 256 tile of the persistent kernel: -1 = automatic, 0 = never, 1 = whenever legal
 extern "C" void vcad_debug_gemm_wide(int mode) { g_dma_wide = mode; }
+static int g_policy = 0;        // A/B bits for the dispatcher's measured rules: 1 = GELU / GELU' epilogues may use the persistent kernel, 2 = wgrads with < 16 tiles may
+extern "C" void vcad_debug_gemm_policy(int bits) { g_policy = bits; }
 static int g_stagger = -1;      // -1 = automatic
 extern "C" void vcad_debug_gemm_stagger(int n) { g_stagger = n; }
 static int g_debug_skip = 0;
@@ -144,7 +146,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         // it loses where its one-workgroup-per-CU design has nothing to overlap a VALU-heavy epilogue with (GELU / GELU' — the
         // register-staged kernel's second co-resident workgroup hides that), on the long-K dgrad through ds_read_b64_tr_b16
         // (K >= 2048), and on wgrads with fewer than 16 output tiles (the k-slice slabs dominate).
-        const bool wins = tiles * best >= 200 && !p.act && !p.dact_src && !(lay == 1 && p.K >= 2048) && !(lay == 3 && tiles < 16);
+        const bool wins = tiles * best >= 200 && ((g_policy & 1) || (!p.act && !p.dact_src)) && !(lay == 1 && p.K >= 2048) && ((g_policy & 2) || !(lay == 3 && tiles < 16));
         // the wide tile halves the item count: with few, short items (N = 512, K = 512: 814 items of 8 k-tiles = 3.2 rounds) the last,
         // partly filled round costs more than the tile saves (measured: profiles/r02_gemm_wide_ab.txt) — long items amortise it
         const double fill = (double)(tiles * best) / (256.0 * VC_CEIL_DIV(tiles * best, 256));
