@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
 
+if os.environ.get("VCAD_ABL"):      # ablated build (tools/gemm_ablate.sh): timing only, results are garbage
+    L._lib = L.declare(C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", f"libvcad_abl{os.environ['VCAD_ABL']}.so")))
 lib = L.load()
 dev = "cuda:0"
 BF, F32 = torch.bfloat16, torch.float32
@@ -108,6 +110,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "mx8":
         run8("vit out fwd +res f32 [mxfp8]", R, 512, 1024, to=F32, bias=True, res=True)
         run8("vit mlp fwd [mxfp8]", R, 512, 512, bias=True)
         run8("square 8192 [mxfp8]", 8192, 8192, 8192)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "mainloop":
+    # main loop only (epilogue dropped): run under VCAD_ABL = 1 (no MFMA) / 2 (no fragment reads) / 4 (no DMA) / combinations
+    lib.vcad_debug_gemm_dma(1); lib.vcad_debug_gemm_skip(64)
+    tag = os.environ.get("VCAD_ABL", "0")
+    for rnd in range(2):
+        run(f"qkv fwd [abl {tag}]", R, 3072, 512)
+        run(f"dqkv dgrad W^T [abl {tag}]", R, 512, 3072)
+        run(f"qkv wgrad [abl {tag}]", 3072, 512, R, to=F32, tra=1, trb=1)
+        run(f"square 8192 [abl {tag}]", 8192, 8192, 8192)
     sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "abl":
     # where does an item's time go?  full launch vs the same launch without its epilogue (debug bit 64: accumulators are dropped)

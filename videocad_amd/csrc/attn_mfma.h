@@ -371,6 +371,251 @@ VC_DEV void attn_vit_bwd_mfma_body(const AttnParams& p) {
     }
 }
 
+// ---- r02: the same backward on FOUR waves per (frame, head): wave = (orientation, 32-column tile).
+// r01's two waves carried 2x2-tile grids (64 accumulator registers each, three live): 256 registers -> 2 waves per SIMD, and the
+// kernel ran at the pace of one wave's ~7 k-instruction dependency chain (22 us per workgroup, 3 TB/s).  Here every wave owns ONE
+// 32-wide column tile of its orientation (queries for dQ, keys for dV / dK): grids are 2 x 1 tiles, ~128 registers, 4 waves per
+// SIMD, half the work per wave — and the token-contraction products are issued with swapped operands (D^T), so a lane ends up with
+// a token ROW and 4 consecutive head-dim columns per accumulator quad: 8-byte row stores, 8 per output tile instead of 32 scalars.
+template <bool QCOL>
+VC_DEV uint32_t am_keep_bits1(const vc_drop& d, uint32_t base, int T, int tj, int lane) {
+    // bit ti*16 + r  <->  element (row = ti*32 + am_row(r), lane column = tj*32 + (lane&31)); rows = keys / column = query when QCOL,
+    // else rows = queries / column = key.  Same pairing of one hash per two consecutive keys as am_keep_bits_g.
+    uint32_t bits = 0;
+    const int col = tj * 32 + (lane & 31);
+    if ((T & 1) == 0) {
+#pragma unroll 1
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                uint32_t b0, b1;
+                if (QCOL) {
+                    const int key = ti * 32 + am_row(2 * j, lane);
+                    const uint32_t h = vc_drop_hash(d, (base + (uint32_t)(col * T + key)) >> 1);
+                    b0 = vc_drop_keep_lo(d, h) ? 1u : 0u; b1 = vc_drop_keep_hi(d, h) ? 1u : 0u;
+                } else {
+                    const int par = lane & 1;
+                    const int query = ti * 32 + am_row(2 * j + par, lane);
+                    const uint32_t mine = vc_drop_hash(d, (base + (uint32_t)(query * T + (col & ~1))) >> 1);
+                    const uint32_t other = (uint32_t)vc_shfl_xor((int)mine, 1);
+                    const uint32_t h0 = par ? other : mine, h1 = par ? mine : other;
+                    b0 = ((col & 1) ? vc_drop_keep_hi(d, h0) : vc_drop_keep_lo(d, h0)) ? 1u : 0u;
+                    b1 = ((col & 1) ? vc_drop_keep_hi(d, h1) : vc_drop_keep_lo(d, h1)) ? 1u : 0u;
+                }
+                bits |= (b0 | (b1 << 1)) << (ti * 16 + 2 * j);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int row = ti * 32 + am_row(r, lane);
+                const int query = QCOL ? col : row, key = QCOL ? row : col;
+                bits |= (vc_drop_keep(d, base + (uint32_t)(query * T + key)) ? 1u : 0u) << (ti * 16 + r);
+            }
+    }
+    return bits;
+}
+VC_DEV float am_keep1(uint32_t bits, int ti, int r, float scale) { return ((bits >> (ti * 16 + r)) & 1) ? scale : 0.0f; }
+VC_DEV vc_s16x8 am_pack_keep1(const vc_f32x16& a, int s, uint32_t keep, int ti, float scale) {
+    vc_s16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)vc_f32_to_bf16(a[8 * s + j] * (((keep >> (ti * 16 + 8 * s + j)) & 1) ? scale : 0.0f)).bits;
+    return r;
+}
+// acc[i] += X[rows i*32..][d] * Y[rows t*32..][d]^T   (registers = X rows, lane column = Y row of tile t)
+VC_DEV void am_mm_nt1(vc_f32x16 (&acc)[2], const vc_bf16* X, const vc_bf16* Y, int t, int lane) {
+#pragma unroll
+    for (int ks = 0; ks < AM_D / 16; ++ks) {
+        const vc_s16x8 b = am_frag(Y, t * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = vc_mfma_32x32x16_bf16(am_frag(X, i * 32, ks, lane), b, acc[i]);
+    }
+}
+// out[dt][d-row (registers)][token (lane)] += sum over the 64 contracted tokens (register rows of W[tt], tt = 0, 1) of W * Y[token][d]
+template <bool DROP>
+VC_DEV void am_mm_tok1(vc_f32x16 (&out)[2], const vc_f32x16 (&W)[2], const vc_bf16* Y, int lane, uint32_t keep, float scale) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const vc_s16x8 b = DROP ? am_pack_keep1(W[tt], s, keep, tt, scale) : am_pack(W[tt], s);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) out[dt] = vc_mfma_32x32x16_bf16(am_frag_tr(Y, tt * 32 + 16 * s, dt * 32, lane), b, out[dt]);
+        }
+}
+// rows t*32 .. t*32+31 (< T) of a [token][64] result whose registers walk the head dim (lane = token row, 4 consecutive columns per
+// accumulator quad): transposed through a wave-private 32 x AM_S staging tile (8-byte LDS writes), then written as whole 128-byte rows —
+// 16 bytes per lane, 8 full lines per store instruction.  (Storing the quads straight from the registers — 8 bytes per lane at 32
+// different rows — was measured first: 16x the write transactions, the forward got slower.)
+VC_DEV void am_store_rows(vc_bf16* stage, vc_bf16* g, long ld, const vc_f32x16 (&acc)[2], int t, int T, int lane, float mul) {
+    vc_bf16* w = stage + (lane & 31) * AM_S + 4 * (lane >> 5);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            vc_u32x2 q;
+            q.x = vc_pack_bf16x2(acc[dt][4 * gq] * mul, acc[dt][4 * gq + 1] * mul); q.y = vc_pack_bf16x2(acc[dt][4 * gq + 2] * mul, acc[dt][4 * gq + 3] * mul);
+            *reinterpret_cast<vc_u32x2*>(w + dt * 32 + 8 * gq) = q;
+        }
+    vc_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        const vc_u32x4 v = *reinterpret_cast<const vc_u32x4*>(stage + row * AM_S + c);
+        if (t * 32 + row < T) *reinterpret_cast<vc_u32x4*>(g + (long)(t * 32 + row) * ld + c) = v;
+    }
+    vc_wave_barrier();
+}
+VC_DEV void am_zero1(vc_f32x16 (&a)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[i][r] = 0.f;
+}
+
+template <bool DROP>
+VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO
+    VC_SHARED float lse_s[AM_T];
+    VC_SHARED float del_s[AM_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    am_stage_nt<256>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
+    am_stage_nt<256>(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
+    am_stage_nt<256>(tiles[2], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, tid);
+    am_stage_nt<256>(tiles[3], (const vc_bf16*)p.dout + rowq * p.lddo + h * AM_D, p.lddo, T, tid);
+    if (tid < AM_T) lse_s[tid] = (tid < T) ? p.lse[(n * p.H + h) * T + tid] : 0.f;
+    vc_sync();
+    const vc_bf16 *Qs = tiles[0], *Ks = tiles[1], *Vs = tiles[2], *dOs = tiles[3];
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    const int t = wave & 1;
+    if (wave < 2) {    // ---------------- lane = query of tile t:  D_i, dQ
+        uint32_t keep = 0;
+        if (DROP) keep = am_keep_bits1<true>(p.drop, dbase0, T, t, lane);
+        vc_f32x16 st[2], dpt[2];
+        am_zero1(st); am_zero1(dpt);
+        am_mm_nt1(st, Ks, Qs, t, lane);      // S^T[key][query]
+        am_mm_nt1(dpt, Vs, dOs, t, lane);    // dP^T[key][query]
+        const int query = t * 32 + (lane & 31);
+        const float lse = lse_s[query];
+        float dsum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + am_row(r, lane);
+                const bool ok = key < T && query < T;
+                const float pr = ok ? expf(st[kt][r] * p.scale - lse) : 0.f;
+                if (DROP) dpt[kt][r] *= am_keep1(keep, kt, r, p.drop.scale);
+                st[kt][r] = pr; dsum += pr * dpt[kt][r];
+            }
+        dsum += vc_shfl_xor(dsum, 32);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] = st[kt][r] * (dpt[kt][r] - dsum);      // dS^T (scale folded into the store)
+        if (lane < 32) del_s[query] = dsum;
+        vc_sync();                           // publish D_i to the key waves
+        vc_f32x16 dq[2];
+        am_zero1(dq);
+        am_mm_tok1<false>(dq, st, Ks, lane, 0u, 1.0f);          // dQ[query][d] = sum_key dS[query][key] K[key][d]
+        am_store_rows(tiles[2] + t * 32 * AM_S, (vc_bf16*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, t, T, lane, p.scale);   // (V is dead after the barrier)
+    } else {           // ---------------- lane = key of tile t:  dV, dK
+        uint32_t keep = 0;
+        if (DROP) keep = am_keep_bits1<false>(p.drop, dbase0, T, t, lane);
+        vc_f32x16 sn[2];
+        am_zero1(sn);
+        am_mm_nt1(sn, Qs, Ks, t, lane);      // S[query][key]
+        const int key = t * 32 + (lane & 31);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int query = qt * 32 + am_row(r, lane);
+                sn[qt][r] = (key < T && query < T) ? expf(sn[qt][r] * p.scale - lse_s[query]) : 0.f;       // P
+            }
+        vc_f32x16 dv[2];
+        am_zero1(dv);
+        am_mm_tok1<DROP>(dv, sn, dOs, lane, keep, p.drop.scale);         // dV[key][d] = sum_query P'[query][key] dO[query][d]
+        vc_f32x16 dp[2];
+        am_zero1(dp);
+        am_mm_nt1(dp, dOs, Vs, t, lane);     // dP'[query][key]
+        vc_sync();                           // D_i from the query waves; nobody reads V / dO any more: their tiles become the store staging
+        vc_bf16* stage = tiles[3] + t * 32 * AM_S;
+        am_store_rows(stage, (vc_bf16*)p.dv + rowq * p.lddv + h * AM_D, p.lddv, dv, t, T, lane, 1.0f);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int query = qt * 32 + am_row(r, lane);
+                const float ms = DROP ? am_keep1(keep, qt, r, p.drop.scale) : 1.0f;
+                dp[qt][r] = sn[qt][r] * (dp[qt][r] * ms - del_s[query]);                                    // dS
+            }
+        vc_f32x16 dk[2];
+        am_zero1(dk);
+        am_mm_tok1<false>(dk, dp, Qs, lane, 0u, 1.0f);          // dK[key][d] = sum_query dS[query][key] Q[query][d]
+        am_store_rows(stage, (vc_bf16*)p.dk + rowq * p.lddk + h * AM_D, p.lddk, dk, t, T, lane, p.scale);
+    }
+}
+VC_KERNEL __launch_bounds__(256, 4) void attn_vit_bwd4_kernel_eval(AttnParams p) { attn_vit_bwd4_body<false>(p); }
+VC_KERNEL __launch_bounds__(256, 4) void attn_vit_bwd4_kernel_drop(AttnParams p) { attn_vit_bwd4_body<true>(p); }
+
+// ---- r02 forward: TWO waves per (frame, head), one 32-query tile each (grids of 2 x 1 tiles: 4 waves per SIMD instead of 2), O = P V
+// issued with swapped operands so a lane owns a query row and stores 8-byte pieces of it (see the four-wave backward below).
+template <bool DROP>
+VC_KERNEL __launch_bounds__(128, 4) void attn_vit_fwd2_kernel(AttnParams p) {
+    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[2][AM_T * AM_S];      // Q then V, K
+    const int tid = threadIdx.x, lane = tid & 63, t = vc_uniform(tid >> 6);
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    am_stage_nt<128>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
+    am_stage_nt<128>(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
+    vc_sync();
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    uint32_t keep = 0;
+    if (DROP) keep = am_keep_bits1<true>(p.drop, dbase0, T, t, lane);
+    vc_f32x16 st[2];                          // S^T[key tile][query tile t], lane column = query
+    am_zero1(st);
+    am_mm_nt1(st, tiles[1], tiles[0], t, lane);
+    vc_sync();                                // both waves are done with Q: its tile now receives V (the load overlaps the softmax)
+    am_stage_nt<128>(tiles[0], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, tid);
+    {
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + am_row(r, lane);
+                const float sv = (key < T) ? st[kt][r] * p.scale : -INFINITY;
+                st[kt][r] = sv; m = fmaxf(m, sv);
+            }
+        m = fmaxf(m, vc_shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][r] - m); st[kt][r] = e; l += e; }
+        l += vc_shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int query = t * 32 + (lane & 31);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][r] *= DROP ? inv * am_keep1(keep, kt, r, p.drop.scale) : inv;
+        if (p.lse && lane < 32 && query < T) p.lse[(n * p.H + h) * T + query] = m + logf(l);
+    }
+    vc_sync();                                // V has landed
+    vc_f32x16 o[2];
+    am_zero1(o);
+    am_mm_tok1<false>(o, st, tiles[0], lane, 0u, 1.0f);        // O[query][d] = sum_key P[query][key] V[key][d]
+    am_store_rows(tiles[1] + t * 32 * AM_S, (vc_bf16*)p.o + rowq * p.ldo + h * AM_D, p.ldo, o, t, T, lane, 1.0f);       // (K is dead since the first barrier)
+}
+
 // eval / p = 0: capped at 256 registers -> 2 waves per SIMD.  Train mode (mask bits + masked packing) wants 332; capping it at 256
 // spills 38 registers to scratch but doubles the waves per SIMD, which wins (measured: 487 -> ~370 us per call; ATTN_BWD_DROP_WAVES=1
 // restores the uncapped build).

@@ -37,6 +37,11 @@ constexpr int GD_NS = 16;                                                       
 // the LDS (one stage in flight while the other is consumed); each wave owns 64 x 128 outputs (128 accumulator registers), which
 // leaves no room for the 128 side-input registers a fused residual / activation-derivative epilogue would need: plain epilogues
 // (bias, k-slice slabs) only — the QKV forward, every dgrad through W^T, the split-K weight gradients.
+// Ablation builds (tools/gemm_ablate.sh, never the product library): GD_ABLATE bit 1 = no MFMA (fragments still read), 2 = no fragment
+// reads (MFMA on stale registers), 4 = no operand DMA.  Results are garbage by construction; only the time is looked at.
+#ifndef GD_ABLATE
+#define GD_ABLATE 0
+#endif
 template <int BN> struct GdTile {
     static constexpr int STAGES = BN == 128 ? 3 : 2;
     static constexpr int NJ = BN / 64;                                          // 32-column accumulator tiles per wave (2 or 4)
@@ -231,6 +236,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         vc_bf16* st = lds + slot * STAGE_ELEMS;
         // the tile's bias values: issued AHEAD of the item's first stage, so the wait that retires that stage covers them
         if (use_bias && c.kt == 0 && wq == 0 && lane < BN / 4) vc_dma16(p.bias + c.tn * BN + lane * 4, bias_lds + (c.seq % 3) * BN);
+        if constexpr (GD_ABLATE & 4) return;
         gd_issue<NPA>(Ag + kt_abs * kstepA, offA, st, wq * NPA);
         gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS, wq * NPB);
     };
@@ -280,13 +286,20 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         for (int ks = 0; ks < GD_BK / 16; ++ks) {
             vc_s16x8 af[2], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * 64 + i * 32, ks, lane);
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) af[i][e] = (short)(lane + i); asm volatile("" : "+v"(af[i])); }
+                else af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * 64 + i * 32, ks, lane);
+            }
 #pragma unroll
-            for (int jn = 0; jn < NJ; ++jn) bf[jn] = gd_frag<TRB, BN>(b_tile, wn * HALF_N + jn * 32, ks, lane);
+            for (int jn = 0; jn < NJ; ++jn) {
+                if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) bf[jn][e] = (short)(lane + jn); asm volatile("" : "+v"(bf[jn])); }
+                else bf[jn] = gd_frag<TRB, BN>(b_tile, wn * HALF_N + jn * 32, ks, lane);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
+                    if constexpr (GD_ABLATE & 1) { asm volatile("" :: "v"(af[i]), "v"(bf[jn])); continue; }
                     if constexpr (COL) acc[i][jn] = vc_mfma_32x32x16_bf16(af[i], bf[jn], acc[i][jn]);      // D[m][n]: lane = column
                     else acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);                    // swapped, D[n][m]: lane = row
                 }

@@ -86,10 +86,17 @@ static int check_rows_aligned(int t, const AttnParams& p, bool bwd) {
     }
     return VC_OK;
 }
+static int g_vit_bwd_variant = 0;
+extern "C" void vcad_debug_attn_variant(int v) { g_vit_bwd_variant = v; }
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     if (int rc = check_rows_aligned(t, p, false)) return rc;
     ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), attn_bytes(p, D, t, false), s);
+    if (mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {      // two waves per (frame, head)
+        if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        else VC_LAUNCH((attn_vit_fwd2_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        return VC_OK;
+    }
     if (mfma_ok(t, D, p, false)) {
         if (p.drop.key) VC_LAUNCH((attn_vit_fwd_mfma_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         else VC_LAUNCH((attn_vit_fwd_mfma_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
@@ -119,7 +126,12 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         else VC_LAUNCH((attn_bwd_single_query_kernel<float, 1>), g, dim3(256), 0, s, p);
         return VC_OK;
     }
-    if (mfma_ok(t, D, p, true)) {
+    if (mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {       // four waves per (frame, head)
+        if (p.drop.key) VC_LAUNCH(attn_vit_bwd4_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);
+        else VC_LAUNCH(attn_vit_bwd4_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);
+        return VC_OK;
+    }
+    if (mfma_ok(t, D, p, true)) {                                  // r01's two-wave kernel, kept for the A/B (vcad_debug_attn_variant(1))
         if (p.drop.key) VC_LAUNCH(attn_vit_bwd_mfma_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH(attn_vit_bwd_mfma_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
