@@ -509,7 +509,7 @@ VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + am_row(r, lane);
                 const bool ok = key < T && query < T;
-                const float pr = ok ? expf(st[kt][r] * p.scale - lse) : 0.f;
+                const float pr = ok ? vc_expf_fast(st[kt][r] * p.scale - lse) : 0.f;
                 if (DROP) dpt[kt][r] *= am_keep1(keep, kt, r, p.drop.scale);
                 st[kt][r] = pr; dsum += pr * dpt[kt][r];
             }
@@ -536,7 +536,7 @@ VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int query = qt * 32 + am_row(r, lane);
-                sn[qt][r] = (key < T && query < T) ? expf(sn[qt][r] * p.scale - lse_s[query]) : 0.f;       // P
+                sn[qt][r] = (key < T && query < T) ? vc_expf_fast(sn[qt][r] * p.scale - lse_s[query]) : 0.f;       // P
             }
         vc_f32x16 dv[2];
         am_zero1(dv);
@@ -575,6 +575,16 @@ VC_KERNEL __launch_bounds__(128, 4) void attn_vit_fwd2_kernel(AttnParams p) {
     const long rowq = n * T;
     am_stage_nt<128>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
     am_stage_nt<128>(tiles[1], (const vc_bf16*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
+    // V is requested NOW (into registers) and parked in Q's tile once S is done: one memory round trip per workgroup instead of two
+    vc_u32x4 vreg[AM_T * 8 / 128];
+    {
+        const vc_bf16* gv = (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D;
+#pragma unroll
+        for (int it = 0; it < AM_T * 8 / 128; ++it) {
+            const int c = tid + 128 * it, row = c >> 3, col = (c & 7) * 8;
+            vreg[it] = *reinterpret_cast<const vc_u32x4*>(gv + (long)(row < T ? row : T - 1) * p.ldv + col);
+        }
+    }
     vc_sync();
     const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
     uint32_t keep = 0;
@@ -582,8 +592,14 @@ VC_KERNEL __launch_bounds__(128, 4) void attn_vit_fwd2_kernel(AttnParams p) {
     vc_f32x16 st[2];                          // S^T[key tile][query tile t], lane column = query
     am_zero1(st);
     am_mm_nt1(st, tiles[1], tiles[0], t, lane);
-    vc_sync();                                // both waves are done with Q: its tile now receives V (the load overlaps the softmax)
-    am_stage_nt<128>(tiles[0], (const vc_bf16*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, tid);
+    vc_sync();                                // both waves are done with Q: its tile now receives V
+#pragma unroll
+    for (int it = 0; it < AM_T * 8 / 128; ++it) {
+        const int c = tid + 128 * it, row = c >> 3, col = (c & 7) * 8;
+        vc_u32x4 w = vreg[it];
+        if (row >= T) { w.x = 0u; w.y = 0u; w.z = 0u; w.w = 0u; }
+        *reinterpret_cast<vc_u32x4*>(tiles[0] + row * AM_S + col) = w;
+    }
     {
         float m = -INFINITY;
 #pragma unroll
@@ -599,7 +615,7 @@ VC_KERNEL __launch_bounds__(128, 4) void attn_vit_fwd2_kernel(AttnParams p) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][r] - m); st[kt][r] = e; l += e; }
+            for (int r = 0; r < 16; ++r) { const float e = vc_expf_fast(st[kt][r] - m); st[kt][r] = e; l += e; }
         l += vc_shfl_xor(l, 32);
         const float inv = 1.0f / l;
         const int query = t * 32 + (lane & 31);
