@@ -100,6 +100,23 @@ def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
         emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1); emu.vcad_debug_gemm_xcd_cols(-1)
 
 
+@pytest.mark.parametrize("trb,to", [(0, BF16), (0, F32), (1, BF16), (1, F32)])
+def test_gemm_mid_kernel(emu, gemm_tile, trb, to):
+    """the six-stage DMA-ring kernel for mid-size problems (gemm_mid.h): ragged M tail, fewer k-tiles than stages / exactly / more,
+    fused bias + ReLU / residual epilogues, padded leading dimensions"""
+    if gemm_tile != 128:
+        pytest.skip("tile-size fixture does not apply to the DMA-ring kernel")
+    emu.vcad_debug_gemm_dma(0); emu.vcad_debug_gemm_mid(1)
+    n0 = emu.vcad_debug_gemm_mid_launches()
+    try:
+        for K in (64, 192, 384, 640):                 # 1, 3, 6 (= stages) and 10 k-tiles
+            U.check_gemm(emu, "cpu", 300, 256, K, BF16, sa=BF16, sb=BF16, to=to, trb=trb, pad=8, bias=True, act=(2 if to == BF16 else 0),
+                         residual=(to == F32), splitk=False)
+        assert emu.vcad_debug_gemm_mid_launches() == n0 + 4, "the GEMM did not take the DMA-ring kernel"
+    finally:
+        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_mid(-1)
+
+
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16)])
 def test_layernorm(emu, C_, dt):
     U.check_layernorm(emu, "cpu", 11, C_, dt)

@@ -78,6 +78,28 @@ def test_gemm_dma_kernel(hip):
     assert hip.vcad_debug_gemm_dma_launches() == n0 + 18
 
 
+def test_gemm_mid_kernel(hip):
+    """six-stage DMA-ring kernel (gemm_mid.h) at the decoder's shapes: forward (k-contiguous W) and dgrad (row-contiguous W) layouts, fused
+    epilogues, ragged M (B=16, T=186 -> 2976 rows), three times each (a mis-counted vmcnt shows up as sporadic wrong tiles); and the
+    automatic choice takes it for a 2048 x 1024 x 1024 Linear"""
+    n0 = hip.vcad_debug_gemm_mid_launches()
+    hip.vcad_debug_gemm_mid(1); hip.vcad_debug_gemm_dma(0)
+    try:
+        for rep in range(3):
+            U.check_gemm(hip, DEV, 2048, 1024, 1024, BF16, to=F32, bias=True, residual=True, seed=rep)
+            U.check_gemm(hip, DEV, 2976, 3072, 1024, BF16, to=BF16, bias=True, seed=rep)
+            U.check_gemm(hip, DEV, 2976, 1024, 1024, BF16, to=BF16, bias=True, act=2, seed=rep)
+            U.check_gemm(hip, DEV, 2048, 1024, 3072, BF16, to=F32, trb=1, residual=True, seed=rep)
+            U.check_gemm(hip, DEV, 2976, 1024, 2048, BF16, to=BF16, trb=1, seed=rep)
+        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8)
+        U.check_gemm(hip, DEV, 300, 256, 64, BF16, to=BF16, trb=1, pad=8)
+    finally:
+        hip.vcad_debug_gemm_mid(-1); hip.vcad_debug_gemm_dma(-1)
+    assert hip.vcad_debug_gemm_mid_launches() == n0 + 17, "a GEMM did not take the DMA-ring kernel"
+    U.check_gemm(hip, DEV, 2048, 1024, 1024, BF16, to=F32, bias=True, residual=True)
+    assert hip.vcad_debug_gemm_mid_launches() == n0 + 18
+
+
 def test_gemm_dma_kernel_wide_tile(hip):
     """256 x 256 tile (automatic for the plain big GEMMs): QKV-forward-, dgrad-through-W^T- and wgrad-like problems, three times each
     (a mis-counted vmcnt of the two-stage ring shows up as sporadic wrong tiles), ragged M tail, short last k-slice"""

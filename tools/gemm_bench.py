@@ -111,6 +111,20 @@ if len(sys.argv) > 1 and sys.argv[1] == "mx8":
         run8("vit mlp fwd [mxfp8]", R, 512, 512, bias=True)
         run8("square 8192 [mxfp8]", 8192, 8192, 8192)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "mid":
+    # decoder-size problems: register-staged kernel vs the six-stage DMA-ring kernel (gemm_mid.h), interleaved
+    shapes = [("dec out fwd +res f32", (2048, 1024, 1024), dict(to=F32, bias=True, res=True)), ("dec q-proj fwd bf16", (2048, 1024, 1024), dict(bias=True)),
+              ("dec kv-proj fwd", (2048, 2048, 1024), dict(bias=True)), ("dec in_proj fwd", (2048, 3072, 1024), dict(bias=True)),
+              ("dec dgrad W f32+res", (2048, 1024, 1024), dict(to=F32, trb=1, res=True)), ("dec dgrad W bf16", (2048, 1024, 1024), dict(trb=1)),
+              ("dec dkv dgrad", (2048, 1024, 2048), dict(to=F32, trb=1, res=True)), ("dec dqkv dgrad", (2048, 1024, 3072), dict(to=F32, trb=1, res=True)),
+              ("C4 out fwd +res", (2976, 1024, 1024), dict(to=F32, bias=True, res=True)), ("cad vit qkv", (1600, 3072, 512), {}), ("cad vit out +res", (1600, 512, 1024), dict(to=F32, bias=True, res=True))]
+    for name, dims, kw in shapes:
+        for rnd in range(2):
+            for m in (0, 1):
+                lib.vcad_debug_gemm_mid(m)
+                run(f"{name} [{'ring' if m else 'reg'} #{rnd}]", *dims, iters=50, **kw)
+    lib.vcad_debug_gemm_mid(-1)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "mainloop":
     # main loop only (epilogue dropped): run under VCAD_ABL = 1 (no MFMA) / 2 (no fragment reads) / 4 (no DMA) / combinations
     lib.vcad_debug_gemm_dma(1); lib.vcad_debug_gemm_skip(64)

@@ -198,6 +198,7 @@ def run(args):
     eng.lib.vcad_debug_gemm_wide(getattr(args, "gemm_wide", -1))
     eng.lib.vcad_debug_gemm_policy(getattr(args, "gemm_policy", 0))
     eng.lib.vcad_debug_attn_variant(getattr(args, "attn_variant", 0))
+    eng.lib.vcad_debug_gemm_mid(getattr(args, "gemm_mid", -1))
     bd = synthetic_batch(B, T, 1000 * 2 + rank, device, uint8=args.uint8_frames)
     # logit parity of this build against the committed fp32 goldens — BEFORE any optimiser step (the goldens are for the hash-init weights)
     parity = logit_parity(model, device) if (rank == 0 and not getattr(args, "no_parity", False)) else None

@@ -35,6 +35,8 @@ bool vc_profile_on();       // the HIP-event profiler is recording: per-kernel t
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s);
 int vc_gemm_prepare(GemmCall& c);                                   // validation + per-problem legality flags (ops_gemm.hip)
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s);   // persistent DMA-fed kernel (ops_gemm_dma.hip), tile 256 x BN; c already prepared
+int vc_gemm_mid_launch(GemmCall c, vc_stream_t s);          // gemm_mid.h (ops_gemm_mid.hip)
+int vc_gemm_mid_tile_m(int trb); int vc_gemm_mid_tile_n(int trb);
 // grouped launch of many same-signature problems in one grid (see ops_gemm.hip)
 int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start);
 int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s);

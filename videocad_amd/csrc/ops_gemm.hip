@@ -78,6 +78,8 @@ static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal
 extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
 static int g_dma_wide = -1;     // 256 x 256 tile of the persistent kernel: -1 = automatic, 0 = never, 1 = whenever legal
 extern "C" void vcad_debug_gemm_wide(int mode) { g_dma_wide = mode; }
+static int g_mid_mode = -1;     // six-stage DMA-ring kernel for mid-size problems (gemm_mid.h): -1 = automatic, 0 = never, 1 = whenever legal
+extern "C" void vcad_debug_gemm_mid(int mode) { g_mid_mode = mode; }
 static int g_policy = 0;        // A/B bits for the dispatcher's measured rules: 1 = GELU / GELU' epilogues may use the persistent kernel, 2 = wgrads with < 16 tiles may
 extern "C" void vcad_debug_gemm_policy(int bits) { g_policy = bits; }
 static int g_stagger = -1;      // -1 = automatic
@@ -156,6 +158,15 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
             p.partial = best > 1 ? scratch : nullptr;
             return vc_gemm_dma_launch(c, best, BN, s);
         }
+    }
+    // ---- mid-size problems with bf16 operands (the decoder's and the CAD ViT's Linears: a few hundred tiles, operands cold in this XCD's
+    // L2): one tile per workgroup behind a six-stage DMA ring (gemm_mid.h)
+    if (c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && !c.tra && g_mid_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
+        p.K % 64 == 0 && p.N % vc_gemm_mid_tile_n(c.trb) == 0 && (double)p.lda * p.M * 2 < 2.0e9 && (double)p.ldb * (c.trb ? p.K : p.N) * 2 < 2.0e9) {
+        const long mt = (long)VC_CEIL_DIV(p.M, vc_gemm_mid_tile_m(c.trb)) * (p.N / vc_gemm_mid_tile_n(c.trb));
+        // automatic for the k-contiguous-B (forward) layout only: in-model A/B at C2 (profiles/r02_gemm_mid_ab.txt) forward -0.35 ms per step,
+        // but the row-contiguous-B variant (decoder dgrads through W, 64 x 128 tile) +0.26 ms against the register-staged kernel
+        if (g_mid_mode == 1 || (!c.trb && mt >= 96 && mt <= 1024 && p.K >= 256)) return vc_gemm_mid_launch(c, s);
     }
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
     // tile size: 128x128 by default; 64x64 when that grid would leave most of the 256 CUs idle (the decoder's
