@@ -140,6 +140,9 @@ int vcad_infer_step(vcad_engine* e, int t, const void* frame, int64_t frame_bstr
  * optimiser, other) elapsed ms, algorithmic FLOPs, algorithmic bytes, launches — measured on the launch stream. */
 void vcad_profile_begin(void);
 int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launches[8]);
+/* totals of the last vcad_profile_end for one kernel family: 1 = persistent DMA-fed GEMM (gemm_dma_kernel), 2 = register-staged GEMM,
+ * 3 = six-stage ring GEMM, 4 = grouped GEMM; out = {ms, flops, bytes, launches} */
+int vcad_profile_kernel(int family, double out[4]);
 
 /* ---- test / ablation hooks.  These (and the profiler switch above) are the ONLY process-global state of the library; they
  * select between kernels that compute the same result and are never touched by the product path (videocad_amd/*.py).

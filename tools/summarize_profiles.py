@@ -62,6 +62,13 @@ if pmc:
         print(f"| `{k}` | {rd[k]:.2f} | {wr[k]:.2f} | {t:.3f} | {((rd[k] + wr[k]) / t if t else 0):.2f} |")
     g_rd = sum(v for k, v in rd.items() if k.startswith(("gemm_kernel", "gemm_dma_kernel"))); g_wr = sum(v for k, v in wr.items() if k.startswith(("gemm_kernel", "gemm_dma_kernel")))
     g_n = sum(int(r["Calls"]) for r in ours if short(r["Name"]).startswith(("gemm_kernel", "gemm_dma_kernel"))) / steps_traced
-    json.dump({"tag": tag, "gemm_read_GB_per_step": g_rd, "gemm_write_GB_per_step": g_wr, "gemm_launches_per_step": g_n,
+    d_rd = sum(v for k, v in rd.items() if k.startswith("gemm_dma_kernel")); d_wr = sum(v for k, v in wr.items() if k.startswith("gemm_dma_kernel"))
+    d_n = sum(int(r["Calls"]) for r in ours if short(r["Name"]).startswith("gemm_dma_kernel")) / steps_traced
+    d_ms = sum(float(r["TotalDurationNs"]) for r in ours if short(r["Name"]).startswith("gemm_dma_kernel")) / steps_traced / 1e6
+    print(f"\ndominant kernel family `gemm_dma_kernel`: {d_n:.0f} launches / step, {d_ms:.3f} ms / step, average {d_ms * 1e3 / max(d_n, 1):.1f} us per launch, "
+          f"{(d_rd + d_wr) * 1e3 / max(d_n, 1):.0f} MB of HBM-side traffic per launch")
+    json.dump({"tag": tag, "dominant_kernel": "gemm_dma_kernel", "dominant_launches_per_step": d_n, "dominant_ms_per_step": d_ms,
+               "dominant_avg_launch_us": d_ms * 1e3 / max(d_n, 1), "dominant_hbm_bytes_per_launch": (d_rd + d_wr) * 1e9 / max(d_n, 1),
+               "gemm_read_GB_per_step": g_rd, "gemm_write_GB_per_step": g_wr, "gemm_launches_per_step": g_n,
                "gemm_hbm_bytes_per_launch": (g_rd + g_wr) * 1e9 / max(g_n, 1), "total_read_GB_per_step": sum(rd.values()),
                "total_write_GB_per_step": sum(wr.values())}, open(os.path.join(base, "pmc.json"), "w"), indent=1)

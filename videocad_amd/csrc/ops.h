@@ -17,9 +17,11 @@ void vc_set_error(const char* fmt, ...);
 // elapsed time, algorithmic FLOPs and algorithmic bytes per category.
 enum { VC_CAT_GEMM_FWD = 0, VC_CAT_GEMM_DGRAD = 1, VC_CAT_GEMM_WGRAD = 2, VC_CAT_ATTN = 3, VC_CAT_NORM = 4, VC_CAT_LOSS = 5,
        VC_CAT_OPTIM = 6, VC_CAT_OTHER = 7, VC_NCAT = 8 };
+// kernel family of a scope (vcad_profile_kernel): the bench's roofline is quoted on the dominant one, the persistent DMA-fed GEMM
+enum { VC_TAG_NONE = 0, VC_TAG_GEMM_DMA = 1, VC_TAG_GEMM_REG = 2, VC_TAG_GEMM_MID = 3, VC_TAG_GEMM_GROUPED = 4, VC_NTAG = 5 };
 struct ProfScope {
     void* rec;
-    ProfScope(int cat, double flops, double bytes, vc_stream_t s);
+    ProfScope(int cat, double flops, double bytes, vc_stream_t s, int tag = VC_TAG_NONE);
     ~ProfScope();
 };
 const char* vc_get_error();

@@ -12,10 +12,11 @@ const char* vc_get_error() { return g_err; }
 // ---------------------------------------------------------------------------------------------- profiler
 #ifndef VC_EMU
 #include <vector>
-namespace { struct PRec { hipEvent_t a, b; hipStream_t s; int cat; double flops, bytes; }; bool g_on = false; std::vector<PRec*> g_recs; }
-ProfScope::ProfScope(int cat, double flops, double bytes, vc_stream_t s) : rec(nullptr) {
+namespace { struct PRec { hipEvent_t a, b; hipStream_t s; int cat, tag; double flops, bytes; }; bool g_on = false; std::vector<PRec*> g_recs;
+            double g_tag_ms[VC_NTAG], g_tag_flops[VC_NTAG], g_tag_bytes[VC_NTAG]; int g_tag_n[VC_NTAG]; }
+ProfScope::ProfScope(int cat, double flops, double bytes, vc_stream_t s, int tag) : rec(nullptr) {
     if (!g_on) return;
-    PRec* r = new PRec(); r->cat = cat; r->flops = flops; r->bytes = bytes; r->s = s;
+    PRec* r = new PRec(); r->cat = cat; r->tag = tag; r->flops = flops; r->bytes = bytes; r->s = s;
     (void)hipEventCreate(&r->a); (void)hipEventCreate(&r->b); (void)hipEventRecord(r->a, s);
     rec = r;
 }
@@ -26,17 +27,26 @@ bool vc_profile_on() { return g_on; }
 extern "C" int vcad_profile_end(double* ms, double* flops, double* bytes, int* launches) {
     g_on = false;
     for (int i = 0; i < VC_NCAT; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < VC_NTAG; ++i) { g_tag_ms[i] = 0; g_tag_flops[i] = 0; g_tag_bytes[i] = 0; g_tag_n[i] = 0; }
     for (PRec* r : g_recs) {
         (void)hipEventSynchronize(r->b);
         float t = 0.f; (void)hipEventElapsedTime(&t, r->a, r->b);
         ms[r->cat] += t; flops[r->cat] += r->flops; bytes[r->cat] += r->bytes; launches[r->cat]++;
+        g_tag_ms[r->tag] += t; g_tag_flops[r->tag] += r->flops; g_tag_bytes[r->tag] += r->bytes; g_tag_n[r->tag]++;
         (void)hipEventDestroy(r->a); (void)hipEventDestroy(r->b); delete r;
     }
     g_recs.clear();
     return 0;
 }
+// totals of the last vcad_profile_end for one kernel family (VC_TAG_*): out = {ms, flops, bytes, launches}
+extern "C" int vcad_profile_kernel(int tag, double* out) {
+    if (tag < 0 || tag >= VC_NTAG) return VC_ERR_ARG;
+    out[0] = g_tag_ms[tag]; out[1] = g_tag_flops[tag]; out[2] = g_tag_bytes[tag]; out[3] = g_tag_n[tag];
+    return 0;
+}
 #else
-ProfScope::ProfScope(int, double, double, vc_stream_t) : rec(nullptr) {}
+extern "C" int vcad_profile_kernel(int, double* out) { out[0] = out[1] = out[2] = out[3] = 0; return 0; }
+ProfScope::ProfScope(int, double, double, vc_stream_t, int) : rec(nullptr) {}
 ProfScope::~ProfScope() {}
 extern "C" void vcad_profile_begin(void) {}
 bool vc_profile_on() { return false; }
@@ -58,7 +68,7 @@ static int gemm_launch_wt(GemmCall c, int nsplit, vc_stream_t s) {
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
-                 (double)c.p.M * c.p.K * sizeof(SA) + (double)c.p.N * c.p.K * sizeof(SB) + (double)c.p.M * c.p.N * sizeof(TO), s);
+                 (double)c.p.M * c.p.K * sizeof(SA) + (double)c.p.N * c.p.K * sizeof(SB) + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_REG);
     dim3 grid(VC_CEIL_DIV(c.p.N, GEMM_BN), VC_CEIL_DIV(c.p.M, GEMM_BM), nsplit);
     VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>), grid, dim3(GEMM_THREADS), lds, s, c.p);
     if (nsplit > 1) {

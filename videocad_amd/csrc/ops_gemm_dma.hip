@@ -25,7 +25,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
-                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s);
+                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_DMA);
     const int tiles_n = c.p.N / BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
     ++g_dma_launches;
     const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)

@@ -32,7 +32,7 @@ static int grouped_launch(const GemmCall& sig, GemmGroup grp, int total_tiles, d
         attr_set = true;
     }
 #endif
-    ProfScope ps(sig.role ? sig.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), flops, 0.0, s);
+    ProfScope ps(sig.role ? sig.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), flops, 0.0, s, VC_TAG_GEMM_GROUPED);
     VC_LAUNCH((gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>), dim3((unsigned)total_tiles), dim3(GEMM_THREADS), lds, s, grp);
     return VC_OK;
 }

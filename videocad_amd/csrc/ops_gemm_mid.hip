@@ -17,7 +17,7 @@ static int gemm_launch_mid(GemmCall c, vc_stream_t s) {
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD), 2.0 * c.p.M * c.p.N * c.p.K,
-                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s);
+                 (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_MID);
     ++g_mid_launches;
     const int tiles = VC_CEIL_DIV(c.p.M, BM) * (c.p.N / BN);
     VC_LAUNCH((gemm_mid_kernel<TO, TRB, BM, BN>), dim3(tiles), dim3(GM_THREADS), TL::LDS_BYTES, s, c.p);

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "vcad_infer_begin_u8": (_i, [_vp, _vp, _i, _i, _vp]),
     "vcad_infer_step": (_i, [_vp, _i, _vp, _i64, _vp, _vp, _vp, _vp]),
     "vcad_profile_begin": (None, []),
+    "vcad_profile_kernel": (_i, [_i, C.POINTER(C.c_double * 4)]),
     "vcad_profile_end": (_i, [C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_int * 8)]),
     "vcad_debug_force_gemm_tile": (None, [_i]),
     "vcad_debug_gemm_dma": (None, [_i]),
