@@ -80,12 +80,14 @@ def test_gemm_dma_kernel(emu, gemm_tile, tra, trb, to):
         emu.vcad_debug_gemm_dma(-1)
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("tra,trb,to", [(0, 0, BF16), (0, 0, F32), (1, 1, F32)])
-def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
-    """the 256 x 256 tile of the persistent kernel (two 64 KiB stages, 64 x 128 per wave): plain epilogues — bias, k-slice slabs"""
+def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to, waves):
+    """the 256 x 256 tile of the persistent kernel (two 64 KiB stages): eight waves of 64 x 128 or four waves of 128 x 128; plain
+    epilogues — bias, k-slice slabs"""
     if gemm_tile != 128:
         pytest.skip("tile-size fixture does not apply to the DMA kernel")
-    emu.vcad_debug_gemm_dma(1); emu.vcad_debug_gemm_wide(1)
+    emu.vcad_debug_gemm_dma(1); emu.vcad_debug_gemm_wide(1); emu.vcad_debug_gemm_waves(waves)
     n0 = emu.vcad_debug_gemm_dma_launches()
     try:
         M = 520 if tra else 600                       # three rows of items, ragged last one
@@ -97,7 +99,7 @@ def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
                 emu.vcad_debug_gemm_xcd_cols(xn if xn > 1 else -1)
                 U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, splitk=False)
     finally:
-        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1); emu.vcad_debug_gemm_xcd_cols(-1)
+        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1); emu.vcad_debug_gemm_xcd_cols(-1); emu.vcad_debug_gemm_waves(8)
 
 
 @pytest.mark.parametrize("trb,to", [(0, BF16), (0, F32), (1, BF16), (1, F32)])

@@ -100,11 +100,12 @@ def test_gemm_mid_kernel(hip):
     assert hip.vcad_debug_gemm_mid_launches() == n0 + 18
 
 
-def test_gemm_dma_kernel_wide_tile(hip):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_gemm_dma_kernel_wide_tile(hip, waves):
     """256 x 256 tile (automatic for the plain big GEMMs): QKV-forward-, dgrad-through-W^T- and wgrad-like problems, three times each
     (a mis-counted vmcnt of the two-stage ring shows up as sporadic wrong tiles), ragged M tail, short last k-slice"""
     n0 = hip.vcad_debug_gemm_dma_launches()
-    hip.vcad_debug_gemm_dma(1); hip.vcad_debug_gemm_wide(1)
+    hip.vcad_debug_gemm_dma(1); hip.vcad_debug_gemm_wide(1); hip.vcad_debug_gemm_waves(waves)
     try:
         for rep in range(3):
             U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=rep)
@@ -121,7 +122,7 @@ def test_gemm_dma_kernel_wide_tile(hip):
             U.check_gemm(hip, DEV, 20040, 1024, 512, BF16, to=F32, bias=True, residual=True, seed=xn)
             hip.vcad_debug_gemm_wide(1)
     finally:
-        hip.vcad_debug_gemm_dma(-1); hip.vcad_debug_gemm_wide(-1); hip.vcad_debug_gemm_xcd_cols(-1)
+        hip.vcad_debug_gemm_dma(-1); hip.vcad_debug_gemm_wide(-1); hip.vcad_debug_gemm_xcd_cols(-1); hip.vcad_debug_gemm_waves(8)
     assert hip.vcad_debug_gemm_dma_launches() == n0 + 25, "a GEMM did not take the DMA kernel"
 
 

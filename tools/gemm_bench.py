@@ -111,6 +111,21 @@ if len(sys.argv) > 1 and sys.argv[1] == "mx8":
         run8("vit mlp fwd [mxfp8]", R, 512, 512, bias=True)
         run8("square 8192 [mxfp8]", 8192, 8192, 8192)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "waves":
+    # 256-wide tile of the persistent kernel: eight waves (64 x 128 each) vs four waves (128 x 128 each), interleaved; with and without epilogue
+    lib.vcad_debug_gemm_dma(1)
+    shapes = [("qkv fwd", (R, 3072, 512), {}), ("dqkv dgrad W^T", (R, 512, 3072), {}), ("dao dgrad W^T", (R, 1024, 512), {}), ("dh dgrad W^T", (R, 512, 512), {}),
+              ("patch embed f32", (101920, 512, 1024), dict(to=F32, bias=True)), ("qkv wgrad", (3072, 512, R), dict(to=F32, tra=1, trb=1)),
+              ("out wgrad", (512, 1024, R), dict(to=F32, tra=1, trb=1)), ("square 8192", (8192, 8192, 8192), {})]
+    for name, dims, kw in shapes:
+        for sk in (0, 64):
+            lib.vcad_debug_gemm_skip(sk)
+            for rnd in range(2):
+                for w in (8, 4):
+                    lib.vcad_debug_gemm_waves(w)
+                    run(f"{name} [{'no epi' if sk else 'full'} {w} waves #{rnd}]", *dims, **kw)
+    lib.vcad_debug_gemm_skip(0); lib.vcad_debug_gemm_waves(8)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "mid":
     # decoder-size problems: register-staged kernel vs the six-stage DMA-ring kernel (gemm_mid.h), interleaved
     shapes = [("dec out fwd +res f32", (2048, 1024, 1024), dict(to=F32, bias=True, res=True)), ("dec q-proj fwd bf16", (2048, 1024, 1024), dict(bias=True)),

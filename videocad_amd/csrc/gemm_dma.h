@@ -162,17 +162,24 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
     quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
 }
 
-template <typename TO, bool TRA, bool TRB, int BN, bool COLW>
-VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn) {
+// NW = 4 (256-wide tile only): FOUR waves, one per SIMD, 128 x 128 outputs each (256 accumulator registers).  With eight waves the LDS
+// port is the co-limiter of the main loop — per k-tile 192 KiB of fragment reads + 64 KiB of DMA writes against 2 048 MFMA cycles at
+// 128 B/clk (ablations: profiles/r02_gemm_mainloop_ablation.txt); a 128 x 128 register tile needs 8 fragments per 16 MFMAs instead of 6
+// per 8 (128 KiB of reads per k-tile), and a wave hides its own fragment latency behind 16 back-to-back MFMAs.  All four waves issue
+// their quarter of every stage (no second wave on the SIMD to take turns with).
+template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
+VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn) {
     using TL = GdTile<BN>;
+    static_assert(NW == 8 || (NW == 4 && BN == 256), "four-wave form: 256-wide tile only");
     constexpr int NJ = TL::NJ, STAGES = TL::STAGES, STAGE_ELEMS = TL::STAGE_ELEMS, PIECES_B = TL::PIECES_B, HALF_N = BN / 2;
+    constexpr int MI = NW == 8 ? 2 : 4, WR = MI * 32;                           // 32-row accumulator tiles / rows per wave
     // COL: column-per-lane accumulators (MFMA issued A x B; a lane owns NJ ADJACENT output columns of 16 rows).  r01's epilogue was
     // row-per-lane (swapped MFMA): every store / side-load instruction touched 32-64 different cache lines with 8-16 bytes each and
     // ran at ~7 B/clk per CU — a third of the QKV forward.  Here an instruction covers 2 rows x 32 lanes x NJ adjacent columns
     // (128-512 contiguous bytes per row).  Needs the B rows permuted on their way into LDS (gd_offsets<PERM>), which the DMA's
     // per-lane source address gives for free for a k-contiguous B; the tr-read B layouts (wgrad, dgrad through W) keep the r01 form.
     constexpr bool COL = !TRB && COLW;
-    constexpr int NS_ITEM = COL ? 32 : TL::NS;                                  // epilogue stores per wave per interior item
+    constexpr int NS_ITEM = (COL ? 32 : TL::NS) * (MI / 2);                      // epilogue stores per wave per interior item
     VC_DYN_SHARED(vc_bf16, lds);
     float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + TL::RING_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
@@ -210,7 +217,8 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     // the group whose turn it is stalls ~0.3 us in the address path while the other group is already on the matrix cores,
     // then runs its own MFMAs while the first group waits at the next barrier — issue time no longer adds to MFMA time.
     constexpr int NPA = GD_PIECES_A / 4, NPB = PIECES_B / 4;
-    const int grp = wave >> 2, wq = wave & 3;
+    const int grp = NW == 8 ? wave >> 2 : 0, wq = wave & 3;
+    auto my_turn = [&](int tn) { return NW == 4 || grp == tn; };
     // bytes one k-tile advances the (wave-uniform) operand base
     const long kstepA = TRA ? (long)GD_BK * p.lda * 2 : (long)GD_BK * 2, kstepB = TRB ? (long)GD_BK * p.ldb * 2 : (long)GD_BK * 2;
 
@@ -245,9 +253,9 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     if (first < last) { locate(pf); retarget(pf); }
     GdCursor cp = pf;
     int turn = 0;                                                // parity of the stage being consumed == the group that issued it
-    for (int s0 = 0; s0 < STAGES - 1 && pf.item < last; ++s0) { if (grp == (s0 & 1)) issue(pf, s0); if (advance(pf) && pf.item < last) retarget(pf); }
+    for (int s0 = 0; s0 < STAGES - 1 && pf.item < last; ++s0) { if (my_turn(s0 & 1)) issue(pf, s0); if (advance(pf) && pf.item < last) retarget(pf); }
 
-    vc_f32x16 acc[2][NJ];
+    vc_f32x16 acc[MI][NJ];
     int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
     const int dbg = p.debug_skip;
 
@@ -263,7 +271,9 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         // and nothing younger of its own is in flight yet — the stage after next is issued below, after the barrier)
         // (3 stages: the stage was issued two k-tiles ago, after that k-tile's barrier and before its epilogue — the stores of the
         // last two epilogues are younger; 2 stages: issued one k-tile ago — only the last epilogue's stores are)
-        if (grp == turn) gd_wait_le<TL::PW, NS_ITEM>(STAGES == 3 ? young_prev + young_cur : young_cur);
+        if constexpr (NW == 4) {                                 // every wave issued a quarter of the stage one k-tile ago; only the last epilogue's stores are younger
+            if (young_cur) vc_wait_vmcnt<(NS_ITEM > 63 ? 63 : NS_ITEM)>(); else vc_wait_vmcnt<0>();     // (6-bit counter: 63 rounds DOWN, which is safe)
+        } else if (grp == turn) gd_wait_le<TL::PW, NS_ITEM>(STAGES == 3 ? young_prev + young_cur : young_cur);
         young_prev = young_cur; young_cur = 0;
         vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
     };
@@ -274,7 +284,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
     auto ktile_prefetch = [&]() {
         if (pf.item < last) {
             // stage s is issued by group s & 1: during k-tile t (turn = t & 1) that is stage t + STAGES - 1
-            if (grp == (STAGES == 3 ? turn : turn ^ 1)) issue(pf, slot == 0 ? STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
+            if (my_turn(STAGES == 3 ? turn : turn ^ 1)) issue(pf, slot == 0 ? STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
             if (advance(pf) && pf.item < last) retarget(pf);
         }
         turn ^= 1;
@@ -284,11 +294,11 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         const vc_bf16* b_tile = a_tile + GD_A_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < GD_BK / 16; ++ks) {
-            vc_s16x8 af[2], bf[NJ];
+            vc_s16x8 af[MI], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) af[i][e] = (short)(lane + i); asm volatile("" : "+v"(af[i])); }
-                else af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * 64 + i * 32, ks, lane);
+                else af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * WR + i * 32, ks, lane);
             }
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn) {
@@ -296,7 +306,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                 else bf[jn] = gd_frag<TRB, BN>(b_tile, wn * HALF_N + jn * 32, ks, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
                     if constexpr (GD_ABLATE & 1) { asm volatile("" :: "v"(af[i]), "v"(bf[jn])); continue; }
@@ -315,7 +325,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         if (cp.seq) locate(cp);
         const int z = cp.z, tm = cp.tm, tn = cp.tn;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
@@ -328,12 +338,12 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         if constexpr (COL) {
             const int cl = lane & 31;
             const int nb = tn * BN + wn * HALF_N + NJ * cl;                        // first of this lane's NJ adjacent columns
-            const int mb = tm * GD_BM + wm * 64 + 4 * (lane >> 5);                 // row of (i = 0, r = 0); row(i, r) = mb + 32 i + (r & 3) + 8 (r >> 2)
-            vc_u32x2 sd[2][16];                                                    // side input of (i, r): NJ = 2 columns (fp32 pair / packed bf16 pair in .x)
+            const int mb = tm * GD_BM + wm * WR + 4 * (lane >> 5);                 // row of (i = 0, r = 0); row(i, r) = mb + 32 i + (r & 3) + 8 (r >> 2)
+            vc_u32x2 sd[MI][16];                                                    // side input of (i, r): NJ = 2 columns (fp32 pair / packed bf16 pair in .x)
             if constexpr (NJ == 2) if (use_side) {
                 if (p.residual) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
@@ -341,7 +351,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                         }
                 } else if constexpr (sizeof(TO) == 2) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
@@ -349,7 +359,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                         }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
@@ -365,7 +375,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
             for (int jn = 0; jn < NJ; ++jn) bv[jn] = 0.0f;
             if (use_bias) gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % 3) * BN + wn * HALF_N + NJ * cl, bv);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
@@ -404,17 +414,17 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
             continue;
         }
         // ---------------------------------------------------------------- row-per-lane form (tr-read B layouts), as in r01
-        vc_u32x4 side[2][2][4];
+        vc_u32x4 side[MI][2][4];
         if constexpr (NJ == 2) if (use_side) {
             // the residual / dact choice is hoisted around the whole unrolled batch (a per-load select makes hipcc branch and
             // drain around every load)
-            int mrow[2];
+            int mrow[MI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31); mrow[i] = m < p.M ? m : p.M - 1; }
+            for (int i = 0; i < MI; ++i) { const int m = tm * GD_BM + wm * WR + i * 32 + (lane & 31); mrow[i] = m < p.M ? m : p.M - 1; }
             const int ncol = tn * BN + wn * HALF_N + 4 * (lane >> 5);
             if (p.residual) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -422,7 +432,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                             side[i][jn][q] = *reinterpret_cast<const vc_u32x4*>(p.residual + (long)mrow[i] * p.ldr + ncol + jn * 32 + 8 * q);
             } else if constexpr (sizeof(TO) == 2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -432,7 +442,7 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
                         }
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -447,8 +457,8 @@ VC_KERNEL __launch_bounds__(GD_THREADS, 1) void gemm_dma_kernel(GemmParams p, in
         // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3
         if (dbg & 64) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = tm * GD_BM + wm * 64 + i * 32 + (lane & 31);
+        for (int i = 0; i < MI; ++i) {
+            const int m = tm * GD_BM + wm * WR + i * 32 + (lane & 31);
             if (m < p.M) {
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn)

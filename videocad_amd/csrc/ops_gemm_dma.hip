@@ -14,12 +14,14 @@ extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
 static int g_epi = -1;           // epilogue form of the k-contiguous-B launches: -1 = automatic, 0 = row-per-lane (r01), 1 = column-per-lane
 extern "C" void vcad_debug_gemm_epilogue(int m) { g_epi = m; }
-template <typename TO, bool TRA, bool TRB, int BN, bool COLW>
+static int g_waves = 8;          // wave count of the 256-wide tile's launches: 8 (4 x 2 waves of 64 x 128) or 4 (2 x 2 waves of 128 x 128, one per SIMD)
+extern "C" void vcad_debug_gemm_waves(int n) { g_waves = n == 4 ? 4 : 8; }
+template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
 static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #ifndef VC_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN, COLW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
         attr_set = true;
     }
@@ -30,7 +32,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     ++g_dma_launches;
     const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
     // the ping-pong kernel carries the plain epilogue (bias, k-slice slabs); per-element side inputs stay on the lockstep kernel
-    if (BN == GD_BN && g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
+    if (NW == 8 && BN == GD_BN && g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
 #ifndef VC_EMU
         static bool attr_pp = false;
         if (!attr_pp) {
@@ -53,7 +55,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
             if (tiles_n % xn || a_bytes * xn > 0.5 * (double)tiles_mn * slice || tiles_m < 8 * 8 / xn) xn = 1;
         }
     }
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW>), dim3(grid), dim3(GD_THREADS), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total, xn);
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>), dim3(grid), dim3(NW * 64), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total, xn);
     }
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;
@@ -74,6 +76,10 @@ static bool use_col(const GemmCall& c, int BN) {
 }
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
     const int lay = c.tra * 2 + c.trb;
+    if (BN == 256 && g_waves == 4) {       // four-wave form of the hot instantiations
+        if (lay == 3) return gemm_launch_dma<float, true, true, 256, false, 4>(c, nsplit, s);
+        if (lay == 0 && use_col(c, BN)) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256, true, 4>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, true, 4>(c, nsplit, s);
+    }
     if (BN == 256) {                       // plain epilogues only (checked by the dispatcher); no tr-read B instantiation
         if (lay == 3) return gemm_launch_dma<float, true, true, 256, false>(c, nsplit, s);
         if (lay == 0 && c.to == VC_F32) return use_col(c, BN) ? gemm_launch_dma<float, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<float, false, false, 256, false>(c, nsplit, s);
