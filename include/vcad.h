@@ -68,6 +68,11 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * attention / to_out / feed-forward dropouts, TransformerDecoderLayer dropout, dropout1-3 and attention dropout).
  * p = 0 disables (model.eval()).  Masks are a stateless hash of (seed, site, element index): set a fresh seed before every
  * training forward; the backward of that forward regenerates the same masks.  No mask tensors are stored. */
+/* VCAD_FP8 forward mode (bf16 engines): the four Linear layers of every full ViT layer run on the block-scaled fp8 matrix cores
+ * (MXFP8: e4m3 elements, one E8M0 scale per 32 k-values, fp32 accumulate); weights are re-quantised from the fp32 master after every
+ * optimiser step, activations right before each GEMM; the backward pass is the bf16 one.  Re-plans the workspace (query
+ * vcad_workspace_bytes again).  Replaces nothing in the reference: BASELINE configs[4]'s "fp8 MFMA" variant. */
+int vcad_set_fp8(vcad_engine* e, int on);
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed);
 /* test hook: keep-multipliers of one site (module 1 = frame ViT, 2 = CAD ViT, 3 = decoder; kind ids in engine.hip) -> HOST buffer */
 int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out);
@@ -145,7 +150,7 @@ int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launche
 int vcad_profile_kernel(int family, double out[4]);
 
 /* ---- test / ablation hooks.  These (and the profiler switch above) are the ONLY process-global state of the library; they
- * select between kernels that compute the same result and are never touched by the product path (videocad_amd/*.py).
+ * select between kernels that compute the same result and are never touched by the product path (the videocad_amd Python package).
  * force the GEMM block tile (64 or 128; 0 = automatic choice by problem size) */
 void vcad_debug_force_gemm_tile(int tile);
 /* -1 automatic, 0 never, 1 whenever legal: routes bf16 GEMMs through the persistent DMA-fed kernel (tests, bench A/B) */

@@ -91,6 +91,30 @@ def test_engine_forward_bf16_close(emu):
     assert U.relerr(cmds, ocmds) < 3e-2
 
 
+def test_engine_fp8_forward_mode(emu):
+    """VCAD_FP8 (vcad_set_fp8): the ViT Linears on the block-scaled fp8 matrix cores; forward close to the fp32 oracle at fp8 accuracy, the
+    bf16 backward still runs on the activations the fp8 forward saved, and switching the mode off restores the bf16 numbers bit for bit"""
+    cfg = small_cfg(vit_depth=2, num_decoder_layers=1)          # (the last ViT layer is the cls-only one: depth 2 = one full fp8 layer)
+    eng, weights = build(cfg, L.VCAD_BF16, emu)
+    batch = synth.make_batch(1, 2, seed=9)
+    ot = O.OracleTrainer(weights, cfg)
+    with torch.no_grad():
+        ocmds, opars, _ = ot.forward(batch)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    an = O.normalize_actions(actions[:, :-1])
+    c_bf, p_bf = eng.forward(frames[:, :-1], an, cad); c_bf = c_bf.clone(); p_bf = p_bf.clone()
+    eng.set_fp8(True)
+    c8, p8 = eng.forward(frames[:, :-1], an, cad); c8 = c8.clone(); p8 = p8.clone()
+    assert not torch.equal(p8, p_bf), "fp8 mode did not change the forward"
+    assert U.relerr(p8, opars) < 8e-2 and U.relerr(c8, ocmds) < 8e-2, (U.relerr(p8, opars), U.relerr(c8, ocmds))
+    loss, _ = eng.loss(c8, p8, actions[:, 1:], U.LABEL_W)
+    eng.backward()
+    assert torch.isfinite(loss).all() and torch.isfinite(eng.grads).all() and float(eng.grads.abs().sum()) > 0
+    eng.set_fp8(False)
+    c2, p2 = eng.forward(frames[:, :-1], an, cad)
+    assert torch.equal(p2, p_bf) and torch.equal(c2, c_bf)
+
+
 def engine_masks(eng, cfg, B, T):
     """Rebuild every dropout keep-multiplier tensor the engine uses (vcad_debug_dropout_mask) in the oracle's tensor shapes.
     The last ViT layer computes the cls row only, so its site masks are indexed per frame: cls rows get them, the unused

@@ -132,6 +132,29 @@ def test_bf16_step_close_to_goldens(golden_dir, gemm_dma_mode):
         assert gemm_dma_mode[1]() > 20, "forced mode did not reach the DMA kernel"
 
 
+def test_fp8_forward_mode_close_to_goldens(golden_dir):
+    """VCAD_FP8 (BASELINE configs[4]'s "fp8 MFMA" variant): ViT Linears on the block-scaled fp8 matrix cores, everything else bf16.
+    Reported against the imported reference's fp32 goldens: logit MAE, norm-wise error, argmax agreement; the bf16 backward runs on top."""
+    gold = np.load(os.path.join(golden_dir, "c1_full.npz"))
+    eng = build(L.VCAD_BF16)
+    eng.set_fp8(True)
+    batch, cmds, pars, gc, gp, _ = run_case(eng, gold, 2, 8, 1, None, True)
+    mae = float((pars - gp).abs().mean()); rel = U.relerr(pars, gp)
+    agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
+    print(f"\n[fp8 forward vs fp32 reference] params-logit MAE {mae:.3e}  norm-wise rel {rel:.3e}  argmax agreement {agree:.3f}  cmd rel {U.relerr(cmds, gc):.3e}")
+    assert rel < 8e-2 and agree > 0.7
+    loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - float(gold["loss"])) < 5e-2 * abs(float(gold["loss"]))
+    eng.backward()
+    names = [str(n) for n in gold["grad_names"]]
+    rels = [abs(float(eng.view(n, eng.grads).double().norm()) - gn) / (gn + 1e-12) for n, gn in zip(names, gold["grad_norms"])]
+    print(f"[fp8 forward] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
+    assert np.median(rels) < 1e-1
+    eng.optimizer_step(lr=1e-5)                                  # weights changed: the fp8 copies are rebuilt by the next forward
+    c2, p2 = eng.forward(batch["frames"][:, :-1].contiguous(), O.normalize_actions(batch["actions"][:, :-1]), batch["cad_image"])
+    assert torch.isfinite(p2).all()
+
+
 def test_f32_causality_and_batch_independence():
     """Size-independent properties (reference SURVEY §3.3 probe): step t ignores inputs at steps > t; clips are independent."""
     eng = build(L.VCAD_F32)

@@ -199,6 +199,8 @@ def run(args):
     eng.lib.vcad_debug_gemm_policy(getattr(args, "gemm_policy", 0))
     eng.lib.vcad_debug_attn_variant(getattr(args, "attn_variant", 0))
     eng.lib.vcad_debug_gemm_mid(getattr(args, "gemm_mid", -1))
+    if getattr(args, "fp8", False):
+        eng.set_fp8(True)            # VCAD_FP8 forward mode: ViT Linears on the block-scaled fp8 matrix cores (BASELINE configs[4] variant)
     bd = synthetic_batch(B, T, 1000 * 2 + rank, device, uint8=args.uint8_frames)
     # logit parity of this build against the committed fp32 goldens — BEFORE any optimiser step (the goldens are for the hash-init weights)
     parity = logit_parity(model, device) if (rank == 0 and not getattr(args, "no_parity", False)) else None
@@ -290,7 +292,7 @@ def run(args):
         out = {"metric": "training frames/sec (224x224 grayscale frames, canonical AutoRegressiveTransformer)",
                "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": args.dtype, "data": "synthetic (" + ("uint8 pixels" if args.uint8_frames else "U[-1,1) fp32 frames") + " in HBM, hash-init weights)",
+               "dtype": args.dtype + ("+fp8 forward GEMMs (ViT)" if getattr(args, "fp8", False) else ""), "data": "synthetic (" + ("uint8 pixels" if args.uint8_frames else "U[-1,1) fp32 frames") + " in HBM, hash-init weights)",
                "config": {"workload": f"autoregressive_transformer bf16 seq_len={T} batch={B} per GPU, {world}xMI355X (BASELINE configs[1])"
                           if (T, B) == (64, 32) else f"canonical model seq_len={T} batch={B} per GPU",
                           "dropout": args.dropout, "clips_per_gpu": B, "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",

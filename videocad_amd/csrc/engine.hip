@@ -45,7 +45,7 @@ struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w
 // Scratch and ViT-backward temporaries exist twice: lane 0 = the caller's stream (frame ViT, decoder), lane 1 = the side stream the
 // CAD ViT (32 images: ~230 launch-bound kernels, 6 % of a step when serialised) runs on concurrently with the frame ViT.
 struct Lane { float* scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
-              float *t_dx, *t_dpe; void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_dum; float* t_delta; };
+              float *t_dx, *t_dpe; void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_dum; float* t_delta; uint8_t *q8a, *q8as; };
 
 struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo; };
 struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e; };
@@ -89,6 +89,10 @@ struct vcad_engine {
     // (ds_read_b128) GEMM instead of a ds_read_b64_tr_b16 one (measured: dqkv dgrad 569 -> 462 us); refreshed lazily after
     // every weight change (optimizer step / shadow sync / re-plan)
     vc_bf16* wT = nullptr; bool wT_fresh = false; std::vector<TransposeJob> wT_jobs;
+    // VCAD_FP8 forward mode (vcad_set_fp8): the four Linears of every full ViT layer run on the block-scaled fp8 matrix cores (gemm_mx8.h):
+    // weights quantised from the fp32 master once per optimiser step (q8w / q8ws mirror the flat parameter layout: byte i <-> parameter i,
+    // scale byte i/32), activations quantised into the lane's q8a / q8as right before each GEMM.  Backward is the bf16 path, unchanged.
+    bool fp8 = false, q8_fresh = false; uint8_t* q8w = nullptr; uint8_t* q8ws = nullptr;
     // Train mode: the decoder's 56 weight gradients (each a ~25-40 us launch on 2 080 rows) and their 56 bias column sums are
     // DEFERRED to the end of the decoder backward and run as two grouped GEMM grids + one grouped column-sum — their dY inputs
     // live in per-layer buffers instead of shared temporaries.  Descriptor tables are built on first use (they hold pointers
@@ -249,7 +253,11 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         l.scr_splitk_bytes = 64ul << 20; l.scr_splitk = b.take<float>(l.scr_splitk_bytes);
         l.scr_colsum_bytes = (ln == 0 ? 64ul : 16ul) << 20; l.scr_colsum = b.take<float>(l.scr_colsum_bytes);
         l.scr_lnpart_bytes = 1024ul * 2 * 1024 * 4; l.scr_lnpart = b.take<float>(l.scr_lnpart_bytes);
+        l.q8a = nullptr; l.q8as = nullptr;
+        if (e->fp8) { const long kmax = inner > D ? inner : D; l.q8a = b.take<uint8_t>(R * kmax); l.q8as = b.take<uint8_t>(R * kmax / 32); }
     }
+    e->q8w = nullptr; e->q8ws = nullptr; e->q8_fresh = false;
+    if (e->fp8) { e->q8w = b.take<uint8_t>(e->ptotal); e->q8ws = b.take<uint8_t>(e->ptotal / 32 + 64); }
     e->t_dmem = b.take<float>(M * H * 4); e->t_dcur = b.take<float>(M * H * 4); e->t_dui = b.take<float>(M * H * 4); e->t_dpre = b.take<float>(M * H * 4);
     e->t_dcadterm = b.take<float>((long)B * H * 4); e->t_dcadE = b.take<float>((long)B * H * 4);
     e->t_dec = b.take<float>((long)B * D * 4); e->t_des = b.take<float>(M * D * 4);
@@ -276,6 +284,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+#define CK_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 struct Ctx {
     vcad_engine* e; vc_stream_t s; int ln = 0;       // ln: which Lane's scratch / temporaries this context may touch
@@ -324,6 +333,31 @@ struct Ctx {
     }
     // Y[M,N] = X[M,K] W[N,K]^T (+ epilogue)
     int lin_fwd(Mat X, Mat Wm, Mat Y, int M, int N, int K, const Epi& ep) const { return gemm(X, 0, Wm, 0, Y, M, N, K, ep); }
+    // the same Linear on the fp8 matrix cores (VCAD_FP8): X (compute dtype, compact [M, K]) is quantised into the lane's buffer, W comes from
+    // the engine's quantised copy of the parameter tensor at w_off ([N, K], K % 128 == 0)
+    int lin_fwd_q(Mat X, long w_off, Mat Y, int M, int N, int K, const Epi& ep) const {
+        if (X.ld != K) { vc_set_error("lin_fwd_q: compact activations expected"); return VC_ERR_ARG; }
+        CK_(vc_mx8_quant(X.dt, X.p, X.ld, L().q8a, L().q8as, M, K, s));
+        Mx8Params q; memset(&q, 0, sizeof(q));
+        GemmParams& p = q.g;
+        p.A = L().q8a; p.B = e->q8w + w_off; p.C = (void*)Y.p; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = Y.ld; p.alpha = 1.0f;
+        p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr; p.rowadd_div = 1;
+        p.aux = ep.aux; p.ldaux = ep.ldaux; p.drop = ep.drop;
+        q.sa = L().q8as; q.ldsa = K / 32; q.sb = e->q8ws + w_off / 32; q.ldsb = K / 32;
+        return vc_gemm_mx8(q, Y.dt, s);
+    }
+    // quantised copies of the ViT Linear weights: rebuilt from the fp32 master whenever the parameters changed
+    int refresh_q8() const {
+        if (!e->fp8 || e->q8_fresh) return 0;
+        const vcad_config& c = e->c; const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head;
+        for (int v = 0; v < 2; ++v)
+            for (const auto& l : e->wv[v].l) {
+                const long offs[4] = {l.qkv, l.ow, l.w1, l.w4}; const int rows[4] = {3 * inner, D, c.vit_mlp, D}, cols[4] = {D, inner, D, c.vit_mlp};
+                for (int i = 0; i < 4; ++i) CK_(vc_mx8_quant(VC_F32, e->P + offs[i], cols[i], e->q8w + offs[i], e->q8ws + offs[i] / 32, rows[i], cols[i], s));
+            }
+        e->q8_fresh = true;
+        return 0;
+    }
     // dX[M,K] = dY[M,N] W[N,K]
     int lin_dgrad(Mat dY, Mat Wm, Mat dX, int M, int N, int K, const Epi& ep) const { return gemm(dY, 0, Wm, 1, dX, M, K, N, ep); }
     // dW[N,K] = dY[tok,N]^T X[tok,K]   (fp32, written);  db[N] = colsum(dY)
@@ -404,14 +438,20 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
         ap.drop = cx.site(v + 1, L, Ctx::K_ATTN);
         const vc_drop d_out = cx.site(v + 1, L, Ctx::K_OUT), d_act = cx.site(v + 1, L, Ctx::K_MLP_ACT), d_mlp = cx.site(v + 1, L, Ctx::K_MLP_OUT);
         if (!cls_only) {
-            CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
+            const bool q8 = e->fp8 && e->dt == VC_BF16;       // VCAD_FP8: these four Linears on the block-scaled fp8 matrix cores
+            if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_a, D), wl.qkv, cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
+            else CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
-            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; ep.drop = d_out; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
+            { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; ep.drop = d_out;
+              if (q8) CK(cx.lin_fwd_q(cx.AT(l.ao, inner), wl.ow, cx.A32(l.xm, D), (int)R, D, inner, ep));
+              else CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
             CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
             { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
-              CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
+              if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_f, D), wl.w1, cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep));
+              else CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
             { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
-              CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
+              if (q8) CK(cx.lin_fwd_q(cx.AT(l.g, c.vit_mlp), wl.w4, cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep));
+              else CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
         } else {
             CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv + (long)inner * D, D), cx.AT(q + (size_t)inner * e->esz, 3 * inner), (int)R, 2 * inner, D, Epi()));   // K, V: all tokens
             CK(cx.lin_fwd(cx.AT(l.h_a, TD), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * TI), (int)N, inner, D, Epi()));                                       // Q: cls rows
@@ -538,6 +578,7 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     // memory = tanh(image_projection([ui, cad])) only when BOTH flags are set, otherwise tanh(cad embedding) repeated over time.
     const bool pa = c.enable_past_actions, ps = c.enable_past_states;
     const float* ts = c.enable_timestep_embedding ? cx.Pf(e->o_ts) : nullptr;
+    CK(cx.refresh_q8());
     // CAD ViT (B images) on the side stream, issued first so that its ~100 small kernels slot in beside the frame ViT's big ones
     const bool fork = ps && ensure_side(e);
     Ctx cxs{e, fork ? e->side : s, 1};
@@ -794,13 +835,13 @@ int vcad_bucket_range(const vcad_engine* e, int b, int64_t* begin, int64_t* end)
 int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, void* shadow) {
     if (!params) { vc_set_error("vcad_bind: params is null"); return VC_ERR_ARG; }
     if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
-    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow; e->wT_fresh = false; e->def.ready = false;
+    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow; e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false;
     return 0;
 }
 int vcad_sync_shadow(vcad_engine* e, void* stream) {
     if (e->dt != VC_BF16) return 0;
     if (!e->P || !e->S) { vc_set_error("vcad_sync_shadow: not bound"); return VC_ERR_ARG; }
-    e->wT_fresh = false;
+    e->wT_fresh = false; e->q8_fresh = false;
     return vc_cast(VC_BF16, e->P, e->S, e->ptotal, (vc_stream_t)stream);
 }
 size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
@@ -809,6 +850,14 @@ size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
 }
 int vcad_set_workspace(vcad_engine* e, void* ws, size_t bytes) { e->ws = (char*)ws; e->ws_bytes = bytes; e->fwd_valid = false; e->B = e->T = 0; e->planned_ws = nullptr; e->infer_T = 0; return 0; }
 
+// VCAD_FP8 forward mode: the ViT's Linear layers on the block-scaled fp8 matrix cores (bf16 engines only; backward unchanged).  Changes the
+// workspace plan: call before the next forward.
+int vcad_set_fp8(vcad_engine* e, int on) {
+    if (on && e->dt != VC_BF16) { vc_set_error("vcad_set_fp8: fp8 forward GEMMs need a bf16 engine"); return VC_ERR_UNSUPPORTED; }
+    if (on && (e->c.vit_dim % 128 || (e->c.vit_heads * e->c.vit_dim_head) % 128 || e->c.vit_mlp % 128)) { vc_set_error("vcad_set_fp8: ViT widths must be multiples of 128"); return VC_ERR_UNSUPPORTED; }
+    e->fp8 = on != 0; e->planned_ws = nullptr; e->B = e->T = 0; e->fwd_valid = false; e->infer_T = 0;
+    return 0;
+}
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed) {
     if (!(p >= 0.f && p < 1.f)) { vc_set_error("vcad_set_dropout: p must be in [0, 1)"); return VC_ERR_ARG; }
     e->drop_p = p; e->drop_seed = seed;
@@ -1107,6 +1156,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
         b0 = b1i + 1;
     }
     e->wT_fresh = false;                  // the bf16 shadow just changed: its transposed copies are rebuilt before the next backward
+    e->q8_fresh = false;                  // ... and the fp8 copies before the next forward
     if (norm_out) CK(vc_memcpy_d2d_async(norm_out, e->norm_out, 2 * 4, s));
     return 0;
 }

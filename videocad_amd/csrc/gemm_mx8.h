@@ -12,17 +12,13 @@
 // straight to registers.  Epilogue: gemm.h's column-per-lane gemm_epilogue_tile (bias, GELU + pre-activation output, dropout,
 // residual ...), so every fused forward epilogue of the ViT is available.
 #pragma once
-#include "gemm.h"
+#include "ops.h"
 
 constexpr int MX_BM = 128, MX_BN = 128, MX_BK = 128, MX_THREADS = 256;
 constexpr int MX_TILE_BYTES = MX_BM * MX_BK;                                   // 16 KiB per operand tile
 constexpr size_t MX_LDS_BYTES = 2ul * 2 * MX_TILE_BYTES;                       // double buffer x (A + B) = 64 KiB
 
-struct Mx8Params {
-    GemmParams g;                 // A / B point at the e4m3 bytes; lda / ldb in bytes (= elements); everything else as in gemm.h
-    const uint8_t* sa; long ldsa; // E8M0 scales of A: [M][K/32]
-    const uint8_t* sb; long ldsb; // E8M0 scales of B: [N][K/32]
-};
+// (struct Mx8Params: ops.h — GemmParams whose A / B point at the e4m3 bytes, plus the E8M0 scale matrices [rows][K / 32])
 
 // ---- quantiser: x [rows, cols] (fp32 or bf16, row stride ld) -> q [rows, cols] e4m3 + scales [rows, cols/32] (E8M0)
 // scale exponent = floor(log2(amax of the block)) - 8 (e4m3's largest binade), so the block's largest value lands in [256, 512) and is

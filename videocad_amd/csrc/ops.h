@@ -65,7 +65,7 @@ int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chun
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]
 
 // MXFP8 (gemm_mx8.h): quantise [rows, cols] (fp32 / bf16) to e4m3 + E8M0 block scales; C = epilogue(A8 B8^T)
-struct Mx8Params;
+struct Mx8Params { GemmParams g; const uint8_t* sa; long ldsa; const uint8_t* sb; long ldsb; };     // fp8 operands + their E8M0 scale matrices [rows][K / 32]
 int vc_mx8_quant(int tx, const void* x, long ld, uint8_t* q, uint8_t* sc, long rows, int cols, vc_stream_t s);
 int vc_gemm_mx8(Mx8Params q, int to, vc_stream_t s);
 

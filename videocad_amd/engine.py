@@ -4,6 +4,7 @@ to the C ABI on torch's current HIP stream."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -53,7 +54,10 @@ class NativeEngine:
         self.params = self.grads = self.m = self.v = self.shadow = None
         self.ws = None
         self.step_count = 0
+        self.fp8 = False
         self.allocate(self.device)
+        if os.environ.get("VCAD_FP8", "0") == "1" and self.cfg.dtype == L.VCAD_BF16:
+            self.set_fp8(True)
 
     # ------------------------------------------------------------------ buffers
     def allocate(self, device, params: Optional[torch.Tensor] = None):
@@ -86,6 +90,12 @@ class NativeEngine:
             self.ws = None
             self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             L.check(self.lib, self.lib.vcad_set_workspace(self.h, _ptr(self.ws), need), "set_workspace")
+
+    def set_fp8(self, on: bool = True):
+        """VCAD_FP8 forward mode (include/vcad.h: vcad_set_fp8): the ViT's Linear layers on the block-scaled fp8 matrix cores; bf16 engines
+        only, backward unchanged.  The workspace is re-planned on the next forward."""
+        L.check(self.lib, self.lib.vcad_set_fp8(self.h, 1 if on else 0), "set_fp8")
+        self.fp8 = bool(on)
 
     def set_dropout(self, p: float, seed: int = 0):
         """p = 0 disables; call with a fresh seed before every training forward (masks = hash(seed, site, index))."""

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "vcad_workspace_bytes": (_sz, [_vp, _i, _i]),
     "vcad_set_workspace": (_i, [_vp, _vp, _sz]),
     "vcad_set_dropout": (_i, [_vp, _f, C.c_uint64]),
+    "vcad_set_fp8": (_i, [_vp, _i]),
     "vcad_debug_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_forward_u8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
