@@ -94,6 +94,9 @@ def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to, waves):
         U.check_gemm(emu, "cpu", M, 512, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=not tra, splitk=bool(tra))
         U.check_gemm(emu, "cpu", 264, 256, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
         assert emu.vcad_debug_gemm_dma_launches() == n0 + 2, "the GEMM did not take the DMA kernel"
+        if not tra:      # fused epilogue without side inputs (bias + GELU: the MLP's first Linear) — eight-wave column-per-lane form
+            U.check_gemm(emu, "cpu", 600, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, act=1, splitk=False)
+            assert emu.vcad_debug_gemm_dma_launches() == n0 + 3
         if not tra:      # XCD column groups (forward layout): 2 x 4 and 4 x 2 XCD grids over 3 tile rows x 2 tile columns
             for xn in (2, 1):
                 emu.vcad_debug_gemm_xcd_cols(xn if xn > 1 else -1)

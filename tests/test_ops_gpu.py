@@ -114,6 +114,7 @@ def test_gemm_dma_kernel_wide_tile(hip, waves):
             U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep)
             U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep)
         U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, pad=8)
+        U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1)      # fused bias + GELU on the 256-wide tile (MLP-1 forward)
         for xn in (2, 4, 8):                                             # XCD column groups, both tile widths
             hip.vcad_debug_gemm_xcd_cols(xn)
             U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=xn)
@@ -123,7 +124,7 @@ def test_gemm_dma_kernel_wide_tile(hip, waves):
             hip.vcad_debug_gemm_wide(1)
     finally:
         hip.vcad_debug_gemm_dma(-1); hip.vcad_debug_gemm_wide(-1); hip.vcad_debug_gemm_xcd_cols(-1); hip.vcad_debug_gemm_waves(8)
-    assert hip.vcad_debug_gemm_dma_launches() == n0 + 25, "a GEMM did not take the DMA kernel"
+    assert hip.vcad_debug_gemm_dma_launches() == n0 + 26, "a GEMM did not take the DMA kernel"
 
 
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16), (1024, BF16)])

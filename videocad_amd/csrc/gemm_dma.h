@@ -389,6 +389,23 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 #pragma unroll
                             for (int jn = 0; jn < NJ; ++jn) v[jn] += bv[jn];
                             gd_vec_st<TO, NJ>(((TO*)p.C) + (long)m * p.ldc + nb, v);
+                        } else if constexpr (NJ == 4) {
+                            // 256-wide tile: the fused epilogues that need NO per-element side input (the MLP's first Linear: bias,
+                            // pre-activation output, GELU, dropout) on the lane's four adjacent columns — 8 / 16-byte row pieces
+                            float b4[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = p.alpha * v[k] + b4[k];
+                            if (p.aux) gd_vec_st<TO, 4>(((TO*)p.aux) + (long)m * p.ldaux + nb, v);
+                            if (p.act) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = vc_apply_act(v[k], p.act);
+                            }
+                            if (p.drop.key) {
+                                float dm[4]; vc_drop_mul4(p.drop, (uint32_t)((long)m * p.N + nb), dm);        // nb % 4 == 0
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] *= dm[k];
+                            }
+                            gd_vec_st<TO, 4>(((TO*)p.C) + (long)m * p.ldc + nb, v);
                         } else if constexpr (NJ == 2) {
                             // fused epilogue on the lane's two adjacent columns: alpha, bias, pre-activation output, activation, dropout,
                             // activation derivative, residual (order of gemm.h: gemm_epilogue_quad)

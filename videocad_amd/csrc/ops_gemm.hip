@@ -132,9 +132,14 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad): 256 x 256 tile where
     // the epilogue is plain (bias / k-slice slabs: QKV forward, dgrads through W^T, split-K wgrads), else 256 x 128
     const bool plain_epi = !p.act && !p.dact_src && !p.aux && !p.residual && !p.drop.key && p.alpha == 1.0f;
+    // ... or a fused epilogue WITHOUT per-element side inputs (bias, pre-activation output, activation, dropout: the MLP's first Linear) on
+    // the forward layout, whose column-per-lane epilogue has the registers for it
+    // — measured in-model (profiles/r02_gemm_policy_ab.txt): no faster than the register-staged kernel for the GELU Linear (29.73 vs 29.56 ms per
+    // step), so it is taken only when the wide tile is forced (tests) or asked for (policy bit 8)
+    const bool wide_fused = lay == 0 && !p.dact_src && !p.residual && !p.rowadd && (g_dma_wide == 1 || (g_policy & 8));
     for (int pass = 0; pass < 2; ++pass) {
         const int BN = pass == 0 ? 256 : GD_BN;
-        if (pass == 0 && (!plain_epi || g_dma_wide == 0)) continue;
+        if (pass == 0 && (!(plain_epi || wide_fused) || g_dma_wide == 0)) continue;
         if (!(c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && lay != 2 && g_dma_mode != 0 && !(g_debug_skip & 31) && p.vecA && p.vecB && p.vecC &&
               p.N % BN == 0 && p.K % GD_BK == 0 && (!c.tra || p.M % 8 == 0) && (lay != 3 || c.to == VC_F32) && p.M >= 8 && !p.rowadd &&
               (double)p.lda * (c.tra ? p.K : p.M) * 2 < 2.0e9 && (double)p.ldb * (c.trb ? p.K : p.N) * 2 < 2.0e9)) continue;
@@ -158,7 +163,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         // it loses where its one-workgroup-per-CU design has nothing to overlap a VALU-heavy epilogue with (GELU / GELU' — the
         // register-staged kernel's second co-resident workgroup hides that), on the long-K dgrad through ds_read_b64_tr_b16
         // (K >= 2048), and on wgrads with fewer than 16 output tiles (the k-slice slabs dominate).
-        const bool wins = tiles * best >= 200 && ((g_policy & 1) || (!p.act && !p.dact_src)) && !(lay == 1 && p.K >= 2048) && ((g_policy & 2) || !(lay == 3 && tiles < 16));
+        const bool wins = tiles * best >= 200 && ((g_policy & 1) || (BN == 256 && wide_fused && !p.dact_src) || (!p.act && !p.dact_src)) && !(lay == 1 && p.K >= 2048) && ((g_policy & 2) || !(lay == 3 && tiles < 16));
         // the wide tile halves the item count: with few, short items (N = 512, K = 512: 814 items of 8 k-tiles = 3.2 rounds) the last,
         // partly filled round costs more than the tile saves (measured: profiles/r02_gemm_wide_ab.txt) — long items amortise it
         const double fill = (double)(tiles * best) / (256.0 * VC_CEIL_DIV(tiles * best, 256));

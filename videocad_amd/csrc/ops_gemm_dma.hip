@@ -76,6 +76,12 @@ static bool use_col(const GemmCall& c, int BN) {
 }
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
     const int lay = c.tra * 2 + c.trb;
+    // the 256-wide tile's fused epilogue (activation / pre-activation output / dropout) exists in the column-per-lane form only
+    const bool fused = c.p.act || c.p.aux || c.p.drop.key || c.p.alpha != 1.0f;
+    if (BN == 256 && fused) {
+        if (lay != 0 || c.p.dact_src || c.p.residual) { vc_set_error("vc_gemm_dma_launch: 256-wide tile has no such fused epilogue"); return VC_ERR_UNSUPPORTED; }
+        return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, true>(c, nsplit, s);
+    }
     if (BN == 256 && g_waves == 4) {       // four-wave form of the hot instantiations
         if (lay == 3) return gemm_launch_dma<float, true, true, 256, false, 4>(c, nsplit, s);
         if (lay == 0 && use_col(c, BN)) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256, true, 4>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, true, 4>(c, nsplit, s);
