@@ -115,3 +115,35 @@ def test_full_size_step_bf16_close_and_train_mode_sane(name, B, T):
     assert np.isfinite(float(loss_t[0])) and np.isfinite(g_train) and 0.3 * g_eval < g_train < 3.0 * g_eval, (g_eval, g_train)
     assert not torch.equal(pars[:2], pars[2 * (K - 1):])                    # dropout masks differ per clip
     assert not torch.equal(eng.view("embed_state.weight"), w0)
+
+
+def test_full_size_fp8_forward_mode_c5_per_gpu_shape():
+    """BASELINE configs[4]'s per-GPU shape (16 clips x 186 steps) in the VCAD_FP8 forward mode (ViT Linears on the MXFP8 matrix cores):
+    logits against the fp32 oracle at fp8 accuracy (reported), repetitions bit-identical, the bf16 backward on top, one train-mode step."""
+    B, T = 16, 186
+    ref = oracle_two_clips(T)
+    K = B // 2
+    eng = build(L.VCAD_BF16)
+    eng.set_fp8(True)
+    frames, actions, cad = tiled(ref["batch"], K)
+    an = O.normalize_actions(actions[:, :-1])
+    cmds, pars = eng.forward(frames[:, :-1], an, cad)
+    p = pars[:2].cpu()
+    rel, mae = U.relerr(p, ref["pars"]), float((p - ref["pars"]).abs().mean())
+    agree = float((p.argmax(-1) == ref["pars"].argmax(-1)).float().mean())
+    print(f"\n[C5 per-GPU shape, fp8 forward vs fp32 oracle] logit MAE {mae:.3e}  rel {rel:.3e}  argmax agreement {agree:.4f}")
+    assert rel < 8e-2 and agree > 0.7
+    assert torch.equal(pars[:2], pars[2 * (K - 1):])
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - ref["loss"]) < 5e-2 * abs(ref["loss"])
+    eng.backward()
+    worst = max(abs(float(eng.view(n, eng.grads).double().norm()) - w) / w for n, w in ref["gn"].items())
+    print(f"[C5 per-GPU shape, fp8 forward] worst probed gradient-norm error {worst:.3e}")
+    assert worst < 2.5e-1, worst
+    g_eval = float(eng.optimizer_step(lr=0.0)[0])
+    eng.set_dropout(0.1, seed=11)
+    cmds, pars = eng.forward(frames[:, :-1], an, cad)
+    loss_t, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    eng.backward()
+    g_train = float(eng.optimizer_step(lr=1e-5)[0])
+    assert np.isfinite(float(loss_t[0])) and np.isfinite(g_train) and 0.3 * g_eval < g_train < 3.0 * g_eval, (g_eval, g_train)
