@@ -712,6 +712,73 @@ VC_KERNEL __launch_bounds__(64) void attn_dec_fwd_mfma_kernel(AttnParams p) {
     }
 }
 
+// r02 forward: ONE WAVE PER HEAD-DIM CHUNK (NCH waves per (clip, head)).  The one-wave kernel above walks the chunks through the same two
+// LDS tiles — 2 NCH dependent load -> MFMA phases, ~22 us for a launch of only B x H workgroups.  Here every wave stages its own Q / K / V
+// chunk at once (one memory round trip), computes its partial score grid, the partials are summed through LDS in a fixed order (every
+// wave ends up with the same bits), each wave runs the (cheap) softmax redundantly and produces its own 64 output columns.
+constexpr int AM_CW_WAVE_ELEMS = 3 * AM_T * AM_S;                                    // Q, K, V chunk tiles of one wave
+constexpr size_t am_cw_lds_bytes(int nch) { return (size_t)nch * AM_CW_WAVE_ELEMS * 2; }
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(64 * NCH) void attn_dec_fwd_cw_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, lds);
+    const int tid = threadIdx.x, lane = tid & 63, c = vc_uniform(tid >> 6);
+    vc_bf16* Qs = lds + c * AM_CW_WAVE_ELEMS; vc_bf16* Ks = Qs + AM_T * AM_S; vc_bf16* Vs = Ks + AM_T * AM_S;
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH + c * AM_D;
+    am_stage(Qs, (const vc_bf16*)p.q + rowq * p.ldq + hd, p.ldq, T, lane);
+    am_stage(Ks, (const vc_bf16*)p.k + rowq * p.ldk + hd, p.ldk, T, lane);
+    am_stage(Vs, (const vc_bf16*)p.v + rowq * p.ldv + hd, p.ldv, T, lane);
+    vc_sync();                                // every wave's chunk is in LDS
+    // every wave accumulates the FULL score grid over the chunks in the order 0 .. NCH-1 — the order of the backward kernel's recompute, so
+    // exp(s - lse) is exactly 1 where a query sees a single key (window = 1: dS = 0 bit for bit, like the reference); the 4x redundant MFMAs
+    // run on four different SIMDs and cost no wall time, the memory round trip was the price
+    vc_f32x16 st[2][2];                       // S^T: [key tile][query tile], lane column = query
+    am_zero(st);
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) am_mm_nt(st, lds + cc * AM_CW_WAVE_ELEMS + AM_T * AM_S, lds + cc * AM_CW_WAVE_ELEMS, lane);
+    vc_sync();                                // all Q / K fragments consumed: the own Q tile becomes the store staging
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    uint64_t keep = 0;
+    if (DROP) keep = am_keep_bits<true>(p.drop, dbase0, T, lane);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int query = qt * 32 + (lane & 31);
+        const int qm = query < T ? query : T - 1;              // padding columns: keep the row finite (never stored)
+        float m = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + am_row(r, lane);
+                const float sc = am_visible(qm, key, T, p.window) ? st[kt][qt][r] * p.scale : -INFINITY;
+                st[kt][qt][r] = sc; m = fmaxf(m, sc);
+            }
+        m = fmaxf(m, vc_shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
+        l += vc_shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kt][qt][r] *= DROP ? inv * am_keep(keep, kt, qt, r, p.drop.scale) : inv;
+        if (c == 0 && p.lse && lane < 32 && query < T) p.lse[(n * p.H + h) * T + query] = m + logf(l);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const vc_f32x16 W[2] = {st[0][qt], st[1][qt]};
+        vc_f32x16 o[2];
+        am_zero1(o);
+        am_mm_tok1<false>(o, W, Vs, lane, 0u, 1.0f);           // O[query][d] = sum_key P[query][key] V[key][d], this wave's 64 columns
+        am_store_rows(Qs, (vc_bf16*)p.o + rowq * p.ldo + hd, p.ldo, o, qt, T, lane, 1.0f);
+    }
+}
+
 // Backward: 2 waves per (clip, head) as in the ViT kernel — wave 0 owns "lane = query" (D_i, dQ), wave 1 "lane = key" (dV, dK).
 // Phase 1 accumulates both score-shaped grids of each wave over the head-dim chunks, phase 2 re-stages the chunks and emits
 // the three gradients chunk by chunk.
@@ -813,6 +880,152 @@ VC_KERNEL __launch_bounds__(128, 1) void attn_dec_bwd_mfma_kernel(AttnParams p) 
             am_zero(acc);
             am_mm_tok(acc, dg, Qs, lane);        // dK[key][d] = sum_query dS[query][key] Q[query][d]
             am_store((vc_bf16*)p.dk + rowq * p.lddk + hd + c * AM_D, p.lddk, acc, T, lane, p.scale);
+        }
+    }
+}
+
+// r02 backward: FOUR waves per (clip, head) — (orientation) x (half of the head-dim chunks), one per SIMD with the full register file (an
+// eight-wave form, one per chunk, spilled 120 registers at the 256-register cap).  All 4 NCH chunk tiles (Q, K, V, dO) are staged at once
+// (one memory round trip instead of 2 NCH); every wave of an orientation accumulates the two score-shaped grids over the chunks in the order
+// 0 .. NCH-1 (bit-identical to the forward's lse, see above; redundant MFMAs on otherwise idle SIMDs), then produces the gradients of its own
+// chunks: dQ_c (query waves), dV_c and dK_c (key waves) — token-contraction products with swapped operands and whole-row stores through a
+// wave-private staging area carved out of the V tiles, which are dead after the first phase.
+constexpr size_t am_cwb_lds_bytes(int nch) { return (size_t)4 * nch * AM_T * AM_S * 2 + 2 * AM_T * sizeof(float); }
+template <bool DROP>
+VC_DEV void am_mm_tok1k(vc_f32x16 (&out)[2], const vc_f32x16 (&W)[2], const vc_bf16* Y, int lane, uint64_t keep, int tj, float scale) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const vc_s16x8 b = DROP ? am_pack_keep(W[tt], s, keep, tt, tj, scale) : am_pack(W[tt], s);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) out[dt] = vc_mfma_32x32x16_bf16(am_frag_tr(Y, tt * 32 + 16 * s, dt * 32, lane), b, out[dt]);
+        }
+}
+template <bool DROP, int NCH>
+VC_KERNEL __launch_bounds__(256, 1) void attn_dec_bwd_cw_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, lds);
+    constexpr int TILE = AM_T * AM_S, CPW = NCH / 2;             // chunks per wave in the second phase
+    float* lse_s = reinterpret_cast<float*>(lds + 4 * NCH * TILE);
+    float* del_s = lse_s + AM_T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
+    const int o = wave >> 1, half = wave & 1;                    // orientation (0 = lane is a query, 1 = lane is a key), which half of the chunks
+    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    const int T = p.Tq;
+    const long rowq = n * T;
+    const int hd = h * AM_D * NCH;
+    auto Qt = [&](int cc) { return lds + (0 * NCH + cc) * TILE; };
+    auto Kt = [&](int cc) { return lds + (1 * NCH + cc) * TILE; };
+    auto Vt = [&](int cc) { return lds + (2 * NCH + cc) * TILE; };
+    auto Ot = [&](int cc) { return lds + (3 * NCH + cc) * TILE; };
+    {   // wave w stages all NCH chunks of tensor w (Q, K, V, dO): every load is issued before the first LDS store (one memory round trip)
+        const vc_bf16* g = wave == 0 ? (const vc_bf16*)p.q : (wave == 1 ? (const vc_bf16*)p.k : (wave == 2 ? (const vc_bf16*)p.v : (const vc_bf16*)p.dout));
+        const long ld = wave == 0 ? p.ldq : (wave == 1 ? p.ldk : (wave == 2 ? p.ldv : p.lddo));
+        g += rowq * ld + hd;
+        vc_u32x4 v[NCH][AM_T / 8];
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+            for (int it = 0; it < AM_T / 8; ++it) {
+                const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+                v[cc][it] = *reinterpret_cast<const vc_u32x4*>(g + (long)(row < T ? row : T - 1) * ld + cc * AM_D + col);
+            }
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc)
+#pragma unroll
+            for (int it = 0; it < AM_T / 8; ++it) {
+                const int row = it * 8 + (lane >> 3), col = (lane & 7) * 8;
+                vc_u32x4 w = v[cc][it];
+                if (row >= T) { w.x = 0u; w.y = 0u; w.z = 0u; w.w = 0u; }
+                *reinterpret_cast<vc_u32x4*>(lds + (wave * NCH + cc) * TILE + row * AM_S + col) = w;
+            }
+    }
+    if (tid < AM_T) lse_s[tid] = (tid < T) ? p.lse[(n * p.H + h) * T + tid] : 0.f;
+    vc_sync();
+    const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    vc_f32x16 sg[2][2], dg[2][2];            // query waves: S^T, dP^T [key tile][query tile]; key waves: S, dP' [query tile][key tile]
+    am_zero(sg); am_zero(dg);
+#pragma unroll 1
+    for (int cc = 0; cc < NCH; ++cc) {
+        if (o == 0) { am_mm_nt(sg, Kt(cc), Qt(cc), lane); am_mm_nt(dg, Vt(cc), Ot(cc), lane); }
+        else        { am_mm_nt(sg, Qt(cc), Kt(cc), lane); am_mm_nt(dg, Ot(cc), Vt(cc), lane); }
+    }
+    uint64_t keep = 0;
+    if (o == 0) {      // ---------------- lane = query: P, D_i, dS^T
+        if (DROP) keep = am_keep_bits<true>(p.drop, dbase0, T, lane);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int query = qt * 32 + (lane & 31);
+            const float lse = lse_s[query];
+            float dsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + am_row(r, lane);
+                    const bool ok = query < T && am_visible(query, key, T, p.window);
+                    const float pr = ok ? expf(sg[kt][qt][r] * p.scale - lse) : 0.f;
+                    if (DROP) dg[kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);                    // dP = dP' * mask
+                    sg[kt][qt][r] = pr; dsum += pr * dg[kt][qt][r];
+                }
+            dsum += vc_shfl_xor(dsum, 32);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sg[kt][qt][r] = sg[kt][qt][r] * (dg[kt][qt][r] - dsum);   // dS^T (scale folded into the store)
+            if (half == 0 && lane < 32) del_s[query] = dsum;
+        }
+    } else {           // ---------------- lane = key: P (kept in sg), later dS (in dg)
+        if (DROP) keep = am_keep_bits<false>(p.drop, dbase0, T, lane);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = kt * 32 + (lane & 31);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + am_row(r, lane);
+                    sg[qt][kt][r] = (query < T && am_visible(query, key, T, p.window)) ? expf(sg[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
+                }
+        }
+    }
+    vc_sync();                               // D_i published; nobody reads V any more: its tiles become the store staging
+    vc_bf16* stage = Vt(wave >> 1) + (wave & 1) * 32 * AM_S;
+    if (o == 0) {
+#pragma unroll 1
+      for (int c = half * CPW; c < (half + 1) * CPW; ++c)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const vc_f32x16 W[2] = {sg[0][qt], sg[1][qt]};
+            vc_f32x16 acc[2];
+            am_zero1(acc);
+            am_mm_tok1k<false>(acc, W, Kt(c), lane, 0, 0, 1.0f);             // dQ[query][d] = sum_key dS[query][key] K[key][d]
+            am_store_rows(stage, (vc_bf16*)p.dq + rowq * p.lddq + hd + c * AM_D, p.lddq, acc, qt, T, lane, p.scale);
+        }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int query = qt * 32 + am_row(r, lane);
+                    const float ms = DROP ? am_keep(keep, qt, kt, r, p.drop.scale) : 1.0f;
+                    dg[qt][kt][r] = sg[qt][kt][r] * (dg[qt][kt][r] * ms - del_s[query]);                          // dS
+                }
+#pragma unroll 1
+      for (int c = half * CPW; c < (half + 1) * CPW; ++c)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            vc_f32x16 acc[2];
+            { const vc_f32x16 W[2] = {sg[0][kt], sg[1][kt]};
+              am_zero1(acc);
+              am_mm_tok1k<DROP>(acc, W, Ot(c), lane, keep, kt, p.drop.scale);   // dV[key][d] = sum_query P'[query][key] dO[query][d]
+              am_store_rows(stage, (vc_bf16*)p.dv + rowq * p.lddv + hd + c * AM_D, p.lddv, acc, kt, T, lane, 1.0f); }
+            { const vc_f32x16 W[2] = {dg[0][kt], dg[1][kt]};
+              am_zero1(acc);
+              am_mm_tok1k<false>(acc, W, Qt(c), lane, 0, 0, 1.0f);               // dK[key][d] = sum_query dS[query][key] Q[query][d]
+              am_store_rows(stage, (vc_bf16*)p.dk + rowq * p.lddk + hd + c * AM_D, p.lddk, acc, kt, T, lane, p.scale); }
         }
     }
 }

@@ -102,6 +102,20 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         else VC_LAUNCH((attn_vit_fwd_mfma_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         return VC_OK;
     }
+    if (dec_mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {       // one wave per head-dim chunk
+        const dim3 g((unsigned)((long)p.B * p.H));
+        static bool attr = false;
+        if (!attr) {
+            if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<true, 4>, am_cw_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<false, 4>, am_cw_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<true, 2>, am_cw_lds_bytes(2))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<false, 2>, am_cw_lds_bytes(2))) return rc;
+            attr = true;
+        }
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_cw_kernel<true, 4>), g, dim3(256), am_cw_lds_bytes(4), s, p); else VC_LAUNCH((attn_dec_fwd_cw_kernel<false, 4>), g, dim3(256), am_cw_lds_bytes(4), s, p); }
+        else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_cw_kernel<true, 2>), g, dim3(128), am_cw_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_fwd_cw_kernel<false, 2>), g, dim3(128), am_cw_lds_bytes(2), s, p); }
+        return VC_OK;
+    }
     if (dec_mfma_ok(t, D, p, false)) {
         const dim3 g((unsigned)((long)p.B * p.H));
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
@@ -134,6 +148,20 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (mfma_ok(t, D, p, true)) {                                  // r01's two-wave kernel, kept for the A/B (vcad_debug_attn_variant(1))
         if (p.drop.key) VC_LAUNCH(attn_vit_bwd_mfma_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH(attn_vit_bwd_mfma_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        return VC_OK;
+    }
+    if (dec_mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {        // one wave per (orientation, head-dim chunk)
+        const dim3 g((unsigned)((long)p.B * p.H));
+        static bool attr = false;
+        if (!attr) {
+            if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<true, 4>, am_cwb_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<false, 4>, am_cwb_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<true, 2>, am_cwb_lds_bytes(2))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<false, 2>, am_cwb_lds_bytes(2))) return rc;
+            attr = true;
+        }
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_cw_kernel<true, 4>), g, dim3(256), am_cwb_lds_bytes(4), s, p); else VC_LAUNCH((attn_dec_bwd_cw_kernel<false, 4>), g, dim3(256), am_cwb_lds_bytes(4), s, p); }
+        else               { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_cw_kernel<true, 2>), g, dim3(256), am_cwb_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_bwd_cw_kernel<false, 2>), g, dim3(256), am_cwb_lds_bytes(2), s, p); }
         return VC_OK;
     }
     if (dec_mfma_ok(t, D, p, true)) {
