@@ -7,12 +7,16 @@
 // workgroup is persistent: it walks a list of (tile, k-slice) items as ONE flat stream of k-tiles, so the loads of the next
 // tile are already in flight while the current tile's epilogue runs straight out of the accumulator registers.
 //
-// Shape: 512 threads = 8 waves (4 along M x 2 along N), tile 256x128, BK = 64, one workgroup per CU (ring = 3 x 48 KiB).
+// Shapes (GdTile<BN>): 512 threads = 8 waves (4 along M x 2 along N), BK = 64, one workgroup per CU;
+//   tile 256 x 128, ring = 3 x 48 KiB — the fused residual / activation-derivative epilogues;
+//   tile 256 x 256, ring = 2 x 64 KiB (r02) — plain epilogues (bias, k-slice slabs): half the operand bytes per MFMA.
 // LDS images are UNPADDED (the DMA writes lane-linear 1 KiB pieces) and XOR-swizzled through the per-lane SOURCE address:
 //   k-contiguous operand  [rows][64]  : 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7)  (ds_read_b128, conflict-free)
 //   row-contiguous operand [64][COLS] : slot s of k-row k is stored at slot s ^ ((k & 3) << 2)          (ds_read_b64_tr_b16)
-// The MFMA is issued with the operands swapped (D = B_frag x A_frag) so that each lane ends up with 4 CONSECUTIVE output
-// columns per accumulator quad: the epilogue needs no LDS transpose and uses 8/16-byte accesses.
+// Epilogue forms: "row per lane" — the MFMA is issued with the operands swapped (D = B_frag x A_frag) so that a lane ends up with
+// one output row and 4 CONSECUTIVE columns per accumulator quad (8/16-byte accesses, no LDS transpose); "column per lane" (r02,
+// k-contiguous B on the wide tile) — unswapped MFMA over a B image whose rows were permuted by the DMA's source addresses, so a lane
+// owns NJ ADJACENT columns of 16 rows and a store instruction covers 2 rows x 256-512 contiguous bytes (see the kernel).
 //
 // The per-column bias of a tile rides along as one more (512-byte) DMA into a spare LDS corner; the per-element side input of a
 // fused epilogue (residual stream, or the activation-derivative source) is fetched with ordinary loads issued BEFORE the tile's
