@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over tools/gemm_pmc.py; output: gpurun_out/gemm_pmc/<pass>/...csv + a per-kernel summary
-R=$PWD; OUT=$R/gpurun_out/gemm_pmc; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+R=$PWD; OUT=$R/gpurun_out/gemm_pmc; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq -o p -- python $R/tools/gemm_pmc.py > $OUT/sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/rd -o p -- python $R/tools/gemm_pmc.py > $OUT/rd.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/wr -o p -- python $R/tools/gemm_pmc.py > $OUT/wr.log 2>&1
