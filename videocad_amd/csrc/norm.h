@@ -204,8 +204,11 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     }
 }
 
-// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c].  Deterministic 128-way tree: every pass gives each block <= 32
-// rows of 256 columns (so there are always enough blocks in flight), partials are reduced by the next pass.
+// ---- column sums: out[c] (=|+=) sum_r x[r*ld + c].  Deterministic 512-way tree: a block is 64 columns x 4 row quarters of a 512-row
+// chunk (each thread walks <= 128 rows with 8 loads in flight; the quarters are added 0..3 through LDS), partial rows are reduced by the
+// next pass: 104 000 token rows -> 204 -> 1 in two launches, the <= 512 partial rows of a LayerNorm backward in one.  (r01's 128-way
+// tree of 256-column blocks needed three and two: ~210 launches of ~6.5 us per train step.)
+constexpr int COLSUM_ROWS = 512;
 struct ColsumParams {
     const void* x; long ld; long rows; int cols; long batch_stride_x;
     float* out; long ld_out_rows; long batch_stride_out; int accumulate;    // out row g = block-row index (partials) or 0 (final)
@@ -213,22 +216,32 @@ struct ColsumParams {
 };
 template <typename TX>
 VC_KERNEL __launch_bounds__(256) void colsum_pass_kernel(ColsumParams p) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= p.cols) return;
+    VC_SHARED float red[4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool live = c < p.cols;
     const TX* x = (const TX*)p.x + (long)blockIdx.z * p.batch_stride_x;
-    long r0 = (long)blockIdx.y * p.rows_per_block, r1 = r0 + p.rows_per_block;
-    if (r1 > p.rows) r1 = p.rows;
+    const long b0 = (long)blockIdx.y * p.rows_per_block;
+    long b1 = b0 + p.rows_per_block; if (b1 > p.rows) b1 = p.rows;
+    const long per = ((b1 - b0) + 3) / 4;
+    long r = b0 + q * per, r1 = r + per; if (r1 > b1) r1 = b1;
     float s = 0.f;
-    long r = r0;
-    for (; r + 8 <= r1; r += 8) {                 // 8 independent loads in flight per thread (a plain loop waits for each)
-        float v[8];
+    if (live) {
+        for (; r + 8 <= r1; r += 8) {             // 8 independent loads in flight per thread (a plain loop waits for each)
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = vc_ld(x + (r + u) * p.ld + c);
-        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            for (int u = 0; u < 8; ++u) v[u] = vc_ld(x + (r + u) * p.ld + c);
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; r < r1; ++r) s += vc_ld(x + r * p.ld + c);
     }
-    for (; r < r1; ++r) s += vc_ld(x + r * p.ld + c);
-    float* o = p.out + (long)blockIdx.z * p.batch_stride_out + (long)blockIdx.y * p.ld_out_rows + c;
-    *o = p.accumulate ? (*o + s) : s;
+    red[q][cl] = s;
+    vc_sync();
+    if (q == 0 && live) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        float* o = p.out + (long)blockIdx.z * p.batch_stride_out + (long)blockIdx.y * p.ld_out_rows + c;
+        *o = p.accumulate ? (*o + t) : t;
+    }
 }
 
 // ---- elementwise: dpre = d * (1 - y^2)   (tanh backward; y fp32)

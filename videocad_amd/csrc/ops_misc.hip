@@ -74,13 +74,13 @@ int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, i
     float* wsA = ws; float* wsB = ws + (long)batch * VC_CEIL_DIV(rows, 128) * cols;
     bool useA = true;
     while (true) {
-        const bool last = cur_rows <= 128;
-        const long nblk = last ? 1 : VC_CEIL_DIV(cur_rows, 128);
+        const bool last = cur_rows <= COLSUM_ROWS;
+        const long nblk = last ? 1 : VC_CEIL_DIV(cur_rows, COLSUM_ROWS);
         ColsumParams p;
-        p.x = cur; p.ld = cur_ld; p.rows = cur_rows; p.cols = cols; p.batch_stride_x = cur_bs; p.rows_per_block = 128;
+        p.x = cur; p.ld = cur_ld; p.rows = cur_rows; p.cols = cols; p.batch_stride_x = cur_bs; p.rows_per_block = COLSUM_ROWS;
         float* dst = last ? out : (useA ? wsA : wsB);
         p.out = dst; p.ld_out_rows = last ? 0 : cols; p.batch_stride_out = last ? bstride_out : nblk * cols; p.accumulate = last ? accumulate : 0;
-        dim3 g(VC_CEIL_DIV(cols, 256), (unsigned)nblk, batch);
+        dim3 g(VC_CEIL_DIV(cols, 64), (unsigned)nblk, batch);
         if (cur_t == VC_F32) VC_LAUNCH((colsum_pass_kernel<float>), g, dim3(256), 0, s, p);
         else VC_LAUNCH((colsum_pass_kernel<vc_bf16>), g, dim3(256), 0, s, p);
         if (last) break;
