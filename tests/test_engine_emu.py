@@ -110,6 +110,12 @@ def test_engine_fp8_forward_mode(emu):
     loss, _ = eng.loss(c8, p8, actions[:, 1:], U.LABEL_W)
     eng.backward()
     assert torch.isfinite(loss).all() and torch.isfinite(eng.grads).all() and float(eng.grads.abs().sum()) > 0
+    # cached incremental inference runs the same fp8 Linears (per-row quantisation blocks: a row's result does not depend on the batch)
+    T = an.shape[1]
+    eng.infer_begin(cad, 1, T)
+    for t in range(T):
+        ci, pi = eng.infer_step(t, frames[:, t], an[:, t])
+        assert U.relerr(pi, p8[:, t]) < 2e-2 and U.relerr(ci, c8[:, t]) < 2e-2, (t, U.relerr(pi, p8[:, t]))
     eng.set_fp8(False)
     c2, p2 = eng.forward(frames[:, :-1], an, cad)
     assert torch.equal(p2, p_bf) and torch.equal(c2, c_bf)

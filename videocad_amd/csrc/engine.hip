@@ -1037,7 +1037,8 @@ static int infer_begin_any(vcad_engine* e, const void* cad, int u8, int B, int T
     const float keep_p = e->drop_p; e->drop_p = 0.f;       // inference = model.eval()
     vc_stream_t s = (vc_stream_t)stream; Ctx cx{e, s}; const vcad_config& c = e->c;
     const int H = c.hidden_size, D = c.vit_dim;
-    int rc = vit_forward(cx, 1, cad, 1, (long)c.image_size * c.image_size);
+    int rc = cx.refresh_q8();                                 // (VCAD_FP8: quantised weight copies, no-op otherwise)
+    if (!rc) rc = vit_forward(cx, 1, cad, 1, (long)c.image_size * c.image_size);
     if (!rc) { Epi ep; ep.bias = cx.Pf(e->o_ei_b); rc = cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep); }
     if (!rc && c.enable_past_actions && c.enable_past_states) {
         Epi ep; ep.bias = cx.Pf(e->o_ip_b);
@@ -1081,6 +1082,7 @@ int vcad_infer_step(vcad_engine* e, int t, const void* frame, int64_t frame_bstr
     e->in_frames = frame; e->in_fbstride = frame_bstride; e->in_actions = action_norm; e->in_u8 = e->infer_u8;
     auto body = [&]() -> int {
         if (ps) {
+            CK(cx.refresh_q8());
             CK(vit_forward(cx, 0, frame, 1, frame_bstride));
             Epi ep; ep.bias = cx.Pf(e->o_es_b); ep.rowadd = ts; ep.rdiv = 1; ep.rmod = 1; ep.ldrow = H; ep.act = VC_ACT_TANH;
             CK(cx.lin_fwd(cx.AT(e->va[0].e, D), cx.W(e->o_es_w, D), cx.A32(e->ui, H), B, H, D, ep));
