@@ -54,14 +54,14 @@ static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     bool ok = t == VC_BF16 && D == AM_D && p.Tq == p.Tk && p.Tq <= AM_T && !p.causal && clampw(p) >= p.Tk && !p.qpos && !p.kv_rows &&
               al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
     if (!bwd) return ok && al(p.o, p.ldo);
-    return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
+    return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv && al(p.dq, p.lddq) && al(p.dk, p.lddk) && al(p.dv, p.lddv);   // (16-byte row stores)
 }
 // decoder attention on the matrix cores (attn_mfma.h): bf16, head dim 256, causal (+ window band), T <= 64
 static bool dec_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
     bool ok = t == VC_BF16 && (D == 4 * AM_D || D == 2 * AM_D) && p.Tq == p.Tk && p.Tq <= AM_T && p.causal && !p.qpos && !p.kv_rows && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
     if (!bwd) return ok && al(p.o, p.ldo);
-    return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv;
+    return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv && al(p.dq, p.lddq) && al(p.dk, p.lddk) && al(p.dv, p.lddv);   // (16-byte row stores)
 }
 // ... and for 64 < T <= 192 (key-block loop)
 static bool dec_long_ok(int t, int D, const AttnParams& p, bool bwd) {
