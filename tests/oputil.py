@@ -193,6 +193,26 @@ def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=
         assert relerr(dqkv[:, :, i], g) < tolb, ("attn bwd", i, relerr(dqkv[:, :, i], g))
 
 
+def check_attention_single_query(lib, device, B, H, Tk, dt, seed=0):
+    """the cls-only last ViT layer: ONE query (token 0 of every image) against all Tk keys; q / o addressed like the engine does (row
+    stride = one whole image)"""
+    D = 64
+    scale = 1.0 / math.sqrt(D)
+    qkv = rnd((B, Tk, 3, H, D), device, dt, seed=seed)
+    ld = 3 * H * D; es = qkv.element_size(); base = qkv.data_ptr()
+    o = torch.zeros(B, H, D, dtype=dt, device=device)
+    lse = torch.empty(B, H, device=device)
+    rc = lib.vcad_op_attention_fwd(TD[dt], D, C.c_void_p(base), C.c_void_p(base + H * D * es), C.c_void_p(base + 2 * H * D * es), ptr(o),
+                                   Tk * ld, ld, ld, H * D, ptr(lse), B, H, 1, Tk, Tk, 0, scale, stream_of(device))
+    L.check(lib, rc, "attn_fwd (single query)")
+    q = qkv[:, 0, 0].double().cpu(); k = qkv[:, :, 1].double().cpu(); v = qkv[:, :, 2].double().cpu()      # [B,H,D], [B,Tk,H,D]
+    sc = torch.einsum("bhd,bkhd->bhk", q, k) * scale
+    ref = torch.einsum("bhk,bkhd->bhd", torch.softmax(sc, -1), v)
+    tol = 3e-6 if dt == torch.float32 else 6e-3
+    assert relerr(o, ref) < tol, ("attn fwd single query", relerr(o, ref))
+    assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ MXFP8 (csrc/gemm_mx8.h)
 def mx8_quant_ref(x):
     """[rows, cols] float -> (e4m3 bytes [rows, cols] uint8, E8M0 scale bytes [rows, cols/32] uint8): the OCP MX rule the kernel

@@ -128,6 +128,13 @@ def test_layernorm(emu, C_, dt):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_single_query(emu, dt):
+    """cls-only last ViT layer (one query per image and head, 50 keys): bf16 takes the dedicated kernel, fp32 the wave-per-row one"""
+    U.check_attention_single_query(emu, "cpu", 5, 16, 50, dt)
+    U.check_attention_single_query(emu, "cpu", 3, 2, 64, dt, seed=3)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 def test_attention_vit_shape(emu, dt):
     U.check_attention(emu, "cpu", 2, 2, 50, 64, window=50, causal=0, dt=dt)
 

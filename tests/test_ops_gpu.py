@@ -137,6 +137,13 @@ def test_attention_vit(hip, dt):
     U.check_attention(hip, DEV, 6, 16, 50, 64, window=50, causal=0, dt=dt)
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_single_query(hip, dt):
+    """cls-only last ViT layer (one query per image and head, 50 keys): bf16 takes the dedicated kernel, fp32 the wave-per-row one"""
+    U.check_attention_single_query(hip, DEV, 5, 16, 50, dt)
+    U.check_attention_single_query(hip, DEV, 3, 2, 64, dt, seed=3)
+
+
 @pytest.mark.parametrize("T", [8, 64, 186])
 def test_attention_decoder_causal(hip, T):
     U.check_attention(hip, DEV, 2, 4, T, 256, window=T, causal=1, dt=F32)

@@ -254,6 +254,60 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_kv_kernel(AttnParams p) {
 }
 
 
+// ---- single-query attention forward, bf16, D = 64 (the cls-only last ViT layer: one query against <= 64 keys per (frame, head)).  One wave per
+// (batch, head): lane = key for the scores (each lane walks its own K row), then the V rows are read as 16-byte pieces, eight rows per
+// instruction, and the eight row groups are folded with three xor-shuffles — the wave-per-row kernel above read V two bytes per lane, one
+// row per instruction (208 us for the frame ViT's 32 768 heads; r02).
+VC_KERNEL __launch_bounds__(256) void attn_fwd_single_query_bf16_kernel(AttnParams p) {
+    constexpr int D = 64;
+    VC_SHARED float qs[4][D];
+    VC_SHARED float ps[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wid = (long)blockIdx.x * 4 + wave;
+    if (wid >= (long)p.B * p.H) return;
+    const int h = (int)(wid % p.H); const long b = wid / p.H;
+    const vc_bf16* qrow = (const vc_bf16*)p.q + b * p.ldq + h * D;                     // Tq = 1: query row b
+    qs[wave][lane] = vc_ld(qrow + lane);
+    vc_wave_barrier();
+    const bool on = lane < p.Tk;
+    const vc_bf16* krow = (const vc_bf16*)p.k + (b * p.Tk + (on ? lane : 0)) * p.ldk + h * D;
+    const float sc = on ? attn_dot_row<vc_bf16, D>(krow, qs[wave]) * p.scale : -INFINITY;
+    const float m = vc_wave_max(sc);
+    float e = on ? expf(sc - m) : 0.f;
+    const float l = vc_wave_sum(e);
+    if (p.drop.key && on) e *= vc_drop_mul(p.drop, wid * p.Tk + lane);                 // Tq = 1: idx = (b*H+h)*Tk + j (dropout acts on the normalised probabilities)
+    ps[wave][lane] = e;
+    vc_wave_barrier();
+    const int rg = lane >> 3, cg = lane & 7;
+    const vc_bf16* vbase = (const vc_bf16*)p.v + b * p.Tk * p.ldv + h * D + cg * 8;
+    vc_u32x4 vv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { const int r = it * 8 + rg; vv[it] = *reinterpret_cast<const vc_u32x4*>(vbase + (long)(r < p.Tk ? r : p.Tk - 1) * p.ldv); }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + rg;
+        const float w = r < p.Tk ? ps[wave][r] : 0.f;
+        const uint32_t u[4] = {vv[it].x, vv[it].y, vv[it].z, vv[it].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[2 * k] += w * vc_bits_f32(u[k] << 16); acc[2 * k + 1] += w * vc_bits_f32(u[k] & 0xFFFF0000u); }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += vc_shfl_xor(acc[j], off);
+    if (lane < 8) {
+        const float inv = 1.0f / l;
+        vc_u32x4 o;
+        o.x = vc_pack_bf16x2(acc[0] * inv, acc[1] * inv); o.y = vc_pack_bf16x2(acc[2] * inv, acc[3] * inv);
+        o.z = vc_pack_bf16x2(acc[4] * inv, acc[5] * inv); o.w = vc_pack_bf16x2(acc[6] * inv, acc[7] * inv);
+        *reinterpret_cast<vc_u32x4*>((vc_bf16*)p.o + b * p.ldo + h * D + lane * 8) = o;
+    }
+    if (p.lse && lane == 0) p.lse[wid] = m + logf(l);
+}
+
 // ---- single-query attention backward (the ViT's last layer only consumes the cls token: Tq = 1).  One wave per
 // (batch, head): lane = key for the scores / dS (each lane walks its own K and V row), then lane = DPL output dims for
 // dq; dk_j = dS_j q and dv_j = P_j dO are written by the key's lane.  Replaces B*H*Tk one-key waves by B*H waves.
@@ -289,6 +343,51 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_single_query_kernel(AttnParams p)
     dss[wave][lane] = ds;
     pss[wave][lane] = pr * ms;
     vc_wave_barrier();
+    if constexpr (sizeof(T) == 2 && DPL == 1) {
+        // bf16, D = 64 (r02): eight key rows per instruction, 16 bytes per lane — dk_j = scale dS_j q, dv_j = P_j dO as whole 128-byte rows,
+        // dq = scale sum_j dS_j k_j folded over the eight row groups with three xor-shuffles
+        const int rg = lane >> 3, cg = lane & 7;
+        float qv[8], dov[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { qv[j] = qs[wave][cg * 8 + j] * p.scale; dov[j] = dos[wave][cg * 8 + j]; }
+        const T* kb = (const T*)p.k + b * p.Tk * p.ldk + h * D + cg * 8;
+        vc_u32x4 kk[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) { const int r = it * 8 + rg; kk[it] = *reinterpret_cast<const vc_u32x4*>(kb + (long)(r < p.Tk ? r : p.Tk - 1) * p.ldk); }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 8 + rg;
+            const bool live = r < p.Tk;
+            const float dsj = live ? dss[wave][r] : 0.f, pj = live ? pss[wave][r] : 0.f;
+            const uint32_t u[4] = {kk[it].x, kk[it].y, kk[it].z, kk[it].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += dsj * vc_bits_f32(u[k] << 16); acc[2 * k + 1] += dsj * vc_bits_f32(u[k] & 0xFFFF0000u); }
+            if (live) {
+                vc_u32x4 wk, wv;
+                wk.x = vc_pack_bf16x2(dsj * qv[0], dsj * qv[1]); wk.y = vc_pack_bf16x2(dsj * qv[2], dsj * qv[3]);
+                wk.z = vc_pack_bf16x2(dsj * qv[4], dsj * qv[5]); wk.w = vc_pack_bf16x2(dsj * qv[6], dsj * qv[7]);
+                wv.x = vc_pack_bf16x2(pj * dov[0], pj * dov[1]); wv.y = vc_pack_bf16x2(pj * dov[2], pj * dov[3]);
+                wv.z = vc_pack_bf16x2(pj * dov[4], pj * dov[5]); wv.w = vc_pack_bf16x2(pj * dov[6], pj * dov[7]);
+                *reinterpret_cast<vc_u32x4*>((T*)p.dk + (b * p.Tk + r) * p.lddk + h * D + cg * 8) = wk;
+                *reinterpret_cast<vc_u32x4*>((T*)p.dv + (b * p.Tk + r) * p.lddv + h * D + cg * 8) = wv;
+            }
+        }
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += vc_shfl_xor(acc[j], off);
+        if (lane < 8) {
+            vc_u32x4 o;
+            o.x = vc_pack_bf16x2(acc[0] * p.scale, acc[1] * p.scale); o.y = vc_pack_bf16x2(acc[2] * p.scale, acc[3] * p.scale);
+            o.z = vc_pack_bf16x2(acc[4] * p.scale, acc[5] * p.scale); o.w = vc_pack_bf16x2(acc[6] * p.scale, acc[7] * p.scale);
+            *reinterpret_cast<vc_u32x4*>((T*)p.dq + b * p.lddq + h * D + lane * 8) = o;
+        }
+        if (lane == 0) p.delta[wid] = dsum;
+        return;
+    }
     {   // dk_j = scale * dS_j * q ;  dv_j = P_j * dO   — lane = dims, so every key row is one coalesced store
         float qv[DPL], dov[DPL];
 #pragma unroll

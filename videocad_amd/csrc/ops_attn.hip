@@ -92,6 +92,11 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     if (int rc = check_rows_aligned(t, p, false)) return rc;
     ProfScope ps(VC_CAT_ATTN, attn_flops(p, D), attn_bytes(p, D, t, false), s);
+    if (t == VC_BF16 && p.Tq == 1 && !p.causal && p.Tk <= 64 && D == 64 && p.window >= p.Tk && !p.qpos && !p.kv_rows && g_vit_bwd_variant == 0 &&
+        ((uintptr_t)p.o % 16 == 0) && (p.ldo % 8 == 0)) {         // cls-only query (last ViT layer)
+        VC_LAUNCH(attn_fwd_single_query_bf16_kernel, dim3((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4)), dim3(256), 0, s, p);
+        return VC_OK;
+    }
     if (mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {      // two waves per (frame, head)
         if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH((attn_vit_fwd2_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
@@ -135,6 +140,10 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (int rc = check_rows_aligned(t, p, true)) return rc;
     ProfScope ps(VC_CAT_ATTN, 2.5 * attn_flops(p, D), attn_bytes(p, D, t, true), s);
     if (p.Tq == 1 && !p.causal && p.Tk <= 64 && D == 64 && p.window >= p.Tk) {     // cls-only query (last ViT layer)
+        if (t == VC_BF16) {                                        // (its bf16 form stores 16-byte row pieces)
+            auto bad = [](const void* q, long ld) { return ((uintptr_t)q % 16) || (ld % 8); };
+            if (bad(p.dq, p.lddq) || bad(p.dk, p.lddk) || bad(p.dv, p.lddv)) { vc_set_error("attention backward (single query): dq/dk/dv head slices must be 16-byte aligned"); return VC_ERR_ARG; }
+        }
         dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4));
         if (t == VC_BF16) VC_LAUNCH((attn_bwd_single_query_kernel<vc_bf16, 1>), g, dim3(256), 0, s, p);
         else VC_LAUNCH((attn_bwd_single_query_kernel<float, 1>), g, dim3(256), 0, s, p);
