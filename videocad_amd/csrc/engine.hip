@@ -283,6 +283,9 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 // ---------------------------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------
+// the ViT MLP's GELU / GELU' as their own passes behind plain GEMMs (bf16 mode): 1 = yes (default), 0 = fused into the GEMM epilogues (r01; A/B)
+static int g_split_gelu = 1;
+extern "C" void vcad_debug_split_gelu(int on) { g_split_gelu = on ? 1 : 0; }
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CK_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -446,7 +449,11 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.ao, inner), wl.ow, cx.A32(l.xm, D), (int)R, D, inner, ep));
               else CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
             CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
-            { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
+            if (!q8 && e->dt == VC_BF16 && g_split_gelu) {     // bf16: plain GEMM (persistent kernel) -> z, then the activation pass (norm.h: act_fwd_bf16_kernel)
+                { Epi ep; ep.bias = cx.Pf(wl.b1); CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.z, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
+                CK(vc_act_fwd_bf16(l.z, l.g, R, c.vit_mlp, VC_ACT_GELU, d_act, cx.s));
+            } else {
+              Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_f, D), wl.w1, cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep));
               else CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
             { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
@@ -500,8 +507,11 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         have_du = false;
         CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
-          if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep));
-          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, ep)); }
+          const bool split = e->dt == VC_BF16 && g_split_gelu && !cls_only;      // bf16: plain dgrad, then the activation-derivative pass
+          const Epi epg = split ? Epi() : ep;
+          if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
+          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
+          if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s)); }
         CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
         if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         else CK(cx.lin_dgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));

@@ -302,6 +302,51 @@ VC_KERNEL __launch_bounds__(256) void cast_kernel(const float* x, TY* y, long n)
     for (int j = 0; j < 4; ++j) if (i + j < n) vc_st(y + i + j, x[i + j]);
 }
 
+// ---- g = dropout(act(z)) and dz = (dz * dropmask) * act'(z), bf16, 8 elements (16 bytes) per thread: the MLP activation of the ViT as its own
+// pass (r02).  Fused into the register-staged GEMM's epilogue these cost 200 / 235 us per call (that kernel overlaps 54 GFLOP of MFMA, ~60 us
+// of erf / exp / hash VALU work and 320 MB of traffic poorly); the plain GEMM on the persistent kernel plus this pass is 68 + ~60 us.
+// Element index = row * cols + col of the compact tensor = the index the fused epilogue hashes, so the masks are the same bits.
+VC_DEV void vc_unpack8(const vc_u32x4& q, float (&v)[8]) {
+    const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = vc_bits_f32(u[k] << 16); v[2 * k + 1] = vc_bits_f32(u[k] & 0xFFFF0000u); }
+}
+VC_DEV vc_u32x4 vc_pack8(const float (&v)[8]) {
+    vc_u32x4 q; q.x = vc_pack_bf16x2(v[0], v[1]); q.y = vc_pack_bf16x2(v[2], v[3]); q.z = vc_pack_bf16x2(v[4], v[5]); q.w = vc_pack_bf16x2(v[6], v[7]);
+    return q;
+}
+VC_KERNEL __launch_bounds__(256) void act_fwd_bf16_kernel(const vc_bf16* z, vc_bf16* g, long n8, int act, vc_drop d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8];
+    vc_unpack8(*reinterpret_cast<const vc_u32x4*>(z + i * 8), v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = vc_apply_act(v[k], act);
+    if (d.key) {
+        float m0[4], m1[4];
+        vc_drop_mul4(d, (uint32_t)(i * 8), m0); vc_drop_mul4(d, (uint32_t)(i * 8 + 4), m1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] *= m0[k]; v[4 + k] *= m1[k]; }
+    }
+    *reinterpret_cast<vc_u32x4*>(g + i * 8) = vc_pack8(v);
+}
+VC_KERNEL __launch_bounds__(256) void dact_bwd_bf16_kernel(vc_bf16* dz, const vc_bf16* z, long n8, int kind, vc_drop d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], s[8];
+    vc_unpack8(*reinterpret_cast<const vc_u32x4*>(dz + i * 8), v);
+    vc_unpack8(*reinterpret_cast<const vc_u32x4*>(z + i * 8), s);
+    if (d.key) {
+        float m0[4], m1[4];
+        vc_drop_mul4(d, (uint32_t)(i * 8), m0); vc_drop_mul4(d, (uint32_t)(i * 8 + 4), m1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] *= m0[k]; v[4 + k] *= m1[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = vc_apply_dact(v[k], s[k], kind);
+    *reinterpret_cast<vc_u32x4*>(dz + i * 8) = vc_pack8(v);
+}
+
 // ---- dst[c][r] = src[r][c] (bf16): the transposed weight shadows of the frame ViT (engine.hip: wT); 32x32 tiles through LDS
 VC_KERNEL __launch_bounds__(256) void transpose_bf16_kernel(const vc_bf16* src, vc_bf16* dst, int rows, int cols) {
     VC_SHARED uint16_t tile[32 * 33];

@@ -60,6 +60,9 @@ int vc_embed_action(int ty, const float* a, const float* W, const float* b, cons
 int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s);
 int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s);
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
+// g = dropout(act(z)) / dz = (dz * dropmask) * act'(z): compact bf16 [rows, cols], masks indexed like the fused GEMM epilogue
+int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_drop d, vc_stream_t s);
+int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s);
 // grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]

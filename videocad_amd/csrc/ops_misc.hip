@@ -128,6 +128,30 @@ int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
     return VC_OK;
 }
 
+// the ViT MLP's activation as its own pass (norm.h): compact bf16 tensors, cols % 8 == 0, 16-byte aligned
+static int act_check(const void* a, const void* b, long rows, int cols, const char* what) {
+    if (cols % 8 || ((uintptr_t)a % 16) || ((uintptr_t)b % 16) || (double)rows * cols >= 4294967296.0) { vc_set_error("%s: needs 16-byte aligned compact bf16 tensors, cols %% 8 == 0, < 2^32 elements", what); return VC_ERR_ARG; }
+    return VC_OK;
+}
+int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_drop d, vc_stream_t s) {
+    if (rows <= 0) return VC_OK;
+    if (int rc = act_check(z, g, rows, cols, "act_fwd")) return rc;
+    if (act == VC_ACT_GELU) act = VC_ACT_GELU_FAST;                 // bf16 mode: the cheap erf of the GEMM epilogues (gemm.h)
+    ProfScope ps(VC_CAT_OTHER, 0, (double)rows * cols * 4, s);
+    const long n8 = rows * cols / 8;
+    VC_LAUNCH(act_fwd_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(n8, 256)), dim3(256), 0, s, (const vc_bf16*)z, (vc_bf16*)g, n8, act, d);
+    return VC_OK;
+}
+int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s) {
+    if (rows <= 0) return VC_OK;
+    if (int rc = act_check(dz, z, rows, cols, "dact_bwd")) return rc;
+    if (kind == VC_ACT_GELU) kind = VC_ACT_GELU_FAST;
+    ProfScope ps(VC_CAT_OTHER, 0, (double)rows * cols * 6, s);
+    const long n8 = rows * cols / 8;
+    VC_LAUNCH(dact_bwd_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(n8, 256)), dim3(256), 0, s, (vc_bf16*)dz, (const vc_bf16*)z, n8, kind, d);
+    return VC_OK;
+}
+
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s) {
     if (njobs <= 0) return VC_OK;
     ProfScope ps(VC_CAT_OTHER, 0, 0, s);
