@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--gemm-mid", type=int, default=-1, help="A/B: 0 = no six-stage DMA-ring kernel for mid-size GEMMs, -1 = automatic")
     ap.add_argument("--fp8", action="store_true", help="VCAD_FP8 forward mode: the ViT Linear layers on the MXFP8 matrix cores (not the headline number)")
     ap.add_argument("--split-gelu", type=int, default=1, help="A/B: 0 = GELU / GELU' fused into the MLP GEMM epilogues (r01), 1 = own passes behind plain GEMMs")
+    ap.add_argument("--no-side", type=int, default=0, help="A/B: 1 = no library side stream (CAD ViT and deferred wgrads serialised on the caller's stream)")
     ap.add_argument("--gemm-wide", type=int, default=-1, help="A/B switch: 0 = 256x128 tile only, -1 = automatic (default)")
     ap.add_argument("--uint8-frames", action="store_true", help="feed uint8 grayscale pixels (normalised inside the patchify kernel) instead of fp32 frames")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (pinned host -> HBM staged) measurement reported beside the headline")

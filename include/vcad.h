@@ -163,6 +163,7 @@ void vcad_debug_gemm_mid(int mode);        /* six-stage DMA-ring kernel for mid-
 long vcad_debug_gemm_mid_launches(void);
 void vcad_debug_gemm_waves(int n);         /* 256-wide tile of the persistent kernel: 8 waves (64 x 128 each) or 4 waves (128 x 128 each) */
 void vcad_debug_split_gelu(int on);        /* ViT MLP activation as its own pass behind a plain GEMM (1, default) or fused into the GEMM epilogue (0) */
+void vcad_debug_no_side_stream(int on);    /* A/B: keep the CAD ViT / deferred weight gradients on the caller's stream */
 void vcad_debug_gemm_policy(int bits);   /* A/B of dispatcher rules: 1 = activation epilogues on the persistent kernel, 2 = small-tile-count wgrads too */
 /* XCD column groups of the persistent kernel's forward-layout launches: -1 automatic, 0 never, 2 / 4 / 8 forced */
 void vcad_debug_gemm_xcd_cols(int xn);

@@ -200,6 +200,7 @@ def run(args):
     eng.lib.vcad_debug_attn_variant(getattr(args, "attn_variant", 0))
     eng.lib.vcad_debug_gemm_mid(getattr(args, "gemm_mid", -1))
     eng.lib.vcad_debug_split_gelu(getattr(args, "split_gelu", 1))
+    eng.lib.vcad_debug_no_side_stream(getattr(args, "no_side", 0))
     if getattr(args, "fp8", False):
         eng.set_fp8(True)            # VCAD_FP8 forward mode: ViT Linears on the block-scaled fp8 matrix cores (BASELINE configs[4] variant)
     bd = synthetic_batch(B, T, 1000 * 2 + rank, device, uint8=args.uint8_frames)

@@ -286,6 +286,8 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 // the ViT MLP's GELU / GELU' as their own passes behind plain GEMMs (bf16 mode): 1 = yes (default), 0 = fused into the GEMM epilogues (r01; A/B)
 static int g_split_gelu = 1;
 extern "C" void vcad_debug_split_gelu(int on) { g_split_gelu = on ? 1 : 0; }
+static int g_no_side = 0;           // A/B: 1 = the CAD ViT and the deferred weight gradients stay on the caller's stream
+extern "C" void vcad_debug_no_side_stream(int on) { g_no_side = on ? 1 : 0; }
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CK_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -398,7 +400,7 @@ struct Ctx {
 
 // The side stream of lane 1 (created on first use).  Without one (CPU emulator) the CAD ViT simply runs in line.
 bool ensure_side(vcad_engine* e) {
-    if (!vc_has_side_streams() || e->no_side || vc_profile_on()) return false;
+    if (!vc_has_side_streams() || e->no_side || g_no_side || vc_profile_on()) return false;
     if (!e->side_ok) {
         if (vc_stream_create(&e->side) || vc_event_create(&e->ev_fork) || vc_event_create(&e->ev_fork2) || vc_event_create(&e->ev_join)) return false;
         e->side_ok = true;

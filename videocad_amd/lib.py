@@ -69,6 +69,7 @@ PROTOTYPES = {
     "vcad_debug_gemm_variant": (None, [_i]),
     "vcad_debug_gemm_wide": (None, [_i]),
     "vcad_debug_gemm_policy": (None, [_i]),
+    "vcad_debug_no_side_stream": (None, [_i]),
     "vcad_debug_split_gelu": (None, [_i]),
     "vcad_debug_gemm_waves": (None, [_i]),
     "vcad_debug_gemm_mid": (None, [_i]),
