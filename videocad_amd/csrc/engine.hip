@@ -552,11 +552,15 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         {   // LN(512) backward through the embed mapping
             LnBwdParams p; memset(&p, 0, sizeof(p));
             p.dy = dx; p.lddy = D; p.x = a.pe; p.ldx = D; p.stats = a.stat2; p.gamma = cx.Pf(w.ln2w);
-            p.dx32 = cx.L().t_dpe; p.lddx32 = D; p.rows = Rp; p.P = P;
-            CK(vc_ln_bwd(VC_F32, VC_F32, VC_F32, D, 2, p, cx.L().scr_lnpart, cx.Gf(w.ln2w), cx.Gf(w.ln2b), cx.L().scr_colsum, cx.s));
+            p.rows = Rp; p.P = P;
+            // bf16 mode: the gradient entering the patch-embed Linear is emitted in bf16 (the GEMMs rounded it to bf16 while staging anyway — same
+            // values), so its wgrad / dgrad are all-bf16 problems for the persistent kernel instead of fp32-source ones for the register-staged one
+            if (e->dt == VC_BF16) { p.dxt = cx.L().t_dpe; p.lddxt = D; } else { p.dx32 = cx.L().t_dpe; p.lddx32 = D; }
+            CK(vc_ln_bwd(VC_F32, VC_F32, e->dt == VC_BF16 ? VC_BF16 : VC_F32, D, 2, p, cx.L().scr_lnpart, cx.Gf(w.ln2w), cx.Gf(w.ln2b), cx.L().scr_colsum, cx.s));
         }
-        CK(cx.lin_wgrad(cx.A32(cx.L().t_dpe, D), cx.AT(a.pn, pd), cx.Gf(w.pew), pd, cx.Gf(w.peb), (int)Rp, D, pd));
-        CK(cx.lin_dgrad(cx.A32(cx.L().t_dpe, D), cx.W(w.pew, pd), cx.AT(cx.L().t_dpn, pd), (int)Rp, D, pd, Epi()));
+        const Mat dpe = e->dt == VC_BF16 ? cx.AT(cx.L().t_dpe, D) : cx.A32(cx.L().t_dpe, D);
+        CK(cx.lin_wgrad(dpe, cx.AT(a.pn, pd), cx.Gf(w.pew), pd, cx.Gf(w.peb), (int)Rp, D, pd));
+        CK(cx.lin_dgrad(dpe, cx.W(w.pew, pd), cx.AT(cx.L().t_dpn, pd), (int)Rp, D, pd, Epi()));
         {   // LN(1024) parameter gradients (input frames need no gradient)
             LnBwdParams p; memset(&p, 0, sizeof(p));
             p.dy = cx.L().t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
