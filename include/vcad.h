@@ -13,7 +13,9 @@
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); nothing here synchronises the device
  *   - return value 0 = ok; non-zero = error, text via vcad_last_error() (thread-local)
  *   - dtype: VCAD_F32 = exact-fp32 parity mode (f32 MFMA), VCAD_BF16 = bf16 MFMA with fp32 accumulate,
- *     fp32 residual stream, fp32 master weights + bf16 weight shadow
+ *     fp32 residual stream, fp32 master weights + bf16 weight shadow; VCAD_BF16X3 = fp32 tensors everywhere (like VCAD_F32, no
+ *     shadow), every Linear on the bf16 matrix cores with hi/lo operand splits (three MFMAs per product, fp32 accumulate): the
+ *     in-tolerance throughput mode (logits within 1e-3 of the fp32 reference, reference main.py:28 allows TF32 there)
  */
 #ifndef VCAD_H
 #define VCAD_H
@@ -23,7 +25,7 @@
 extern "C" {
 #endif
 
-enum { VCAD_F32 = 0, VCAD_BF16 = 1 };
+enum { VCAD_F32 = 0, VCAD_BF16 = 1, VCAD_BF16X3 = 2 };
 
 typedef struct vcad_config {
     /* AutoRegressiveTransformer.__init__ kwargs (reference model/autoregressive_transformer.py:11-35) */
@@ -31,7 +33,7 @@ typedef struct vcad_config {
     int num_classes, num_params, num_params_values, max_ep_len;
     /* vit_pytorch.ViT(...) constructor call at reference model/trajectory_model.py:54-65 */
     int vit_dim, vit_depth, vit_heads, vit_dim_head, vit_mlp, image_size, patch_size;
-    int dtype;                     /* VCAD_F32 | VCAD_BF16 */
+    int dtype;                     /* VCAD_F32 | VCAD_BF16 | VCAD_BF16X3 */
     /* wiring flags of forward (reference model/autoregressive_transformer.py:149-213) */
     int enable_past_actions, enable_past_states, enable_timestep_embedding;
 } vcad_config;

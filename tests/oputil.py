@@ -12,7 +12,8 @@ from videocad_amd import lib as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_PATH = os.path.join(ROOT, "tests", "emu", "libvcad_emu.so")
-TD = {torch.float32: L.VCAD_F32, torch.bfloat16: L.VCAD_BF16}
+X3 = "bf16x3"            # GEMM compute type of the VCAD_BF16X3 mode: fp32 tensors, hi/lo-split bf16 MFMAs
+TD = {torch.float32: L.VCAD_F32, torch.bfloat16: L.VCAD_BF16, X3: L.VCAD_BF16X3}
 
 
 def load_emu():
@@ -76,13 +77,15 @@ def relerr(a, b):
 def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0, bias=False, act=0, residual=False, seed=0,
                pad=0, tol=None, splitk=True):
     """C = act(opA @ opB^T + bias) + residual ; operands stored with `pad` extra leading-dimension elements."""
-    sa = ct if sa is None else sa
-    to = ct if to is None else to
-    sb = ct if sb is None else sb
+    x3 = ct == X3
+    st = torch.float32 if x3 else ct
+    sa = st if sa is None else sa
+    to = st if to is None else to
+    sb = st if sb is None else sb
     A_log = rnd((M, K), "cpu", seed=seed + 1)
     B_log = rnd((N, K), "cpu", seed=seed + 2)
-    A_q = A_log.to(sa).float() if ct == torch.float32 else A_log.to(torch.bfloat16).float()
-    B_q = B_log.to(sb).float() if ct == torch.float32 else B_log.to(torch.bfloat16).float()
+    A_q = A_log.to(sa).float() if ct == torch.float32 or x3 else A_log.to(torch.bfloat16).float()
+    B_q = B_log.to(sb).float() if ct == torch.float32 or x3 else B_log.to(torch.bfloat16).float()
 
     def store(x_log, tr, dt):
         x = x_log.t().contiguous() if tr else x_log.contiguous()
@@ -116,6 +119,8 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
         tol = 2e-6 if (ct == torch.float32) else (6e-3 if to == torch.bfloat16 else 2e-5)
         if ct == torch.bfloat16 and to == torch.float32:
             tol = 1e-5
+        if x3:
+            tol = 1.5e-5          # three-term split: ~2^-17 per operand + the dropped lo*lo term, against the UNROUNDED fp32 operands
     assert err < tol, f"gemm M{M} N{N} K{K} ct={ct} sa={sa} to={to} tra={tra} trb={trb}: rel err {err:.3e} > {tol}"
     if pad:
         assert bool((Cbuf[:, N:].float() == 7.0).all()), "gemm wrote outside the N columns"

@@ -78,6 +78,37 @@ def test_engine_step_matches_oracle_f32(emu):
         assert d < 2e-6, (k, d)      # lr = 1e-5: a step is at most ~1e-5; tiny-|g| elements are ill-conditioned
 
 
+def test_engine_step_bf16x3_in_tolerance(emu):
+    """VCAD_BF16X3 (fp32 tensors, hi/lo-split bf16 MFMAs in every Linear): the whole step against the fp32 oracle — logits two orders
+    inside north_star's 1e-3, arg-max exact, gradients / clip norm / post-Adam weights at the three-term split's accuracy"""
+    cfg = small_cfg()
+    eng, weights = build(cfg, L.VCAD_BF16X3, emu)
+    assert eng.shadow is None                                   # fp32 storage: no bf16 weight shadow
+    B, T = 2, 3
+    batch = synth.make_batch(B, T, seed=5, lengths=[4, 3])
+    ot = O.OracleTrainer(weights, cfg)
+    with torch.no_grad():
+        ocmds, opars, _ = ot.forward(batch)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    assert U.relerr(cmds, ocmds) < 5e-5 and U.relerr(pars, opars) < 5e-5, (U.relerr(cmds, ocmds), U.relerr(pars, opars))
+    assert bool((pars.argmax(-1) == opars.argmax(-1)).all()) and bool((cmds.argmax(-1) == ocmds.argmax(-1)).all())
+    loss, met = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    oloss, ometrics, ototal, _, _ = ot.step(batch)
+    assert abs(float(loss[0]) - float(oloss)) < 1e-4 * max(1.0, abs(float(oloss))), (float(loss[0]), float(oloss))
+    eng.backward()
+    worst = ("", 0.0)
+    for k in weights:
+        g = eng.view(k, eng.grads); og = ot.P[k].grad
+        denom = float(og.norm())
+        err = float((g - og).norm()) / (denom + 1e-12) if denom > 0 else float(g.abs().max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < 1e-3, worst
+    norm = eng.optimizer_step(lr=1e-5)
+    assert abs(float(norm[0]) - ototal) / ototal < 2e-4
+
+
 def test_engine_forward_bf16_close(emu):
     cfg = small_cfg(vit_depth=1, num_decoder_layers=1)
     eng, weights = build(cfg, L.VCAD_BF16, emu)

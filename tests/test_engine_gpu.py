@@ -85,6 +85,39 @@ def test_f32_step_matches_reference_goldens(golden_dir, case):
             assert np.abs(sl(eng.view(n)) - gold[k]).max() < 2e-6, n
 
 
+@pytest.mark.parametrize("case", ["c1_full", "c1_ragged"])
+def test_bf16x3_step_in_tolerance_of_reference_goldens(golden_dir, case):
+    """VCAD_BF16X3 — fp32 tensors, every Linear as three hi/lo-split bf16 MFMAs, attention on the f32 matrix cores — against the goldens
+    of the imported reference: north_star's gate (logits within 1e-3 relative, arg-max bit-exact) with a decade to spare, and the whole
+    step (loss, metrics, 309 gradient norms, clip norm, post-Adam weights) at the split's accuracy."""
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["cases"][case]
+    gold = np.load(os.path.join(golden_dir, case + ".npz"))
+    eng = build(L.VCAD_BF16X3)
+    batch, cmds, pars, gc, gp, pcmp = run_case(eng, gold, meta["B"], meta["T"], meta["seed"], meta["lengths"], case == "c1_full")
+    rel_c, rel_p = U.relerr(cmds, gc), U.relerr(pcmp, gp)
+    print(f"\n[measured bf16x3 {case}] logits rel cmd {rel_c:.3e} params {rel_p:.3e}  max abs {float((pcmp - gp).abs().max()):.3e} (logit scale {float(gp.abs().max()):.2f})")
+    assert rel_c < 1e-4 and rel_p < 1e-4, (rel_c, rel_p)
+    assert float((pcmp - gp).abs().max()) < 1e-3 * float(gp.abs().max())
+    assert np.array_equal(pars.argmax(-1).cpu().numpy(), gold["params_argmax"])
+    assert np.array_equal(cmds.argmax(-1).cpu().numpy(), gold["cmds_argmax"])
+    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+    gm = json.loads(str(gold["metrics_json"]))
+    m = met.tolist()
+    assert m[L.MET_PAR_COUNT:L.MET_PAR_COUNT + 6] == gm["param_counts"] and m[L.MET_PAR_CORRECT:L.MET_PAR_CORRECT + 6] == gm["param_corrects"]
+    assert m[L.MET_CORRECT] == gm["correct_predictions"] and m[L.MET_TOTAL] == gm["total_predictions"]
+    eng.backward()
+    rels = [abs(float(eng.view(str(n), eng.grads).double().norm()) - gn) / (gn + 1e-12) for n, gn in zip(gold["grad_names"], gold["grad_norms"])]
+    print(f"[measured bf16x3 {case}] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
+    assert np.max(rels) < 3e-3, np.max(rels)
+    norm = eng.optimizer_step(lr=1e-5)
+    assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < 1e-3 * float(gold["total_grad_norm"])
+    for k in gold.files:
+        if k.startswith("pslice:"):
+            n = k[len("pslice:"):]
+            assert np.abs(sl(eng.view(n)) - gold[k]).max() < 2e-6, n
+
+
 def test_f32_window1_forward(golden_dir):
     gold = np.load(os.path.join(golden_dir, "win1.npz"))
     cfg = dict(O.CANONICAL_CONFIG); cfg["window_size"] = 1
@@ -115,8 +148,9 @@ def test_bf16_step_close_to_goldens(golden_dir, gemm_dma_mode):
     batch, cmds, pars, gc, gp, _ = run_case(eng, gold, 2, 8, 1, None, True)
     mae = float((pars - gp).abs().mean()); rel = U.relerr(pars, gp)
     agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
-    print(f"\n[bf16 vs fp32 reference] params-logit MAE {mae:.3e}  norm-wise rel {rel:.3e}  argmax agreement {agree:.3f}  cmd rel {U.relerr(cmds, gc):.3e}")
-    assert rel < 3e-2 and agree > 0.85
+    print(f"\n[measured bf16 vs fp32 reference] params-logit MAE {mae:.3e}  norm-wise rel {rel:.3e}  argmax agreement {agree:.3f}  cmd rel {U.relerr(cmds, gc):.3e}")
+    # gates at ~1.5x what this mode measures (r02 driver run: rel 3.9e-3, MAE 7.3e-3, 95 of 96 arg-maxes): a regression of the throughput mode fails here
+    assert rel < 6e-3 and mae < 1.2e-2 and agree >= 0.97, (rel, mae, agree)
     loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(gold["loss"])) < 2e-2 * abs(float(gold["loss"]))
     eng.backward()
@@ -124,8 +158,8 @@ def test_bf16_step_close_to_goldens(golden_dir, gemm_dma_mode):
     rels = []
     for n, gn in zip(names, gold["grad_norms"]):
         rels.append(abs(float(eng.view(n, eng.grads).double().norm()) - gn) / (gn + 1e-12))
-    print(f"[bf16] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
-    assert np.median(rels) < 3e-2
+    print(f"[measured bf16] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
+    assert np.median(rels) < 1e-2
     norm = eng.optimizer_step(lr=1e-5)
     assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < 5e-2 * float(gold["total_grad_norm"])
     if gemm_dma_mode[0] == 1:
@@ -141,15 +175,16 @@ def test_fp8_forward_mode_close_to_goldens(golden_dir):
     batch, cmds, pars, gc, gp, _ = run_case(eng, gold, 2, 8, 1, None, True)
     mae = float((pars - gp).abs().mean()); rel = U.relerr(pars, gp)
     agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
-    print(f"\n[fp8 forward vs fp32 reference] params-logit MAE {mae:.3e}  norm-wise rel {rel:.3e}  argmax agreement {agree:.3f}  cmd rel {U.relerr(cmds, gc):.3e}")
-    assert rel < 8e-2 and agree > 0.7
+    print(f"\n[measured fp8 forward vs fp32 reference] params-logit MAE {mae:.3e}  norm-wise rel {rel:.3e}  argmax agreement {agree:.3f}  cmd rel {U.relerr(cmds, gc):.3e}")
+    # ~1.5x the measured values (r02: rel 8.1e-3, MAE 1.5e-2, arg-max 97.9 %)
+    assert rel < 1.3e-2 and mae < 2.3e-2 and agree >= 0.95, (rel, mae, agree)
     loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - float(gold["loss"])) < 5e-2 * abs(float(gold["loss"]))
     eng.backward()
     names = [str(n) for n in gold["grad_names"]]
     rels = [abs(float(eng.view(n, eng.grads).double().norm()) - gn) / (gn + 1e-12) for n, gn in zip(names, gold["grad_norms"])]
-    print(f"[fp8 forward] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
-    assert np.median(rels) < 1e-1
+    print(f"[measured fp8 forward] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
+    assert np.median(rels) < 1.5e-2            # (r02: 5e-3)
     eng.optimizer_step(lr=1e-5)                                  # weights changed: the fp8 copies are rebuilt by the next forward
     c2, p2 = eng.forward(batch["frames"][:, :-1].contiguous(), O.normalize_actions(batch["actions"][:, :-1]), batch["cad_image"])
     assert torch.isfinite(p2).all()

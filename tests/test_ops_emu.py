@@ -44,6 +44,19 @@ def test_gemm_bf16(emu, tra, trb, sa, to):
     U.check_gemm(emu, "cpu", 72, 48, 136, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=8, bias=True, act=2, splitk=False)
 
 
+@pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_bf16x3_layouts(emu, tra, trb):
+    """VCAD_BF16X3: fp32 operands split into hi / lo bf16 planes while staging, three MFMAs per product (gemm.h) — checked against the
+    exact product of the UNROUNDED operands"""
+    U.check_gemm(emu, "cpu", 70, 40, 100, U.X3, tra=tra, trb=trb, pad=4, bias=True, residual=True, splitk=False)
+    U.check_gemm(emu, "cpu", 33, 7, 50, U.X3, tra=tra, trb=trb, pad=1, act=2, splitk=False)       # unaligned rows: element-wise staging path
+
+
+def test_gemm_bf16x3_multi_tile_splitk(emu):
+    U.check_gemm(emu, "cpu", 130, 136, 70, U.X3, act=1, bias=True, pad=4)
+    U.check_gemm(emu, "cpu", 24, 20, 640, U.X3, tra=1, trb=1, bias=True, residual=True)
+
+
 def test_gemm_bf16_wgrad_f32_b(emu):
     U.check_gemm(emu, "cpu", 40, 24, 70, BF16, sa=BF16, sb=F32, to=F32, tra=1, trb=1, pad=4, splitk=False)
 
@@ -153,6 +166,12 @@ def test_attention_decoder_mfma(emu, T, window):
 def test_attention_decoder_mfma_long(emu, T, window):
     """64 < T <= 192: the key-block kernels (forward, D_i pre-pass, dQ and dK/dV kernels)"""
     U.check_attention(emu, "cpu", 1, 2, T, 256, window=window, causal=1, dt=BF16)
+
+
+@pytest.mark.parametrize("T,window,causal,D", [(64, 64, 1, 256), (37, 10, 1, 256), (33, 1, 1, 128), (5, 3, 1, 64), (50, 50, 0, 64), (64, 64, 0, 64), (31, 31, 0, 128)])
+def test_attention_f32_mfma(emu, T, window, causal, D):
+    """fp32 tensors, Tq == Tk <= 64 (attn_f32.h): one wave per 32-query / 32-key block on the f32 matrix cores, forward + both backward kernels"""
+    U.check_attention(emu, "cpu", 2, 2, T, D, window=window, causal=causal, dt=F32)
 
 
 def test_attention_band(emu):

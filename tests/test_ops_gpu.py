@@ -44,6 +44,20 @@ def test_gemm_bf16(hip, tra, trb, sa, to):
     U.check_gemm(hip, DEV, 33, 7, 100, BF16, sa=sa, to=to, tra=tra, trb=trb, pad=1, splitk=False)
 
 
+@pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gemm_bf16x3(hip, tra, trb):
+    """VCAD_BF16X3 compute type: fp32 operands split into hi / lo bf16 planes while staging, three MFMAs per product; checked against
+    the exact product of the unrounded fp32 operands (tolerance 1.5e-5 relative: ~2^-17 per operand + the dropped lo*lo term)"""
+    U.check_gemm(hip, DEV, 520, 264, 392, U.X3, tra=tra, trb=trb, pad=4, bias=True, act=2, residual=True, splitk=False)
+    U.check_gemm(hip, DEV, 33, 7, 100, U.X3, tra=tra, trb=trb, pad=1, splitk=False)
+
+
+def test_gemm_bf16x3_big(hip):
+    U.check_gemm(hip, DEV, 5000, 3072, 512, U.X3, bias=True)                # ViT QKV shape
+    U.check_gemm(hip, DEV, 3072, 512, 20000, U.X3, tra=1, trb=1)            # ViT QKV wgrad, split-K
+    U.check_gemm(hip, DEV, 4096, 512, 1024, U.X3, trb=1, residual=True, act=1, bias=True)
+
+
 def test_gemm_bf16_wgrad_f32_sources(hip):
     for sa in (BF16, F32):
         for sb in (BF16, F32):
@@ -142,6 +156,12 @@ def test_attention_single_query(hip, dt):
     """cls-only last ViT layer (one query per image and head, 50 keys): bf16 takes the dedicated kernel, fp32 the wave-per-row one"""
     U.check_attention_single_query(hip, DEV, 5, 16, 50, dt)
     U.check_attention_single_query(hip, DEV, 3, 2, 64, dt, seed=3)
+
+
+@pytest.mark.parametrize("T,window,causal,D", [(64, 64, 1, 256), (37, 10, 1, 256), (33, 1, 1, 128), (5, 3, 1, 64), (50, 50, 0, 64), (64, 64, 0, 64), (31, 31, 0, 128)])
+def test_attention_f32_mfma(hip, T, window, causal, D):
+    """fp32 tensors, Tq == Tk <= 64 (attn_f32.h): one wave per 32-query / 32-key block on the f32 matrix cores, forward + both backward kernels"""
+    U.check_attention(hip, DEV, 5, 3, T, D, window=window, causal=causal, dt=F32)
 
 
 @pytest.mark.parametrize("T", [8, 64, 186])

@@ -34,7 +34,7 @@ CANONICAL_MODEL_CONFIG = {"model_name": "autoregressive", "state_dim": 1644, "ac
 CLASS_WEIGHTS = os.path.join(ROOT, "tests", "golden", "class_weights.json")     # verbatim copy of the reference's data file
 
 TRAIN_GF_PER_FRAME = {8: 6.25, 64: 5.70, 128: 5.68, 186: 5.68}     # fwd+bwd algorithmic GFLOP per frame
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}                        # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}       # MI355X_MICROARCH.md dense MFMA peaks (bf16x3: three bf16 MFMAs per product)
 CATS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attention", "layernorm", "loss", "optimizer", "other"]
 
 

@@ -1,0 +1,281 @@
+// attn_f32.h — fp32 attention on the f32 matrix cores (v_mfma_f32_32x32x2_f32: an exact fp32 FMA chain), r03.
+//
+// The fp32-storage modes (VCAD_F32 parity mode, VCAD_BF16X3 in-tolerance mode) ran every attention on the wave-per-row kernels of
+// attn.h, where each lane walks a whole K row from global memory: 88 of the 203 ms of a C2 step (profiles/r02_bench_f32.json).  These
+// kernels keep the same mask rule and the same two-kernel backward split (no atomics, deterministic) but put one wave on a
+// 32-query (or 32-key) block and all four contractions on the matrix cores.  They need no LDS and no barrier:
+//
+//   * the score product is issued SWAPPED, S^T = K Q^T, with the k-index of one MFMA step paired as (d, d + 32): lane (row, half)
+//     supplies elements [half*32 + kk] of ITS OWN K / Q row — 32 consecutive floats, loaded as eight 16-byte pieces into registers;
+//   * in the S^T accumulator a lane owns one query (column) — softmax statistics are lane-local plus ONE exchange with lane ^ 32;
+//   * accumulator register r of a tile holds P[i][j_r] in lanes 0-31 and P[i][j_r + 4] in lanes 32-63 — exactly an MFMA A fragment
+//     whose two k-steps are keys (j_r, j_r + 4), so P (and dS) feed the second product straight from the accumulator registers;
+//     the matching B fragment V[j_r + 4*half][n] is a coalesced row read (lanes = 32 x 8-byte column pairs);
+//   * the backward's key-side kernel recomputes the UNSWAPPED orientation (lane = key) so P^T / dS^T are A fragments for dV / dK.
+//
+// Element (b, t, h, d) of q/k/v/o lives at base + (b*T + t)*ld + h*D + d (packed projections consumed in place), as in attn.h.
+// Masks: key j visible to query i iff max(0, i - window + 1) <= j <= (causal ? i : Tk - 1).  Covers Tq == Tk <= 32*NKT.
+#pragma once
+#include "attn.h"
+
+constexpr int AF_MAXT = 64;            // NKT = 2 tiles of 32 keys: the ViT (50 tokens) and the decoder at seq_len <= 64
+
+VC_DEV void af_ld32(const float* p, float (&v)[32]) {            // 32 consecutive floats, 16-byte aligned
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const vc_u32x4 c = reinterpret_cast<const vc_u32x4*>(p)[q];
+        v[4 * q] = vc_bits_f32(c.x); v[4 * q + 1] = vc_bits_f32(c.y); v[4 * q + 2] = vc_bits_f32(c.z); v[4 * q + 3] = vc_bits_f32(c.w);
+    }
+}
+VC_DEV void af_zero(vc_f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+VC_DEV int af_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }     // accumulator row of register r (MFMA 32x32 D layout)
+
+// ------------------------------------------------------------------------------------------------------------ forward
+// one wave per (batch, head, 32-query block)
+template <int NCH, int NKT>
+VC_KERNEL __launch_bounds__(256) void attn_f32_fwd_kernel(AttnParams p) {
+    constexpr int D = 64 * NCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, half = lane >> 5;
+    const int nqb = (p.Tq + 31) >> 5;
+    const long unit = (long)blockIdx.x * 4 + wave;
+    if (unit >= (long)p.B * p.H * nqb) return;
+    const int qb = (int)(unit % nqb), h = (int)((unit / nqb) % p.H); const long b = unit / ((long)nqb * p.H);
+    const int i = qb * 32 + il, iq = i < p.Tq ? i : p.Tq - 1;          // this lane's query (padding lanes repeat the last one; never stored)
+    const int lo = iq - p.window + 1 > 0 ? iq - p.window + 1 : 0, hi = p.causal ? (iq < p.Tk - 1 ? iq : p.Tk - 1) : p.Tk - 1;
+    // key tiles this block needs (wave-uniform): tile t holds keys 32t .. 32t+31
+    const int i_first = qb * 32, i_last = (qb * 32 + 31 < p.Tq ? qb * 32 + 31 : p.Tq - 1);
+    const int j_min = i_first - p.window + 1 > 0 ? i_first - p.window + 1 : 0, j_max = p.causal ? (i_last < p.Tk - 1 ? i_last : p.Tk - 1) : p.Tk - 1;
+    const float* qrow = (const float*)p.q + (b * p.Tq + iq) * p.ldq + (long)h * D + half * 32;
+    vc_f32x16 st[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) af_zero(st[t]);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float qf[32]; af_ld32(qrow + c * 64, qf);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
+            const int jk = t * 32 + il < p.Tk ? t * 32 + il : p.Tk - 1;
+            float kf[32]; af_ld32((const float*)p.k + (b * p.Tk + jk) * p.ldk + (long)h * D + c * 64 + half * 32, kf);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) st[t] = vc_mfma_32x32x2_f32(kf[kk], qf[kk], st[t]);
+        }
+    }
+    // softmax over this lane's query: its 16*NKT keys here + the partner half's
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = t * 32 + af_row(r, half);
+            const float s = (j >= lo && j <= hi) ? st[t][r] * p.scale : -INFINITY;
+            st[t][r] = s; m = fmaxf(m, s);
+        }
+    m = fmaxf(m, vc_shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = expf(st[t][r] - m); st[t][r] = e; l += e; }       // exp(-inf) = 0 for masked keys
+    l += vc_shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    const long dbase = ((b * p.H + h) * p.Tq + iq) * p.Tk;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pr = st[t][r] * inv;
+            if (p.drop.key) { const int j = t * 32 + af_row(r, half); if (j < p.Tk) pr *= vc_drop_mul(p.drop, (uint32_t)(dbase + j)); }
+            st[t][r] = pr;
+        }
+    if (p.lse && half == 0 && i < p.Tq) p.lse[(b * p.H + h) * p.Tq + i] = m + logf(l);
+    // O[i][d] = sum_j P[i][j] V[j][d]: A = P from the accumulator registers, B = V rows (lane = column pair 2*il, 2*il + 1 of the chunk)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        vc_f32x16 o0, o1; af_zero(o0); af_zero(o1);
+        const float* vcol = (const float*)p.v + (long)h * D + c * 64 + 2 * il;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = t * 32 + af_row(r, half), jl = j < p.Tk ? j : p.Tk - 1;
+                const vc_u32x2 vv = *reinterpret_cast<const vc_u32x2*>(vcol + (b * p.Tk + jl) * p.ldv);
+                o0 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(vv.x), o0);
+                o1 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(vv.y), o1);
+            }
+        }
+        float* ocol = (float*)p.o + (long)h * D + c * 64 + 2 * il;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int io = qb * 32 + af_row(r, half);
+            if (io < p.Tq) { vc_u32x2 w; w.x = vc_f32_bits(o0[r]); w.y = vc_f32_bits(o1[r]); *reinterpret_cast<vc_u32x2*>(ocol + (b * p.Tq + io) * p.ldo) = w; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward, query side
+// one wave per (batch, head, 32-query block): D_i = sum_j P_ij dP_ij -> delta,  dq_i = scale * sum_j dS_ij k_j
+template <int NCH, int NKT>
+VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_q_kernel(AttnParams p) {
+    constexpr int D = 64 * NCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, half = lane >> 5;
+    const int nqb = (p.Tq + 31) >> 5;
+    const long unit = (long)blockIdx.x * 4 + wave;
+    if (unit >= (long)p.B * p.H * nqb) return;
+    const int qb = (int)(unit % nqb), h = (int)((unit / nqb) % p.H); const long b = unit / ((long)nqb * p.H);
+    const int i = qb * 32 + il, iq = i < p.Tq ? i : p.Tq - 1;
+    const int lo = iq - p.window + 1 > 0 ? iq - p.window + 1 : 0, hi = p.causal ? (iq < p.Tk - 1 ? iq : p.Tk - 1) : p.Tk - 1;
+    const int i_first = qb * 32, i_last = (qb * 32 + 31 < p.Tq ? qb * 32 + 31 : p.Tq - 1);
+    const int j_min = i_first - p.window + 1 > 0 ? i_first - p.window + 1 : 0, j_max = p.causal ? (i_last < p.Tk - 1 ? i_last : p.Tk - 1) : p.Tk - 1;
+    const float* qrow = (const float*)p.q + (b * p.Tq + iq) * p.ldq + (long)h * D + half * 32;
+    const float* dorow = (const float*)p.dout + (b * p.Tq + iq) * p.lddo + (long)h * D + half * 32;
+    vc_f32x16 st[NKT], dpt[NKT];          // S^T and dP^T = V dO^T, same layout
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) { af_zero(st[t]); af_zero(dpt[t]); }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float qf[32], df[32]; af_ld32(qrow + c * 64, qf); af_ld32(dorow + c * 64, df);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
+            const int jk = t * 32 + il < p.Tk ? t * 32 + il : p.Tk - 1;
+            const long ko = (b * p.Tk + jk);
+            float kf[32]; af_ld32((const float*)p.k + ko * p.ldk + (long)h * D + c * 64 + half * 32, kf);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) st[t] = vc_mfma_32x32x2_f32(kf[kk], qf[kk], st[t]);
+            float vf[32]; af_ld32((const float*)p.v + ko * p.ldv + (long)h * D + c * 64 + half * 32, vf);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) dpt[t] = vc_mfma_32x32x2_f32(vf[kk], df[kk], dpt[t]);
+        }
+    }
+    const float lse = p.lse[(b * p.H + h) * p.Tq + iq];
+    const long dbase = ((b * p.H + h) * p.Tq + iq) * p.Tk;
+    float dsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = t * 32 + af_row(r, half);
+            const bool vis = j >= lo && j <= hi;
+            const float pr = vis ? expf(st[t][r] * p.scale - lse) : 0.f;
+            float dp = vis ? dpt[t][r] : 0.f;
+            if (p.drop.key && vis) dp *= vc_drop_mul(p.drop, (uint32_t)(dbase + j));        // dP = dP' * mask
+            st[t][r] = pr; dpt[t][r] = dp; dsum += pr * dp;
+        }
+    dsum += vc_shfl_xor(dsum, 32);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dpt[t][r] - dsum) * p.scale;      // dS (scale folded in)
+    if (half == 0 && i < p.Tq) p.delta[(b * p.H + h) * p.Tq + i] = dsum;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        vc_f32x16 o0, o1; af_zero(o0); af_zero(o1);
+        const float* kcol = (const float*)p.k + (long)h * D + c * 64 + 2 * il;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = t * 32 + af_row(r, half), jl = j < p.Tk ? j : p.Tk - 1;
+                const vc_u32x2 kv = *reinterpret_cast<const vc_u32x2*>(kcol + (b * p.Tk + jl) * p.ldk);
+                o0 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(kv.x), o0);
+                o1 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(kv.y), o1);
+            }
+        }
+        float* dqcol = (float*)p.dq + (long)h * D + c * 64 + 2 * il;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int io = qb * 32 + af_row(r, half);
+            if (io < p.Tq) { vc_u32x2 w; w.x = vc_f32_bits(o0[r]); w.y = vc_f32_bits(o1[r]); *reinterpret_cast<vc_u32x2*>(dqcol + (b * p.Tq + io) * p.lddq) = w; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward, key side
+// one wave per (batch, head, 32-key block): dk_j = scale * sum_i dS_ij q_i,  dv_j = sum_i P'_ij dO_i   (P' = dropped probabilities)
+// NQT = query tiles of 32.  Unswapped orientation: accumulator column = key (lane), row = query.
+template <int NCH, int NQT>
+VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_kv_kernel(AttnParams p) {
+    constexpr int D = 64 * NCH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, half = lane >> 5;
+    const int nkb = (p.Tk + 31) >> 5;
+    const long unit = (long)blockIdx.x * 4 + wave;
+    if (unit >= (long)p.B * p.H * nkb) return;
+    const int kb = (int)(unit % nkb), h = (int)((unit / nkb) % p.H); const long b = unit / ((long)nkb * p.H);
+    const int j = kb * 32 + il, jk = j < p.Tk ? j : p.Tk - 1;          // this lane's key
+    // queries that can see any key of this block: i in [i_min, i_max]
+    const int j_first = kb * 32, j_last = (kb * 32 + 31 < p.Tk ? kb * 32 + 31 : p.Tk - 1);
+    const int i_min = p.causal ? j_first : 0;
+    int i_max = j_last + p.window - 1; if (i_max > p.Tq - 1) i_max = p.Tq - 1;
+    const float* krow = (const float*)p.k + (b * p.Tk + jk) * p.ldk + (long)h * D + half * 32;
+    const float* vrow = (const float*)p.v + (b * p.Tk + jk) * p.ldv + (long)h * D + half * 32;
+    vc_f32x16 s[NQT], dp[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) { af_zero(s[t]); af_zero(dp[t]); }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float kf[32], vf[32]; af_ld32(krow + c * 64, kf); af_ld32(vrow + c * 64, vf);
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            if (t * 32 > i_max || t * 32 + 31 < i_min) continue;
+            const int iq = t * 32 + il < p.Tq ? t * 32 + il : p.Tq - 1;
+            float qf[32]; af_ld32((const float*)p.q + (b * p.Tq + iq) * p.ldq + (long)h * D + c * 64 + half * 32, qf);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) s[t] = vc_mfma_32x32x2_f32(qf[kk], kf[kk], s[t]);
+            float df[32]; af_ld32((const float*)p.dout + (b * p.Tq + iq) * p.lddo + (long)h * D + c * 64 + half * 32, df);
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) dp[t] = vc_mfma_32x32x2_f32(df[kk], vf[kk], dp[t]);
+        }
+    }
+    // P'^T (-> s) and dS^T (-> dp): row = query i_r, column = this lane's key j
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = t * 32 + af_row(r, half);
+            const int lo = i - p.window + 1 > 0 ? i - p.window + 1 : 0, hi = p.causal ? (i < p.Tk - 1 ? i : p.Tk - 1) : p.Tk - 1;
+            const bool vis = i < p.Tq && j >= lo && j <= hi && j < p.Tk;
+            float pr = 0.f, ds = 0.f;
+            if (vis) {
+                const long sidx = (b * p.H + h) * p.Tq + i;
+                pr = expf(s[t][r] * p.scale - p.lse[sidx]);
+                const float ms = p.drop.key ? vc_drop_mul(p.drop, (uint32_t)(sidx * p.Tk + j)) : 1.0f;
+                ds = pr * (dp[t][r] * ms - p.delta[sidx]) * p.scale;
+                pr *= ms;
+            }
+            s[t][r] = pr; dp[t][r] = ds;
+        }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        vc_f32x16 v0, v1, k0, k1; af_zero(v0); af_zero(v1); af_zero(k0); af_zero(k1);
+        const float* docol = (const float*)p.dout + (long)h * D + c * 64 + 2 * il;
+        const float* qcol = (const float*)p.q + (long)h * D + c * 64 + 2 * il;
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            if (t * 32 > i_max || t * 32 + 31 < i_min) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = t * 32 + af_row(r, half), ic = i < p.Tq ? i : p.Tq - 1;
+                const vc_u32x2 dv = *reinterpret_cast<const vc_u32x2*>(docol + (b * p.Tq + ic) * p.lddo);
+                const vc_u32x2 qv = *reinterpret_cast<const vc_u32x2*>(qcol + (b * p.Tq + ic) * p.ldq);
+                v0 = vc_mfma_32x32x2_f32(s[t][r], vc_bits_f32(dv.x), v0); v1 = vc_mfma_32x32x2_f32(s[t][r], vc_bits_f32(dv.y), v1);
+                k0 = vc_mfma_32x32x2_f32(dp[t][r], vc_bits_f32(qv.x), k0); k1 = vc_mfma_32x32x2_f32(dp[t][r], vc_bits_f32(qv.y), k1);
+            }
+        }
+        float* dkcol = (float*)p.dk + (long)h * D + c * 64 + 2 * il;
+        float* dvcol = (float*)p.dv + (long)h * D + c * 64 + 2 * il;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jo = kb * 32 + af_row(r, half);
+            if (jo < p.Tk) {
+                vc_u32x2 w; w.x = vc_f32_bits(k0[r]); w.y = vc_f32_bits(k1[r]); *reinterpret_cast<vc_u32x2*>(dkcol + (b * p.Tk + jo) * p.lddk) = w;
+                vc_u32x2 u; u.x = vc_f32_bits(v0[r]); u.y = vc_f32_bits(v1[r]); *reinterpret_cast<vc_u32x2*>(dvcol + (b * p.Tk + jo) * p.lddv) = u;
+            }
+        }
+    }
+}

@@ -58,7 +58,8 @@ struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* s
 
 struct vcad_engine {
     vcad_config c;
-    int dt;                       // activation / compute dtype
+    int dt;                       // activation / storage dtype (VC_F32 | VC_BF16)
+    int ct;                       // GEMM compute type: = dt, or VC_X3 (bf16x3 on fp32 tensors: VCAD_BF16X3)
     size_t esz;
     std::vector<PInfo> plist; std::map<std::string, int> pindex; long ptotal = 0;
     std::vector<std::pair<long, long>> buckets;
@@ -328,7 +329,7 @@ struct Ctx {
     }
     int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep, int role = 0) const {
         GemmCall c; memset(&c, 0, sizeof(c));
-        c.role = role; c.ct = e->dt; c.sa = A.dt; c.sb = B.dt; c.to = C.dt; c.tra = tra; c.trb = trb;
+        c.role = role; c.ct = e->ct; c.sa = A.dt; c.sb = B.dt; c.to = C.dt; c.tra = tra; c.trb = trb;
         GemmParams& p = c.p;
         p.A = A.p; p.B = B.p; p.C = (void*)C.p; p.M = M; p.N = N; p.K = K; p.lda = A.ld; p.ldb = B.ld; p.ldc = C.ld;
         p.alpha = 1.0f; p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr;
@@ -657,7 +658,7 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
     df.calls[0].clear(); df.calls[1].clear(); df.cs.clear();
     auto add = [&](int g, Mat dY, Mat X, long w_off, long lddw, long b_off, int N, int K) {
         GemmCall gc; memset(&gc, 0, sizeof(gc));
-        gc.ct = e->dt; gc.sa = dY.dt; gc.sb = X.dt; gc.to = VC_F32; gc.tra = 1; gc.trb = 1;
+        gc.ct = e->ct; gc.sa = dY.dt; gc.sb = X.dt; gc.to = VC_F32; gc.tra = 1; gc.trb = 1;
         GemmParams& p = gc.p;
         p.A = dY.p; p.B = X.p; p.C = (void*)cx.Gf(w_off); p.M = N; p.N = K; p.K = (int)M; p.lda = dY.ld; p.ldb = X.ld; p.ldc = lddw; p.alpha = 1.0f;
         df.calls[g].push_back(gc);
@@ -807,7 +808,7 @@ const char* vcad_version(void) { return "videocad_amd 0.2 (gfx950)"; }
 
 int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (!cfg || !out) { vc_set_error("null argument"); return VC_ERR_ARG; }
-    if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_BF16) { vc_set_error("bad dtype %d", cfg->dtype); return VC_ERR_ARG; }
+    if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_BF16 && cfg->dtype != VCAD_BF16X3) { vc_set_error("bad dtype %d", cfg->dtype); return VC_ERR_ARG; }
     if (cfg->hidden_size % cfg->nhead) { vc_set_error("hidden_size %% nhead != 0"); return VC_ERR_ARG; }
     const int hd = cfg->hidden_size / cfg->nhead;
     if ((hd != 256 && hd != 128 && hd != 64) || cfg->vit_dim_head != 64) { vc_set_error("head dims (%d, %d) unsupported (decoder 64/128/256, ViT 64)", hd, cfg->vit_dim_head); return VC_ERR_UNSUPPORTED; }
@@ -821,7 +822,7 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (cfg->num_classes != 5 || cfg->num_params != 6 || cfg->num_params_values != 1000) { vc_set_error("heads must be 5 + 6x1000 (reference model/autoregressive_transformer.py:218)"); return VC_ERR_UNSUPPORTED; }
     if (cfg->dim_feedforward % 8 || cfg->vit_mlp % 8) { vc_set_error("dim_feedforward / vit_mlp must be multiples of 8 (16-byte bf16 rows)"); return VC_ERR_UNSUPPORTED; }
     vcad_engine* e = new vcad_engine();
-    e->c = *cfg; e->dt = cfg->dtype; e->esz = cfg->dtype == VCAD_BF16 ? 2 : 4;
+    e->c = *cfg; e->dt = cfg->dtype == VCAD_BF16 ? VC_BF16 : VC_F32; e->ct = cfg->dtype == VCAD_BF16X3 ? VC_X3 : e->dt; e->esz = cfg->dtype == VCAD_BF16 ? 2 : 4;
     if (cfg->vit_depth < 1 || cfg->num_decoder_layers < 1) { vc_set_error("vit_depth / num_decoder_layers must be >= 1"); delete e; return VC_ERR_ARG; }
     build_params(e);
     if ((int)e->buckets.size() != NB_BUCKETS) { vc_set_error("internal: %d buckets", (int)e->buckets.size()); delete e; return VC_ERR_ARG; }

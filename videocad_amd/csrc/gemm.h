@@ -9,6 +9,11 @@
 //
 // Compute types: CT=float  -> v_mfma_f32_32x32x2_f32 (exact fp32 fma chain: the parity mode)
 //                CT=vc_bf16 -> v_mfma_f32_32x32x16_bf16 (fp32 accumulate: the throughput mode)
+//                CT=vc_x3   -> "bf16x3" (r03): fp32 operands are split while staging into hi = bf16(x) and lo = bf16(x - hi)
+//                              (two LDS planes per operand) and every product runs as three bf16 MFMAs, lo*hi + hi*lo + hi*hi,
+//                              into the fp32 accumulator: |error| per product ~2^-16 relative (the dropped lo*lo term and the
+//                              16-bit operand representation) against 2^-9 for plain bf16 — the in-tolerance mode (logits within
+//                              1e-3 of the fp32 reference) at 3/16 of the f32-MFMA cost
 // Source types SA/SB may be float while CT is bf16 (converted while staging into LDS), so the fp32
 // residual stream / fp32 residual-gradients feed bf16 MFMA without an extra HBM round trip.
 //
@@ -193,13 +198,26 @@ VC_DEV void gemm_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4],
     quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
 }
 
+struct vc_x3 { uint16_t bits; };      // compute-type tag of the bf16x3 mode: LDS elements are bf16, two planes (hi, lo) per operand tile
 template <typename CT> struct GemmCfg;
 template <> struct GemmCfg<float> {
-    static constexpr int BK = 32, CHUNK = 4, STRIDE = 33, KSTEP = 2;
+    static constexpr int BK = 32, CHUNK = 4, STRIDE = 33, KSTEP = 2, PLANES = 1;
 };
 template <> struct GemmCfg<vc_bf16> {
-    static constexpr int BK = 64, CHUNK = 8, STRIDE = 72, KSTEP = 16;
+    static constexpr int BK = 64, CHUNK = 8, STRIDE = 72, KSTEP = 16, PLANES = 1;
 };
+// BK = 32 keeps the double-buffered stage set of a 128 x 128 tile at 80 KiB (two planes per operand), so two workgroups still share a
+// CU's 160 KiB; row stride 40 elements = 20 dwords: the 16 lanes a ds_read_b128 services per cycle land on 64 distinct banks
+template <> struct GemmCfg<vc_x3> {
+    static constexpr int BK = 32, CHUNK = 8, STRIDE = 40, KSTEP = 16, PLANES = 2;
+};
+template <typename CT> struct gemm_is_x3 { static constexpr bool value = false; };
+template <> struct gemm_is_x3<vc_x3> { static constexpr bool value = true; };
+// hi / lo split of two fp32 values into packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi) (exact subtraction)
+VC_DEV void gemm_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = vc_pack_bf16x2(a, b);
+    lo = vc_pack_bf16x2(a - vc_bits_f32(hi << 16), b - vc_bits_f32(hi & 0xFFFF0000u));
+}
 constexpr int GEMM_THREADS = 256;      // 4 waves as 2 x 2; each wave owns WT x WT MFMA 32x32 tiles => block tile = (64*WT)^2
 
 // LDS image of one operand tile:
@@ -209,9 +227,10 @@ constexpr int GEMM_THREADS = 256;      // 4 waves as 2 x 2; each wave owns WT x 
 //            transpose-read touches on disjoint banks
 //   f32  TR  : transposed on the way into LDS (scalar ds_write_b32), same image as direct
 template <int ROWS> constexpr int gemm_tstride() { return ROWS + 32; }
-template <typename CT, bool TR, int ROWS> constexpr int gemm_tile_elems() {
+template <typename CT, bool TR, int ROWS> constexpr int gemm_plane_elems() {
     return (sizeof(CT) == 2 && TR) ? GemmCfg<CT>::BK * gemm_tstride<ROWS>() : ROWS * GemmCfg<CT>::STRIDE;
 }
+template <typename CT, bool TR, int ROWS> constexpr int gemm_tile_elems() { return GemmCfg<CT>::PLANES * gemm_plane_elems<CT, TR, ROWS>(); }
 template <typename CT, bool TRA, bool TRB, int WT> constexpr size_t gemm_lds_bytes() {
     constexpr size_t stage = 2ul * (gemm_tile_elems<CT, TRA, 64 * WT>() + gemm_tile_elems<CT, TRB, 64 * WT>()) * sizeof(CT);
     constexpr size_t epi = (size_t)(64 * WT) * (64 * WT + 4) * 4;          // fp32 staging tile of the row-wise epilogue
@@ -232,9 +251,12 @@ VC_DEV vc_u32x4 gemm_pack_chunk(const float (&f)[GemmCfg<CT>::CHUNK]) {
 template <typename CT, typename ST, bool TR, int ROWS>
 struct GemmStager {
     static constexpr int BK = GemmCfg<CT>::BK, CH = GemmCfg<CT>::CHUNK, STRIDE = GemmCfg<CT>::STRIDE;
-    static constexpr int NCH = ROWS * BK / CH / GEMM_THREADS;     // chunks per thread (4 for 128 rows, 2 for 64)
+    static constexpr int NCH = ROWS * BK / CH / GEMM_THREADS;     // chunks per thread (4 for 128 rows, 2 for 64; bf16x3: 2 and 1)
     static constexpr int TS = gemm_tstride<ROWS>();
-    vc_u32x4 regs[NCH];
+    static constexpr bool X3 = gemm_is_x3<CT>::value;             // registers hold the RAW fp32 chunk (two quads); the hi / lo split happens in store()
+    static constexpr int PLANE = gemm_plane_elems<CT, TR, ROWS>();
+    static_assert(!X3 || sizeof(ST) == 4, "bf16x3 splits fp32 sources");
+    vc_u32x4 regs[NCH * (X3 ? 2 : 1)];
 
     // interior tile + 16-byte-aligned operand: straight-line vector loads (no per-chunk branch, so all loads of a
     // K-tile are in flight together; a divergent bounds test per chunk makes hipcc drain vmcnt after every load)
@@ -245,7 +267,9 @@ struct GemmStager {
             const ST* p;
             if constexpr (!TR) p = base + (long)(r0 + c / (BK / CH)) * ld + (k0 + (c % (BK / CH)) * CH);
             else p = base + (long)(k0 + c / (ROWS / CH)) * ld + (r0 + (c % (ROWS / CH)) * CH);
-            if constexpr (sizeof(ST) == sizeof(CT)) {
+            if constexpr (X3) {
+                regs[2 * i] = reinterpret_cast<const vc_u32x4*>(p)[0]; regs[2 * i + 1] = reinterpret_cast<const vc_u32x4*>(p)[1];
+            } else if constexpr (sizeof(ST) == sizeof(CT)) {
                 regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
             } else {   // fp32 source feeding bf16 MFMA
                 const vc_u32x4 lo = reinterpret_cast<const vc_u32x4*>(p)[0], hi = reinterpret_cast<const vc_u32x4*>(p)[1];
@@ -273,13 +297,28 @@ struct GemmStager {
             float f[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) f[j] = (j < nv) ? vc_cvt<ST>::to_f32(p[j]) : 0.0f;
-            regs[i] = gemm_pack_chunk<CT, ST>(f);
+            if constexpr (X3) {
+                regs[2 * i].x = vc_f32_bits(f[0]); regs[2 * i].y = vc_f32_bits(f[1]); regs[2 * i].z = vc_f32_bits(f[2]); regs[2 * i].w = vc_f32_bits(f[3]);
+                regs[2 * i + 1].x = vc_f32_bits(f[4]); regs[2 * i + 1].y = vc_f32_bits(f[5]); regs[2 * i + 1].z = vc_f32_bits(f[6]); regs[2 * i + 1].w = vc_f32_bits(f[7]);
+            } else regs[i] = gemm_pack_chunk<CT, ST>(f);
         }
     }
     VC_DEV void store(CT* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + GEMM_THREADS * i;
+            if constexpr (X3) {       // split the fp32 chunk into its hi and lo bf16 planes (same image in both)
+                const vc_u32x4 a = regs[2 * i], b = regs[2 * i + 1];
+                vc_u32x4 hi, lo;
+                gemm_split2(vc_bits_f32(a.x), vc_bits_f32(a.y), hi.x, lo.x); gemm_split2(vc_bits_f32(a.z), vc_bits_f32(a.w), hi.y, lo.y);
+                gemm_split2(vc_bits_f32(b.x), vc_bits_f32(b.y), hi.z, lo.z); gemm_split2(vc_bits_f32(b.z), vc_bits_f32(b.w), hi.w, lo.w);
+                int off;
+                if constexpr (!TR) off = (c / (BK / CH)) * STRIDE + (c % (BK / CH)) * CH;
+                else off = (c / (ROWS / CH)) * TS + (c % (ROWS / CH)) * CH;
+                *reinterpret_cast<vc_u32x4*>(lds + off) = hi;
+                *reinterpret_cast<vc_u32x4*>(lds + PLANE + off) = lo;
+                continue;
+            }
             const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
             if constexpr (!TR) {
                 int row = c / (BK / CH), kc = (c % (BK / CH)) * CH;
@@ -305,14 +344,14 @@ struct GemmStager {
 };
 
 // bf16 MFMA fragment (8 k-values of one row) for k-step ks of the tile; row0 = first row of the wave's 32-row block
-template <bool TR, int ROWS>
-VC_DEV vc_s16x8 gemm_frag_bf16(const vc_bf16* tile, int row0, int ks, int lane) {
+template <bool TR, int ROWS, typename CT = vc_bf16>
+VC_DEV vc_s16x8 gemm_frag_bf16(const CT* tile, int row0, int ks, int lane) {
     constexpr int GEMM_TSTRIDE = gemm_tstride<ROWS>();
     if constexpr (!TR) {
-        return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * GemmCfg<vc_bf16>::STRIDE + ks * 16 + (lane >> 5) * 8);
+        return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * GemmCfg<CT>::STRIDE + ks * 16 + (lane >> 5) * 8);
     } else {
         const int i = lane & 15;
-        const vc_bf16* p = tile + (ks * 16 + 8 * (lane >> 5) + (i >> 2)) * GEMM_TSTRIDE + row0 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+        const CT* p = tile + (ks * 16 + 8 * (lane >> 5) + (i >> 2)) * GEMM_TSTRIDE + row0 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
         const vc_s16x4 lo = vc_ds_read_tr16(p), hi = vc_ds_read_tr16(p + 4 * GEMM_TSTRIDE);
         vc_s16x8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -383,7 +422,29 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
     auto compute = [&](int cur) {
         const CT* a_tile = lds + cur * TILE;
         const CT* b_tile = a_tile + ATILE;
-        if constexpr (sizeof(CT) == 2) {
+        if constexpr (gemm_is_x3<CT>::value) {
+            // bf16x3: small terms first (lo*hi, hi*lo), then hi*hi, all into the same fp32 accumulator
+            constexpr int AP = gemm_plane_elems<CT, TRA, GEMM_BM>(), BP = gemm_plane_elems<CT, TRB, GEMM_BN>();
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                vc_s16x8 ah[WT], al[WT], bh[WT], bl[WT];
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    ah[i] = gemm_frag_bf16<TRA, GEMM_BM, CT>(a_tile, wm * WS + i * 32, ks, lane);
+                    al[i] = gemm_frag_bf16<TRA, GEMM_BM, CT>(a_tile + AP, wm * WS + i * 32, ks, lane);
+                    bh[i] = gemm_frag_bf16<TRB, GEMM_BN, CT>(b_tile, wn * WS + i * 32, ks, lane);
+                    bl[i] = gemm_frag_bf16<TRB, GEMM_BN, CT>(b_tile + BP, wn * WS + i * 32, ks, lane);
+                }
+#pragma unroll
+                for (int i = 0; i < WT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) {
+                        acc[i][j] = vc_mfma_32x32x16_bf16(al[i], bh[j], acc[i][j]);
+                        acc[i][j] = vc_mfma_32x32x16_bf16(ah[i], bl[j], acc[i][j]);
+                        acc[i][j] = vc_mfma_32x32x16_bf16(ah[i], bh[j], acc[i][j]);
+                    }
+            }
+        } else if constexpr (sizeof(CT) == 2) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 vc_s16x8 af[WT], bf[WT];

@@ -7,7 +7,7 @@
 #include "loss.h"
 #include "optim.h"
 
-enum { VC_F32 = 0, VC_BF16 = 1 };
+enum { VC_F32 = 0, VC_BF16 = 1, VC_X3 = 2 /* GEMM compute type only: bf16x3 on fp32 tensors (gemm.h) */ };
 enum { VC_OK = 0, VC_ERR_ARG = 1, VC_ERR_UNSUPPORTED = 2, VC_ERR_LAUNCH = 3, VC_ERR_WORKSPACE = 4 };
 
 void vc_set_error(const char* fmt, ...);

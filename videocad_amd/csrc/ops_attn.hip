@@ -1,6 +1,7 @@
 // ops_attn.hip — launchers for the windowed attention kernels.
 #include "ops.h"
 #include "attn_mfma.h"
+#include "attn_f32.h"
 
 static int clampw(const AttnParams& p) { int mx = (p.Tq + p.qpos) > p.Tk ? (p.Tq + p.qpos) : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
 static int max_keys(const AttnParams& p) { int w = clampw(p); return w < p.Tk ? w : p.Tk; }        // visible keys per query
@@ -70,6 +71,13 @@ static bool dec_long_ok(int t, int D, const AttnParams& p, bool bwd) {
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.delta && p.dq && p.dk && p.dv;
 }
+// fp32 tensors on the f32 matrix cores (attn_f32.h): full / causal / banded attention with Tq == Tk <= 64, head dims 64 / 128 / 256
+static bool f32_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
+    auto al8 = [](const void* q, long ld) { return q && ((uintptr_t)q % 8 == 0) && (ld % 2 == 0); };
+    const bool ok = t == VC_F32 && (D == 64 || D == 128 || D == 256) && p.Tq == p.Tk && p.Tq <= AF_MAXT && !p.qpos && !p.kv_rows;
+    if (!bwd) return ok && al8(p.o, p.ldo);
+    return ok && p.lse && p.delta && al8(p.dq, p.lddq) && al8(p.dk, p.lddk) && al8(p.dv, p.lddv);
+}
 template <typename K> static int set_dyn_lds(K kern, size_t bytes) {
 #ifndef VC_EMU
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -131,6 +139,13 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 2>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 2>), g, dim3(64), 0, s, p); }
+        return VC_OK;
+    }
+    if (f32_mfma_ok(t, D, p, false)) {                            // one wave per 32-query block, everything on the f32 matrix cores
+        const dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H * VC_CEIL_DIV(p.Tq, 32), 4));
+        if (D == 64) VC_LAUNCH((attn_f32_fwd_kernel<1, 2>), g, dim3(256), 0, s, p);
+        else if (D == 128) VC_LAUNCH((attn_f32_fwd_kernel<2, 2>), g, dim3(256), 0, s, p);
+        else VC_LAUNCH((attn_f32_fwd_kernel<4, 2>), g, dim3(256), 0, s, p);
         return VC_OK;
     }
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
@@ -198,6 +213,13 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         if (D == 4 * AM_D) { if (p.drop.key) VC_LONG_BWD(true, 4); else VC_LONG_BWD(false, 4); }
         else               { if (p.drop.key) VC_LONG_BWD(true, 2); else VC_LONG_BWD(false, 2); }
 #undef VC_LONG_BWD
+        return VC_OK;
+    }
+    if (f32_mfma_ok(t, D, p, true)) {
+        const dim3 gq((unsigned)VC_CEIL_DIV((long)p.B * p.H * VC_CEIL_DIV(p.Tq, 32), 4)), gk((unsigned)VC_CEIL_DIV((long)p.B * p.H * VC_CEIL_DIV(p.Tk, 32), 4));
+        if (D == 64) { VC_LAUNCH((attn_f32_bwd_q_kernel<1, 2>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<1, 2>), gk, dim3(256), 0, s, p); }
+        else if (D == 128) { VC_LAUNCH((attn_f32_bwd_q_kernel<2, 2>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<2, 2>), gk, dim3(256), 0, s, p); }
+        else { VC_LAUNCH((attn_f32_bwd_q_kernel<4, 2>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<4, 2>), gk, dim3(256), 0, s, p); }
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);

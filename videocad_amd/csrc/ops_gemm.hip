@@ -105,7 +105,7 @@ static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
 int vc_gemm_prepare(GemmCall& c) {
     GemmParams& p = c.p;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
-    if (c.ct == VC_F32 && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
+    if ((c.ct == VC_F32 || c.ct == VC_X3) && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 / bf16x3 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
     p.debug_skip = g_debug_skip;
     if (c.ct == VC_BF16) {          // bf16 mode: cheap erf (gemm.h) in both GEMM kernels, so results do not depend on the kernel choice
         if (p.act == VC_ACT_GELU) p.act = VC_ACT_GELU_FAST;
@@ -210,6 +210,9 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     if (c.ct == VC_F32) {
         switch (lay) { case 0: G(float, float, float, float, false, false); case 1: G(float, float, float, float, false, true);
                        case 2: G(float, float, float, float, true, false); case 3: G(float, float, float, float, true, true); }
+    } else if (c.ct == VC_X3) {
+        switch (lay) { case 0: G(vc_x3, float, float, float, false, false); case 1: G(vc_x3, float, float, float, false, true);
+                       case 2: G(vc_x3, float, float, float, true, false); case 3: G(vc_x3, float, float, float, true, true); }
     } else if (lay == 3) {            // wgrad: fp32 output always; either operand may be an fp32 tensor (converted while staging)
         if (c.to != VC_F32) { vc_set_error("vc_gemm: wgrad (tra=trb=1) writes fp32"); return VC_ERR_UNSUPPORTED; }
         switch ((c.sa == VC_F32) * 2 + (c.sb == VC_F32)) {

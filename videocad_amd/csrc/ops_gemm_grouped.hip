@@ -44,6 +44,7 @@ int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const i
     GemmGroup grp{probs, tile_start, n};
     if (!(sig.tra && sig.trb) || sig.to != VC_F32) { vc_set_error("vc_gemm_grouped: only the wgrad layout is instantiated"); return VC_ERR_UNSUPPORTED; }
     if (sig.ct == VC_F32) return grouped_launch<float, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
+    if (sig.ct == VC_X3) return grouped_launch<vc_x3, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
     if (sig.sa == VC_BF16 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, vc_bf16, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);
     if (sig.sa == VC_BF16 && sig.sb == VC_F32) return grouped_launch<vc_bf16, vc_bf16, float, float, true, true>(sig, grp, total_tiles, flops, s);
     if (sig.sa == VC_F32 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, float, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);

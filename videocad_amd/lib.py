@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvcad_hip.so")
 
-VCAD_F32, VCAD_BF16 = 0, 1
+VCAD_F32, VCAD_BF16, VCAD_BF16X3 = 0, 1, 2
 NMETRIC = 32
 
 # metric slots (csrc/loss.h)
