@@ -118,6 +118,41 @@ def test_bf16x3_step_in_tolerance_of_reference_goldens(golden_dir, case):
             assert np.abs(sl(eng.view(n)) - gold[k]).max() < 2e-6, n
 
 
+@pytest.mark.parametrize("dtype,tol", [(L.VCAD_F32, 1e-4), (L.VCAD_BF16X3, 1e-4), (L.VCAD_BF16, 8e-3)], ids=["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("case", ["long_t186", "long_t70"])
+def test_long_horizon_step_matches_reference_goldens(golden_dir, case, dtype, tol):
+    """B = 1 at T = 186 (maximum horizon: three 64-key blocks, band mask far off the diagonal tile, timestep rows to 185) and T = 70 against
+    goldens of the IMPORTED reference at those lengths (tests/golden/make_goldens.py, r03): logits, arg-max, loss, metrics, all 309
+    gradient norms and the clip norm.  fp32 and bf16x3 must meet north_star's gate (1e-3 relative, arg-max exact); bf16 is gated at
+    ~2x what it measures."""
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["cases"][case]
+    gold = np.load(os.path.join(golden_dir, case + ".npz"))
+    eng = build(dtype)
+    batch, cmds, pars, gc, gp, pcmp = run_case(eng, gold, meta["B"], meta["T"], meta["seed"], None, False)
+    rel_c, rel_p = U.relerr(cmds, gc), U.relerr(pcmp, gp)
+    agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
+    print(f"\n[measured {case} dtype={dtype}] logits rel cmd {rel_c:.3e} params {rel_p:.3e} arg-max agreement {agree:.4f}")
+    assert rel_c < tol and rel_p < tol, (rel_c, rel_p)
+    if dtype != L.VCAD_BF16:
+        assert float((pcmp - gp).abs().max()) < 1e-3 * float(gp.abs().max())
+        assert agree == 1.0 and np.array_equal(cmds.argmax(-1).cpu().numpy(), gold["cmds_argmax"])
+    else:
+        assert agree >= 0.97
+    loss, met = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
+    ltol = 1e-4 if dtype != L.VCAD_BF16 else 2e-2
+    assert abs(float(loss[0]) - float(gold["loss_fwd"])) < ltol * abs(float(gold["loss_fwd"]))
+    if dtype != L.VCAD_BF16:
+        gm = json.loads(str(gold["metrics_json"])); m = met.tolist()
+        assert m[L.MET_PAR_COUNT:L.MET_PAR_COUNT + 6] == gm["param_counts"] and m[L.MET_PAR_CORRECT:L.MET_PAR_CORRECT + 6] == gm["param_corrects"]
+        assert m[L.MET_CORRECT] == gm["correct_predictions"] and m[L.MET_TOTAL] == gm["total_predictions"]
+    eng.backward()
+    rels = [abs(float(eng.view(str(n), eng.grads).double().norm()) - gn) / (gn + 1e-12) for n, gn in zip(gold["grad_names"], gold["grad_norms"])]
+    print(f"[measured {case} dtype={dtype}] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
+    assert np.max(rels) < (3e-3 if dtype != L.VCAD_BF16 else 5e-2), np.max(rels)
+    norm = eng.optimizer_step(lr=1e-5)
+    assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < (1e-3 if dtype != L.VCAD_BF16 else 3e-2) * float(gold["total_grad_norm"])
+
+
 def test_f32_window1_forward(golden_dir):
     gold = np.load(os.path.join(golden_dir, "win1.npz"))
     cfg = dict(O.CANONICAL_CONFIG); cfg["window_size"] = 1

@@ -52,6 +52,25 @@ def test_oracle_step_matches_reference_goldens(weights, case):
             assert np.abs(sl(ot.P[n].grad) - g[k]).max() <= 1e-4 * np.abs(g[k]).max() + 1e-10, n
 
 
+@pytest.mark.parametrize("case", ["long_t186", "long_t70"])
+def test_oracle_long_horizon_matches_reference_goldens(weights, case):
+    """B = 1 at T = 186 (the maximum horizon) and T = 70: forward, loss and metrics of the IMPORTED reference at the lengths where
+    the causal / band masks span several 64-key blocks — the oracle is pinned there too, not assumed.  The
+    generator also checked all 309 gradients of the full step (meta.json: grad_rel_max 1e-6); the gradient norms are fixtures for
+    the GPU tests."""
+    meta = json.load(open(os.path.join(GOLD, "meta.json")))["cases"][case]
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    ot = O.OracleTrainer(weights)
+    with torch.no_grad():
+        cmds, params, tgt = ot.forward(synth.make_batch(meta["B"], meta["T"], meta["seed"]))
+        loss, metrics = O.compute_loss(cmds, params, tgt)
+    ref = torch.from_numpy(g["params"])
+    assert float((params[:, :, :, ::8] - ref).norm() / ref.norm()) < 5e-6
+    assert float((cmds - torch.from_numpy(g["cmds"])).norm() / torch.from_numpy(g["cmds"]).norm()) < 5e-6
+    assert np.array_equal(params.argmax(-1).numpy(), g["params_argmax"]) and np.array_equal(cmds.argmax(-1).numpy(), g["cmds_argmax"])
+    assert abs(float(loss) - float(g["loss_fwd"])) < 1e-5 * abs(float(g["loss_fwd"])) and metrics == json.loads(str(g["metrics_json"]))
+
+
 def test_oracle_window1_and_loss_cases(weights):
     g = np.load(os.path.join(GOLD, "win1.npz"))
     cfg = dict(O.CANONICAL_CONFIG); cfg["window_size"] = 1

@@ -32,11 +32,27 @@ VC_DEV void af_zero(vc_f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 VC_DEV int af_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }     // accumulator row of register r (MFMA 32x32 D layout)
+// the 16 B-fragment rows of one 32-row tile: dst[r] = the 8-byte column pair at `col` of row (row0 + af_row(r, half)), clamped to nrows - 1
+VC_DEV void af_rows16(vc_u32x2 (&dst)[16], const float* col, long rowbase, long ld, int row0, int half, int nrows, bool skip) {
+    if (skip) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = row0 + af_row(r, half), jl = j < nrows ? j : nrows - 1;
+        dst[r] = *reinterpret_cast<const vc_u32x2*>(col + (rowbase + jl) * ld);
+    }
+}
+// keeps the memory operations above it above (the prefetch of the next work item must be issued BEFORE the current item's MFMAs)
+#ifndef VC_EMU
+VC_DEV void af_pin() { asm volatile("" ::: "memory"); }
+#else
+VC_DEV void af_pin() {}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------ forward
 // one wave per (batch, head, 32-query block)
-template <int NCH, int NKT>
-VC_KERNEL __launch_bounds__(256) void attn_f32_fwd_kernel(AttnParams p) {
+// FULL: no causal / window mask (the ViT): the per-element visibility test reduces to the padding bound
+template <int NCH, int NKT, bool FULL>
+VC_KERNEL __launch_bounds__(256, 2) void attn_f32_fwd_kernel(AttnParams p) {
     constexpr int D = 64 * NCH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, half = lane >> 5;
     const int nqb = (p.Tq + 31) >> 5;
@@ -64,6 +80,9 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_fwd_kernel(AttnParams p) {
             for (int kk = 0; kk < 32; ++kk) st[t] = vc_mfma_32x32x2_f32(kf[kk], qf[kk], st[t]);
         }
     }
+    vc_u32x2 vb[2][16];
+    af_rows16(vb[0], (const float*)p.v + (long)h * D + 2 * il, b * p.Tk, p.ldv, 0, half, p.Tk, 0 > j_max || 31 < j_min);
+    af_pin();
     // softmax over this lane's query: its 16*NKT keys here + the partner half's
     float m = -INFINITY;
 #pragma unroll
@@ -71,7 +90,7 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t * 32 + af_row(r, half);
-            const float s = (j >= lo && j <= hi) ? st[t][r] * p.scale : -INFINITY;
+            const float s = (FULL ? j < p.Tk : (j >= lo && j <= hi)) ? vc_mul_rn(st[t][r], p.scale) : -INFINITY;     // rounded on its own: the backward forms the same product (see there)
             st[t][r] = s; m = fmaxf(m, s);
         }
     m = fmaxf(m, vc_shfl_xor(m, 32));
@@ -79,7 +98,7 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float e = expf(st[t][r] - m); st[t][r] = e; l += e; }       // exp(-inf) = 0 for masked keys
+        for (int r = 0; r < 16; ++r) { const float e = vc_expf_fast(st[t][r] - m); st[t][r] = e; l += e; }       // v_exp_f32 (exp(-inf) = 0 for masked keys, exp(0) = 1 exactly)
     l += vc_shfl_xor(l, 32);
     const float inv = 1.0f / l;
     const long dbase = ((b * p.H + h) * p.Tq + iq) * p.Tk;
@@ -92,35 +111,38 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_fwd_kernel(AttnParams p) {
             st[t][r] = pr;
         }
     if (p.lse && half == 0 && i < p.Tq) p.lse[(b * p.H + h) * p.Tq + i] = m + logf(l);
-    // O[i][d] = sum_j P[i][j] V[j][d]: A = P from the accumulator registers, B = V rows (lane = column pair 2*il, 2*il + 1 of the chunk)
+    // O[i][d] = sum_j P[i][j] V[j][d]: A = P from the accumulator registers, B = V rows (lane = column pair 2*il, 2*il + 1 of the chunk).
+    // Work items (chunk, key tile): the 16 row reads of item n + 1 are in flight while item n's 32 MFMAs run (the first item's were
+    // requested before the softmax) — with one read per MFMA pair a wave waits out a memory round trip per pair.
+    vc_f32x16 o0, o1; af_zero(o0); af_zero(o1);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        vc_f32x16 o0, o1; af_zero(o0); af_zero(o1);
-        const float* vcol = (const float*)p.v + (long)h * D + c * 64 + 2 * il;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-            if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
+    for (int it = 0; it < NCH * NKT; ++it) {
+        const int c = it / NKT, t = it % NKT;
+        if (it + 1 < NCH * NKT) af_rows16(vb[(it + 1) & 1], (const float*)p.v + (long)h * D + ((it + 1) / NKT) * 64 + 2 * il, b * p.Tk, p.ldv, ((it + 1) % NKT) * 32, half, p.Tk, ((it + 1) % NKT) * 32 > j_max || ((it + 1) % NKT) * 32 + 31 < j_min);
+        af_pin();
+        if (!(t * 32 > j_max || t * 32 + 31 < j_min)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = t * 32 + af_row(r, half), jl = j < p.Tk ? j : p.Tk - 1;
-                const vc_u32x2 vv = *reinterpret_cast<const vc_u32x2*>(vcol + (b * p.Tk + jl) * p.ldv);
-                o0 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(vv.x), o0);
-                o1 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(vv.y), o1);
+                o0 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(vb[it & 1][r].x), o0);
+                o1 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(vb[it & 1][r].y), o1);
             }
         }
-        float* ocol = (float*)p.o + (long)h * D + c * 64 + 2 * il;
+        if (t == NKT - 1) {
+            float* ocol = (float*)p.o + (long)h * D + c * 64 + 2 * il;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int io = qb * 32 + af_row(r, half);
-            if (io < p.Tq) { vc_u32x2 w; w.x = vc_f32_bits(o0[r]); w.y = vc_f32_bits(o1[r]); *reinterpret_cast<vc_u32x2*>(ocol + (b * p.Tq + io) * p.ldo) = w; }
+            for (int r = 0; r < 16; ++r) {
+                const int io = qb * 32 + af_row(r, half);
+                if (io < p.Tq) { vc_u32x2 w; w.x = vc_f32_bits(o0[r]); w.y = vc_f32_bits(o1[r]); *reinterpret_cast<vc_u32x2*>(ocol + (b * p.Tq + io) * p.ldo) = w; }
+            }
+            af_zero(o0); af_zero(o1);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward, query side
 // one wave per (batch, head, 32-query block): D_i = sum_j P_ij dP_ij -> delta,  dq_i = scale * sum_j dS_ij k_j
-template <int NCH, int NKT>
-VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_q_kernel(AttnParams p) {
+template <int NCH, int NKT, bool FULL>
+VC_KERNEL __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(AttnParams p) {
     constexpr int D = 64 * NCH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, half = lane >> 5;
     const int nqb = (p.Tq + 31) >> 5;
@@ -152,6 +174,9 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_q_kernel(AttnParams p) {
             for (int kk = 0; kk < 32; ++kk) dpt[t] = vc_mfma_32x32x2_f32(vf[kk], df[kk], dpt[t]);
         }
     }
+    vc_u32x2 kb[2][16];
+    af_rows16(kb[0], (const float*)p.k + (long)h * D + 2 * il, b * p.Tk, p.ldk, 0, half, p.Tk, 0 > j_max || 31 < j_min);
+    af_pin();
     const float lse = p.lse[(b * p.H + h) * p.Tq + iq];
     const long dbase = ((b * p.H + h) * p.Tq + iq) * p.Tk;
     float dsum = 0.f;
@@ -160,10 +185,10 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_q_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = t * 32 + af_row(r, half);
-            const bool vis = j >= lo && j <= hi;
-            const float pr = vis ? expf(st[t][r] * p.scale - lse) : 0.f;
+            const bool vis = FULL ? j < p.Tk : (j >= lo && j <= hi);
+            const float pr = vis ? vc_expf_fast(vc_mul_rn(st[t][r], p.scale) - lse) : 0.f;     // the forward's rounded product: a query with ONE visible key gets P = 1 and dS = 0 exactly, as in the reference
             float dp = vis ? dpt[t][r] : 0.f;
-            if (p.drop.key && vis) dp *= vc_drop_mul(p.drop, (uint32_t)(dbase + j));        // dP = dP' * mask
+            if (p.drop.key && vis) dp = vc_mul_rn(dp, vc_drop_mul(p.drop, (uint32_t)(dbase + j)));        // dP = dP' * mask
             st[t][r] = pr; dpt[t][r] = dp; dsum += pr * dp;
         }
     dsum += vc_shfl_xor(dsum, 32);
@@ -172,26 +197,27 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_q_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * (dpt[t][r] - dsum) * p.scale;      // dS (scale folded in)
     if (half == 0 && i < p.Tq) p.delta[(b * p.H + h) * p.Tq + i] = dsum;
+    vc_f32x16 o0, o1; af_zero(o0); af_zero(o1);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        vc_f32x16 o0, o1; af_zero(o0); af_zero(o1);
-        const float* kcol = (const float*)p.k + (long)h * D + c * 64 + 2 * il;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-            if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
+    for (int it = 0; it < NCH * NKT; ++it) {          // work items (chunk, key tile), K rows of item n + 1 in flight during item n's MFMAs
+        const int c = it / NKT, t = it % NKT;
+        if (it + 1 < NCH * NKT) af_rows16(kb[(it + 1) & 1], (const float*)p.k + (long)h * D + ((it + 1) / NKT) * 64 + 2 * il, b * p.Tk, p.ldk, ((it + 1) % NKT) * 32, half, p.Tk, ((it + 1) % NKT) * 32 > j_max || ((it + 1) % NKT) * 32 + 31 < j_min);
+        af_pin();
+        if (!(t * 32 > j_max || t * 32 + 31 < j_min)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int j = t * 32 + af_row(r, half), jl = j < p.Tk ? j : p.Tk - 1;
-                const vc_u32x2 kv = *reinterpret_cast<const vc_u32x2*>(kcol + (b * p.Tk + jl) * p.ldk);
-                o0 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(kv.x), o0);
-                o1 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(kv.y), o1);
+                o0 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(kb[it & 1][r].x), o0);
+                o1 = vc_mfma_32x32x2_f32(st[t][r], vc_bits_f32(kb[it & 1][r].y), o1);
             }
         }
-        float* dqcol = (float*)p.dq + (long)h * D + c * 64 + 2 * il;
+        if (t == NKT - 1) {
+            float* dqcol = (float*)p.dq + (long)h * D + c * 64 + 2 * il;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int io = qb * 32 + af_row(r, half);
-            if (io < p.Tq) { vc_u32x2 w; w.x = vc_f32_bits(o0[r]); w.y = vc_f32_bits(o1[r]); *reinterpret_cast<vc_u32x2*>(dqcol + (b * p.Tq + io) * p.lddq) = w; }
+            for (int r = 0; r < 16; ++r) {
+                const int io = qb * 32 + af_row(r, half);
+                if (io < p.Tq) { vc_u32x2 w; w.x = vc_f32_bits(o0[r]); w.y = vc_f32_bits(o1[r]); *reinterpret_cast<vc_u32x2*>(dqcol + (b * p.Tq + io) * p.lddq) = w; }
+            }
+            af_zero(o0); af_zero(o1);
         }
     }
 }
@@ -199,8 +225,8 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_q_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------------------ backward, key side
 // one wave per (batch, head, 32-key block): dk_j = scale * sum_i dS_ij q_i,  dv_j = sum_i P'_ij dO_i   (P' = dropped probabilities)
 // NQT = query tiles of 32.  Unswapped orientation: accumulator column = key (lane), row = query.
-template <int NCH, int NQT>
-VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_kv_kernel(AttnParams p) {
+template <int NCH, int NQT, bool FULL>
+VC_KERNEL __launch_bounds__(256, 2) void attn_f32_bwd_kv_kernel(AttnParams p) {
     constexpr int D = 64 * NCH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, il = lane & 31, half = lane >> 5;
     const int nkb = (p.Tk + 31) >> 5;
@@ -232,50 +258,57 @@ VC_KERNEL __launch_bounds__(256) void attn_f32_bwd_kv_kernel(AttnParams p) {
             for (int kk = 0; kk < 32; ++kk) dp[t] = vc_mfma_32x32x2_f32(df[kk], vf[kk], dp[t]);
         }
     }
+    vc_u32x2 rb[2][16];
+    af_rows16(rb[0], (const float*)p.dout + (long)h * D + 2 * il, b * p.Tq, p.lddo, 0, half, p.Tq, 0 > i_max || 31 < i_min);
+    af_pin();
     // P'^T (-> s) and dS^T (-> dp): row = query i_r, column = this lane's key j
 #pragma unroll
     for (int t = 0; t < NQT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = t * 32 + af_row(r, half);
-            const int lo = i - p.window + 1 > 0 ? i - p.window + 1 : 0, hi = p.causal ? (i < p.Tk - 1 ? i : p.Tk - 1) : p.Tk - 1;
-            const bool vis = i < p.Tq && j >= lo && j <= hi && j < p.Tk;
+            bool vis = i < p.Tq && j < p.Tk;
+            if constexpr (!FULL) { const int lo = i - p.window + 1 > 0 ? i - p.window + 1 : 0, hi = p.causal ? (i < p.Tk - 1 ? i : p.Tk - 1) : p.Tk - 1; vis = vis && j >= lo && j <= hi; }
             float pr = 0.f, ds = 0.f;
             if (vis) {
                 const long sidx = (b * p.H + h) * p.Tq + i;
-                pr = expf(s[t][r] * p.scale - p.lse[sidx]);
+                pr = vc_expf_fast(vc_mul_rn(s[t][r], p.scale) - p.lse[sidx]);
                 const float ms = p.drop.key ? vc_drop_mul(p.drop, (uint32_t)(sidx * p.Tk + j)) : 1.0f;
-                ds = pr * (dp[t][r] * ms - p.delta[sidx]) * p.scale;
+                ds = pr * (vc_mul_rn(dp[t][r], ms) - p.delta[sidx]) * p.scale;        // (the query-side kernel rounded dP * mask before it summed D_i)
                 pr *= ms;
             }
             s[t][r] = pr; dp[t][r] = ds;
         }
+    // work items (chunk, product, query tile): dV = P'^T dO (B rows = dO), then dK = dS^T Q (B rows = Q); rows of item n + 1 in flight
+    // during item n's 32 MFMAs
+    vc_f32x16 a0, a1; af_zero(a0); af_zero(a1);
+    constexpr int NIT = NCH * 2 * NQT;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        vc_f32x16 v0, v1, k0, k1; af_zero(v0); af_zero(v1); af_zero(k0); af_zero(k1);
-        const float* docol = (const float*)p.dout + (long)h * D + c * 64 + 2 * il;
-        const float* qcol = (const float*)p.q + (long)h * D + c * 64 + 2 * il;
-#pragma unroll
-        for (int t = 0; t < NQT; ++t) {
-            if (t * 32 > i_max || t * 32 + 31 < i_min) continue;
+    for (int it = 0; it < NIT; ++it) {
+        const int c = it / (2 * NQT), pr = (it / NQT) & 1, t = it % NQT;
+        if (it + 1 < NIT) {
+            const int c1 = (it + 1) / (2 * NQT), pr1 = ((it + 1) / NQT) & 1, t1 = (it + 1) % NQT;
+            af_rows16(rb[(it + 1) & 1], (pr1 ? (const float*)p.q : (const float*)p.dout) + (long)h * D + c1 * 64 + 2 * il, b * p.Tq, pr1 ? p.ldq : p.lddo, t1 * 32, half, p.Tq,
+                      t1 * 32 > i_max || t1 * 32 + 31 < i_min);
+        }
+        af_pin();
+        if (!(t * 32 > i_max || t * 32 + 31 < i_min)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = t * 32 + af_row(r, half), ic = i < p.Tq ? i : p.Tq - 1;
-                const vc_u32x2 dv = *reinterpret_cast<const vc_u32x2*>(docol + (b * p.Tq + ic) * p.lddo);
-                const vc_u32x2 qv = *reinterpret_cast<const vc_u32x2*>(qcol + (b * p.Tq + ic) * p.ldq);
-                v0 = vc_mfma_32x32x2_f32(s[t][r], vc_bits_f32(dv.x), v0); v1 = vc_mfma_32x32x2_f32(s[t][r], vc_bits_f32(dv.y), v1);
-                k0 = vc_mfma_32x32x2_f32(dp[t][r], vc_bits_f32(qv.x), k0); k1 = vc_mfma_32x32x2_f32(dp[t][r], vc_bits_f32(qv.y), k1);
+                const float av = pr ? dp[t][r] : s[t][r];
+                a0 = vc_mfma_32x32x2_f32(av, vc_bits_f32(rb[it & 1][r].x), a0);
+                a1 = vc_mfma_32x32x2_f32(av, vc_bits_f32(rb[it & 1][r].y), a1);
             }
         }
-        float* dkcol = (float*)p.dk + (long)h * D + c * 64 + 2 * il;
-        float* dvcol = (float*)p.dv + (long)h * D + c * 64 + 2 * il;
+        if (t == NQT - 1) {
+            float* ocol = (pr ? (float*)p.dk : (float*)p.dv) + (long)h * D + c * 64 + 2 * il;
+            const long ldo_ = pr ? p.lddk : p.lddv;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jo = kb * 32 + af_row(r, half);
-            if (jo < p.Tk) {
-                vc_u32x2 w; w.x = vc_f32_bits(k0[r]); w.y = vc_f32_bits(k1[r]); *reinterpret_cast<vc_u32x2*>(dkcol + (b * p.Tk + jo) * p.lddk) = w;
-                vc_u32x2 u; u.x = vc_f32_bits(v0[r]); u.y = vc_f32_bits(v1[r]); *reinterpret_cast<vc_u32x2*>(dvcol + (b * p.Tk + jo) * p.lddv) = u;
+            for (int r = 0; r < 16; ++r) {
+                const int jo = kb * 32 + af_row(r, half);
+                if (jo < p.Tk) { vc_u32x2 w; w.x = vc_f32_bits(a0[r]); w.y = vc_f32_bits(a1[r]); *reinterpret_cast<vc_u32x2*>(ocol + (b * p.Tk + jo) * ldo_) = w; }
             }
+            af_zero(a0); af_zero(a1);
         }
     }
 }

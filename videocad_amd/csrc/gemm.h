@@ -206,18 +206,43 @@ template <> struct GemmCfg<float> {
 template <> struct GemmCfg<vc_bf16> {
     static constexpr int BK = 64, CHUNK = 8, STRIDE = 72, KSTEP = 16, PLANES = 1;
 };
-// BK = 32 keeps the double-buffered stage set of a 128 x 128 tile at 80 KiB (two planes per operand), so two workgroups still share a
-// CU's 160 KiB; row stride 40 elements = 20 dwords: the 16 lanes a ds_read_b128 services per cycle land on 64 distinct banks
+// BK = 32 and UNPADDED planes (k-contiguous image: 64-byte rows, the 16-byte chunk index XOR-ed with bits 2-3 of the row; row-contiguous
+// image of a 128-row tile: 256-byte k-rows, the column XOR-ed with (k & 3) * 32 — both conflict-free for their fragment reads) keep the
+// double-buffered stage set of a 128 x 128 tile at 64 KiB, under the 66 KiB epilogue tile: two workgroups share a CU's 160 KiB.  (The
+// first version padded the rows — 80 KiB per workgroup, one workgroup per CU, every phase of the loop exposed: 150 TF/s in the model.)
 template <> struct GemmCfg<vc_x3> {
-    static constexpr int BK = 32, CHUNK = 8, STRIDE = 40, KSTEP = 16, PLANES = 2;
+    static constexpr int BK = 32, CHUNK = 4, STRIDE = 32, KSTEP = 16, PLANES = 2;      // a staged chunk = ONE 16-byte fp32 quad (whole 128-byte lines per 8 lanes)
 };
-template <typename CT> struct gemm_is_x3 { static constexpr bool value = false; };
-template <> struct gemm_is_x3<vc_x3> { static constexpr bool value = true; };
 // hi / lo split of two fp32 values into packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi) (exact subtraction)
 VC_DEV void gemm_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = vc_pack_bf16x2(a, b);
     lo = vc_pack_bf16x2(a - vc_bits_f32(hi << 16), b - vc_bits_f32(hi & 0xFFFF0000u));
 }
+// the same for one 16-byte quad, written on 2-element vectors so that hipcc emits v_cvt_pk_bf16_f32 / v_pk_add_f32 on the (x0, x1), (x2, x3)
+// register pairs the load delivered: 10 VALU instructions per quad.  Left to its own pairing (it chose (x0, x2), (x1, x3)) the compiler
+// spent 16-20 on moves and sub-dword ORs — and the k-loop of the bf16x3 kernel is VALU-bound (281 VALU per 24 MFMAs, profiles/r03_x3_pmc.md)
+VC_DEV void gemm_split4(const vc_u32x4& a, vc_u32x2& hi, vc_u32x2& lo) {
+#ifndef VC_EMU
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+    const f2 x01 = {vc_bits_f32(a.x), vc_bits_f32(a.y)}, x23 = {vc_bits_f32(a.z), vc_bits_f32(a.w)};
+    hi.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(x01, h2));
+    hi.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(x23, h2));
+    const f2 t01 = {vc_bits_f32(hi.x << 16), vc_bits_f32(hi.x & 0xFFFF0000u)}, t23 = {vc_bits_f32(hi.y << 16), vc_bits_f32(hi.y & 0xFFFF0000u)};
+    lo.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(x01 - t01, h2));
+    lo.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(x23 - t23, h2));
+#else
+    gemm_split2(vc_bits_f32(a.x), vc_bits_f32(a.y), hi.x, lo.x); gemm_split2(vc_bits_f32(a.z), vc_bits_f32(a.w), hi.y, lo.y);
+#endif
+}
+struct gemm_true { static constexpr bool value = true; };
+struct gemm_false { static constexpr bool value = false; };
+// pipeline-stage ablation switches (tools/gemm_ablate*.py) exist only in the -DVCAD_AB build used by tools/; the shipped kernels carry no such branches
+#ifdef VCAD_AB
+#define VC_ABL(bit) (p.debug_skip & (bit))
+#else
+#define VC_ABL(bit) false
+#endif
 constexpr int GEMM_THREADS = 256;      // 4 waves as 2 x 2; each wave owns WT x WT MFMA 32x32 tiles => block tile = (64*WT)^2
 
 // LDS image of one operand tile:
@@ -226,9 +251,12 @@ constexpr int GEMM_THREADS = 256;      // 4 waves as 2 x 2; each wave owns WT x 
 //            fragment = two ds_read_b64_tr_b16 (hardware transpose); the 64-byte row pad puts the 4 k-rows a
 //            transpose-read touches on disjoint banks
 //   f32  TR  : transposed on the way into LDS (scalar ds_write_b32), same image as direct
-template <int ROWS> constexpr int gemm_tstride() { return ROWS + 32; }
+template <typename CT> struct gemm_is_x3 { static constexpr bool value = false; };
+template <> struct gemm_is_x3<vc_x3> { static constexpr bool value = true; };
+template <typename CT, int ROWS> constexpr bool gemm_tswz() { return gemm_is_x3<CT>::value && ROWS == 128; }      // row-contiguous image without padding (XOR swizzle)
+template <typename CT, int ROWS> constexpr int gemm_tstride() { return gemm_tswz<CT, ROWS>() ? ROWS : ROWS + 32; }
 template <typename CT, bool TR, int ROWS> constexpr int gemm_plane_elems() {
-    return (sizeof(CT) == 2 && TR) ? GemmCfg<CT>::BK * gemm_tstride<ROWS>() : ROWS * GemmCfg<CT>::STRIDE;
+    return (sizeof(CT) == 2 && TR) ? GemmCfg<CT>::BK * gemm_tstride<CT, ROWS>() : ROWS * GemmCfg<CT>::STRIDE;
 }
 template <typename CT, bool TR, int ROWS> constexpr int gemm_tile_elems() { return GemmCfg<CT>::PLANES * gemm_plane_elems<CT, TR, ROWS>(); }
 template <typename CT, bool TRA, bool TRB, int WT> constexpr size_t gemm_lds_bytes() {
@@ -252,11 +280,11 @@ template <typename CT, typename ST, bool TR, int ROWS>
 struct GemmStager {
     static constexpr int BK = GemmCfg<CT>::BK, CH = GemmCfg<CT>::CHUNK, STRIDE = GemmCfg<CT>::STRIDE;
     static constexpr int NCH = ROWS * BK / CH / GEMM_THREADS;     // chunks per thread (4 for 128 rows, 2 for 64; bf16x3: 2 and 1)
-    static constexpr int TS = gemm_tstride<ROWS>();
-    static constexpr bool X3 = gemm_is_x3<CT>::value;             // registers hold the RAW fp32 chunk (two quads); the hi / lo split happens in store()
+    static constexpr int TS = gemm_tstride<CT, ROWS>();
+    static constexpr bool X3 = gemm_is_x3<CT>::value;             // registers hold the RAW fp32 chunk (one quad = 4 elements); the hi / lo split happens in store()
     static constexpr int PLANE = gemm_plane_elems<CT, TR, ROWS>();
     static_assert(!X3 || sizeof(ST) == 4, "bf16x3 splits fp32 sources");
-    vc_u32x4 regs[NCH * (X3 ? 2 : 1)];
+    vc_u32x4 regs[NCH];
 
     // interior tile + 16-byte-aligned operand: straight-line vector loads (no per-chunk branch, so all loads of a
     // K-tile are in flight together; a divergent bounds test per chunk makes hipcc drain vmcnt after every load)
@@ -268,7 +296,7 @@ struct GemmStager {
             if constexpr (!TR) p = base + (long)(r0 + c / (BK / CH)) * ld + (k0 + (c % (BK / CH)) * CH);
             else p = base + (long)(k0 + c / (ROWS / CH)) * ld + (r0 + (c % (ROWS / CH)) * CH);
             if constexpr (X3) {
-                regs[2 * i] = reinterpret_cast<const vc_u32x4*>(p)[0]; regs[2 * i + 1] = reinterpret_cast<const vc_u32x4*>(p)[1];
+                regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
             } else if constexpr (sizeof(ST) == sizeof(CT)) {
                 regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
             } else {   // fp32 source feeding bf16 MFMA
@@ -297,26 +325,32 @@ struct GemmStager {
             float f[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j) f[j] = (j < nv) ? vc_cvt<ST>::to_f32(p[j]) : 0.0f;
-            if constexpr (X3) {
-                regs[2 * i].x = vc_f32_bits(f[0]); regs[2 * i].y = vc_f32_bits(f[1]); regs[2 * i].z = vc_f32_bits(f[2]); regs[2 * i].w = vc_f32_bits(f[3]);
-                regs[2 * i + 1].x = vc_f32_bits(f[4]); regs[2 * i + 1].y = vc_f32_bits(f[5]); regs[2 * i + 1].z = vc_f32_bits(f[6]); regs[2 * i + 1].w = vc_f32_bits(f[7]);
-            } else regs[i] = gemm_pack_chunk<CT, ST>(f);
+            if constexpr (X3) { regs[i].x = vc_f32_bits(f[0]); regs[i].y = vc_f32_bits(f[1]); regs[i].z = vc_f32_bits(f[2]); regs[i].w = vc_f32_bits(f[3]); }
+            else regs[i] = gemm_pack_chunk<CT, ST>(f);
         }
+    }
+    // "the loaded values are used HERE": without it hipcc hoists the hi / lo split of a bf16x3 tile (pure arithmetic on the load results)
+    // above the MFMAs of the previous tile — right behind the loads, whose latency the MFMAs were meant to hide
+    VC_DEV void pin() {
+#ifndef VC_EMU
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) asm volatile("" : "+v"(regs[i].x), "+v"(regs[i].y), "+v"(regs[i].z), "+v"(regs[i].w));
+#endif
     }
     VC_DEV void store(CT* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int c = tid + GEMM_THREADS * i;
-            if constexpr (X3) {       // split the fp32 chunk into its hi and lo bf16 planes (same image in both)
-                const vc_u32x4 a = regs[2 * i], b = regs[2 * i + 1];
-                vc_u32x4 hi, lo;
-                gemm_split2(vc_bits_f32(a.x), vc_bits_f32(a.y), hi.x, lo.x); gemm_split2(vc_bits_f32(a.z), vc_bits_f32(a.w), hi.y, lo.y);
-                gemm_split2(vc_bits_f32(b.x), vc_bits_f32(b.y), hi.z, lo.z); gemm_split2(vc_bits_f32(b.z), vc_bits_f32(b.w), hi.w, lo.w);
-                int off;
-                if constexpr (!TR) off = (c / (BK / CH)) * STRIDE + (c % (BK / CH)) * CH;
+            if constexpr (X3) {       // split the fp32 quad into its hi and lo bf16 planes (same image in both): two 8-byte LDS stores
+                const vc_u32x4 a = regs[i];
+                vc_u32x2 hi, lo;
+                gemm_split4(a, hi, lo);
+                int off;          // 16-byte slots are swizzled, the two 8-byte halves of a slot stay in order
+                if constexpr (!TR) { const int row = c / (BK / CH), q = c % (BK / CH); off = row * STRIDE + (((q >> 1) ^ ((row >> 2) & 3)) * 8) + (q & 1) * 4; }
+                else if constexpr (gemm_tswz<CT, ROWS>()) { const int k = c / (ROWS / CH); off = k * TS + (((c % (ROWS / CH)) * CH) ^ ((k & 3) << 5)); }
                 else off = (c / (ROWS / CH)) * TS + (c % (ROWS / CH)) * CH;
-                *reinterpret_cast<vc_u32x4*>(lds + off) = hi;
-                *reinterpret_cast<vc_u32x4*>(lds + PLANE + off) = lo;
+                *reinterpret_cast<vc_u32x2*>(lds + off) = hi;
+                *reinterpret_cast<vc_u32x2*>(lds + PLANE + off) = lo;
                 continue;
             }
             const uint32_t w[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
@@ -346,12 +380,17 @@ struct GemmStager {
 // bf16 MFMA fragment (8 k-values of one row) for k-step ks of the tile; row0 = first row of the wave's 32-row block
 template <bool TR, int ROWS, typename CT = vc_bf16>
 VC_DEV vc_s16x8 gemm_frag_bf16(const CT* tile, int row0, int ks, int lane) {
-    constexpr int GEMM_TSTRIDE = gemm_tstride<ROWS>();
-    if constexpr (!TR) {
+    constexpr int GEMM_TSTRIDE = gemm_tstride<CT, ROWS>();
+    if constexpr (!TR && gemm_is_x3<CT>::value) {     // unpadded 64-byte rows, chunk index swizzled by bits 2-3 of the row (row0 is a multiple of 32)
+        return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * GemmCfg<CT>::STRIDE + (((ks * 2 + (lane >> 5)) ^ ((lane >> 2) & 3)) * 8));
+    } else if constexpr (!TR) {
         return *reinterpret_cast<const vc_s16x8*>(tile + (row0 + (lane & 31)) * GemmCfg<CT>::STRIDE + ks * 16 + (lane >> 5) * 8);
     } else {
         const int i = lane & 15;
-        const CT* p = tile + (ks * 16 + 8 * (lane >> 5) + (i >> 2)) * GEMM_TSTRIDE + row0 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+        const int k = ks * 16 + 8 * (lane >> 5) + (i >> 2);
+        int col = row0 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+        if constexpr (gemm_tswz<CT, ROWS>()) col ^= (k & 3) << 5;          // (k + 4 shares k & 3: the second read is 4 rows further down)
+        const CT* p = tile + k * GEMM_TSTRIDE + col;
         const vc_s16x4 lo = vc_ds_read_tr16(p), hi = vc_ds_read_tr16(p + 4 * GEMM_TSTRIDE);
         vc_s16x8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -413,11 +452,16 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
     const SB* Bg = (const SB*)p.B;
     const bool rowsA = p.vecA && (m0 + GEMM_BM <= p.M), rowsB = p.vecB && (n0 + GEMM_BN <= p.N);   // block-uniform
 
-    auto fetch = [&](GemmStager<CT, SA, TRA, GEMM_BM>& sa, GemmStager<CT, SB, TRB, GEMM_BN>& sb, int t) {
+    // `fast` (compile-time): interior block with vector-aligned operands and whole k-tiles — straight-line 16-byte loads only
+    auto fetch = [&](auto fast, GemmStager<CT, SA, TRA, GEMM_BM>& sa, GemmStager<CT, SB, TRB, GEMM_BN>& sb, int t) {
         const int k1 = kbeg + t * BK;
-        const bool kfull = k1 + BK <= kend;
-        if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid); else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
-        if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid); else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
+        if constexpr (decltype(fast)::value) {
+            sa.load_fast(Ag, p.lda, m0, k1, tid); sb.load_fast(Bg, p.ldb, n0, k1, tid);
+        } else {
+            const bool kfull = k1 + BK <= kend;
+            if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid); else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
+            if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid); else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
+        }
     };
     auto compute = [&](int cur) {
         const CT* a_tile = lds + cur * TILE;
@@ -477,26 +521,83 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
         }
     };
 
-    if (nt > 0) {
-        fetch(sa0, sb0, 0);
-        if (nt > 1) fetch(sa1, sb1, 1);
-        sa0.store(lds, tid); sb0.store(lds + ATILE, tid);
-    }
-    vc_sync();
-    const int dbg = p.debug_skip;
-    for (int t = 0; t < nt; t += 2) {
-        if (t + 2 < nt && !(dbg & 1)) fetch(sa0, sb0, t + 2);       // set 0 is free: tile t already sits in LDS buffer 0
-        if (!(dbg & 4)) compute(0);
-        if (t + 1 < nt && !(dbg & 2)) { sa1.store(lds + TILE, tid); sb1.store(lds + TILE + ATILE, tid); }
+    // The k-loop exists twice.  Interior blocks of aligned problems (every block of the hot Linears) take the branch-free copy: when the
+    // bounds-checked element loads shared the loop with the vector loads, the values of both paths met in the same registers and hipcc
+    // waited for every prefetch right where it was issued (vmcnt(0) before the MFMAs: no overlap at all for the bf16x3 kernel, a
+    // one-tile-deep prefetch for the bf16 one) — r03.
+    auto k_loop = [&](auto fast) VC_INLINE_LAMBDA {
+        if (nt > 0) {
+            fetch(fast, sa0, sb0, 0);
+            if (nt > 1) fetch(fast, sa1, sb1, 1);
+            sa0.store(lds, tid); sb0.store(lds + ATILE, tid);
+        }
         vc_sync();
-        if (t + 1 >= nt) break;
-        if (t + 3 < nt && !(dbg & 1)) fetch(sa1, sb1, t + 3);
-        if (!(dbg & 4)) compute(1);
-        if (t + 2 < nt && !(dbg & 2)) { sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
+        int t = 0;
+        // steady state (tiles t + 2 and t + 3 exist): no conditionals around the prefetches, so the number of loads in flight at every
+        // wait is a compile-time constant (a prefetch issued under `if (t + 2 < nt)` made hipcc wait with vmcnt(0) at the next LDS store —
+        // the loads it had JUST issued included)
+        if constexpr (decltype(fast)::value) {
+            for (; t + 3 < nt && !VC_ABL(7); t += 2) {
+                fetch(fast, sa0, sb0, t + 2);
+                compute(0);
+                sa1.store(lds + TILE, tid); sb1.store(lds + TILE + ATILE, tid);
+                vc_sync();
+                fetch(fast, sa1, sb1, t + 3);
+                compute(1);
+                sa0.store(lds, tid); sb0.store(lds + ATILE, tid);
+                vc_sync();
+            }
+        }
+        // tail (and the whole loop of edge blocks): invariant at the top — LDS buffer 0 holds tile t, register set 1 tile t + 1
+        for (; t < nt; t += 2) {
+            if (t + 2 < nt && !VC_ABL(1)) fetch(fast, sa0, sb0, t + 2);       // set 0 is free: tile t already sits in LDS buffer 0
+            if (!VC_ABL(4)) compute(0);
+            if (t + 1 < nt && !VC_ABL(2)) { sa1.store(lds + TILE, tid); sb1.store(lds + TILE + ATILE, tid); }
+            vc_sync();
+            if (t + 1 >= nt) break;
+            if (t + 3 < nt && !VC_ABL(1)) fetch(fast, sa1, sb1, t + 3);
+            if (!VC_ABL(4)) compute(1);
+            if (t + 2 < nt && !VC_ABL(2)) { sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
+            vc_sync();
+        }
+    };
+    // bf16x3: ONE register set (the raw fp32 tile is 32 registers per operand pair; two sets spill) — tile t + 1 flies during tile t's
+    // 24 MFMAs and the other workgroup on the CU covers the rest.  Invariant at the top of an iteration: LDS buffer 0 holds tile t.
+    auto k_loop1 = [&](auto fast) VC_INLINE_LAMBDA {
+        if (nt > 0) { fetch(fast, sa0, sb0, 0); sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
         vc_sync();
-    }
+        int t = 0;
+        if constexpr (decltype(fast)::value) {
+            for (; t + 2 < nt; t += 2) {      // (the fences pin "loads, then MFMAs, then split + LDS stores": left alone, hipcc sinks the loads below the MFMAs, next to their use)
+                fetch(fast, sa0, sb0, t + 1); vc_sched_fence();
+                compute(0); vc_sched_fence();
+                sa0.pin(); sb0.pin(); sa0.store(lds + TILE, tid); sb0.store(lds + TILE + ATILE, tid);
+                vc_sync();
+                fetch(fast, sa0, sb0, t + 2); vc_sched_fence();
+                compute(1); vc_sched_fence();
+                sa0.pin(); sb0.pin(); sa0.store(lds, tid); sb0.store(lds + ATILE, tid);
+                vc_sync();
+            }
+        }
+        for (; t < nt; t += 2) {
+            if (t + 1 < nt) fetch(fast, sa0, sb0, t + 1);
+            compute(0);
+            if (t + 1 < nt) { sa0.store(lds + TILE, tid); sb0.store(lds + TILE + ATILE, tid); }
+            vc_sync();
+            if (t + 1 >= nt) break;
+            if (t + 2 < nt) fetch(fast, sa0, sb0, t + 2);
+            compute(1);
+            if (t + 2 < nt) { sa0.store(lds, tid); sb0.store(lds + ATILE, tid); }
+            vc_sync();
+        }
+    };
+    const bool interior = rowsA && rowsB && (kend - kbeg) % BK == 0;
+    if constexpr (gemm_is_x3<CT>::value) { if (interior) k_loop1(gemm_true()); else k_loop1(gemm_false()); }
+    else { if (interior) k_loop(gemm_true()); else k_loop(gemm_false()); }
 
-    if (dbg & 8) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = 1.f; return; }   // ablation: no epilogue
+#ifdef VCAD_AB
+    if (p.debug_skip & 8) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = 1.f; return; }   // ablation: no epilogue
+#endif
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (!p.partial && p.vecC && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {
         // Interior block: stage the fp32 tile through LDS (free after the last barrier) and run the epilogue on whole

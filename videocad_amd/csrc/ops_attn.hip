@@ -143,9 +143,10 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     }
     if (f32_mfma_ok(t, D, p, false)) {                            // one wave per 32-query block, everything on the f32 matrix cores
         const dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H * VC_CEIL_DIV(p.Tq, 32), 4));
-        if (D == 64) VC_LAUNCH((attn_f32_fwd_kernel<1, 2>), g, dim3(256), 0, s, p);
-        else if (D == 128) VC_LAUNCH((attn_f32_fwd_kernel<2, 2>), g, dim3(256), 0, s, p);
-        else VC_LAUNCH((attn_f32_fwd_kernel<4, 2>), g, dim3(256), 0, s, p);
+        const bool full = !p.causal && p.window >= p.Tk;
+#define VC_AF(NCH_) do { if (full) VC_LAUNCH((attn_f32_fwd_kernel<NCH_, 2, true>), g, dim3(256), 0, s, p); else VC_LAUNCH((attn_f32_fwd_kernel<NCH_, 2, false>), g, dim3(256), 0, s, p); } while (0)
+        if (D == 64) VC_AF(1); else if (D == 128) VC_AF(2); else VC_AF(4);
+#undef VC_AF
         return VC_OK;
     }
     return t == VC_BF16 ? attn_fwd_t<vc_bf16>(D, p, s) : attn_fwd_t<float>(D, p, s);
@@ -217,9 +218,12 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     }
     if (f32_mfma_ok(t, D, p, true)) {
         const dim3 gq((unsigned)VC_CEIL_DIV((long)p.B * p.H * VC_CEIL_DIV(p.Tq, 32), 4)), gk((unsigned)VC_CEIL_DIV((long)p.B * p.H * VC_CEIL_DIV(p.Tk, 32), 4));
-        if (D == 64) { VC_LAUNCH((attn_f32_bwd_q_kernel<1, 2>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<1, 2>), gk, dim3(256), 0, s, p); }
-        else if (D == 128) { VC_LAUNCH((attn_f32_bwd_q_kernel<2, 2>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<2, 2>), gk, dim3(256), 0, s, p); }
-        else { VC_LAUNCH((attn_f32_bwd_q_kernel<4, 2>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<4, 2>), gk, dim3(256), 0, s, p); }
+        const bool full = !p.causal && p.window >= p.Tk;
+#define VC_AB_(NCH_, F_) do { VC_LAUNCH((attn_f32_bwd_q_kernel<NCH_, 2, F_>), gq, dim3(256), 0, s, p); VC_LAUNCH((attn_f32_bwd_kv_kernel<NCH_, 2, F_>), gk, dim3(256), 0, s, p); } while (0)
+#define VC_AB(NCH_) do { if (full) VC_AB_(NCH_, true); else VC_AB_(NCH_, false); } while (0)
+        if (D == 64) VC_AB(1); else if (D == 128) VC_AB(2); else VC_AB(4);
+#undef VC_AB
+#undef VC_AB_
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);

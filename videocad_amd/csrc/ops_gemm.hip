@@ -53,36 +53,11 @@ bool vc_profile_on() { return false; }
 extern "C" int vcad_profile_end(double*, double*, double*, int*) { return 0; }
 #endif
 
-template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
-static int gemm_launch_wt(GemmCall c, int nsplit, vc_stream_t s) {
-    constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB, WT>();
-    constexpr int GEMM_BM = 64 * WT, GEMM_BN = 64 * WT;
-    if (c.p.k_per_split < 0) c.p.k_per_split = -c.p.k_per_split;
-#ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
-    }
-#endif
-    ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
-                 (double)c.p.M * c.p.K * sizeof(SA) + (double)c.p.N * c.p.K * sizeof(SB) + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_REG);
-    dim3 grid(VC_CEIL_DIV(c.p.N, GEMM_BN), VC_CEIL_DIV(c.p.M, GEMM_BM), nsplit);
-    VC_LAUNCH((gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>), grid, dim3(GEMM_THREADS), lds, s, c.p);
-    if (nsplit > 1) {
-        long total = (long)c.p.M * c.p.N;
-        if (c.p.vecC && c.p.N % 4 == 0) VC_LAUNCH((gemm_splitk_reduce4_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total / 4, 256)), dim3(256), 0, s, c.p, nsplit);
-        else VC_LAUNCH((gemm_splitk_reduce_kernel<TO>), dim3((unsigned)VC_CEIL_DIV(total, 256)), dim3(256), 0, s, c.p, nsplit);
-    }
-    return VC_OK;
-}
-
-template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB>
-static int gemm_launch(GemmCall c, int nsplit, vc_stream_t s) {
-    return c.p.k_per_split < 0 ? gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 1>(c, nsplit, s) : gemm_launch_wt<CT, SA, SB, TO, TRA, TRB, 2>(c, nsplit, s);
-}
+// the kernel instantiations live in their own translation units (one per family; gemm_launch.h)
+int vc_gemm_launch_f32(GemmCall c, int nsplit, int lay, vc_stream_t s);
+int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s);
+int vc_gemm_launch_bf16_wgrad(GemmCall c, int nsplit, vc_stream_t s);              // tra = trb = 1, fp32 output, either source fp32 or bf16
+int vc_gemm_launch_bf16(GemmCall c, int nsplit, int lay, vc_stream_t s);            // lay 0 / 1, B bf16
 
 static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal (tests run small problems through it)
 extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
@@ -206,26 +181,13 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     p.partial = nsplit > 1 ? scratch : nullptr;
     c.p.k_per_split = small ? -kps : kps;          // sign carries the tile-size choice to gemm_launch (restored there)
 
-#define G(CT_, SA_, SB_, TO_, TRA_, TRB_) return gemm_launch<CT_, SA_, SB_, TO_, TRA_, TRB_>(c, nsplit, s)
-    if (c.ct == VC_F32) {
-        switch (lay) { case 0: G(float, float, float, float, false, false); case 1: G(float, float, float, float, false, true);
-                       case 2: G(float, float, float, float, true, false); case 3: G(float, float, float, float, true, true); }
-    } else if (c.ct == VC_X3) {
-        switch (lay) { case 0: G(vc_x3, float, float, float, false, false); case 1: G(vc_x3, float, float, float, false, true);
-                       case 2: G(vc_x3, float, float, float, true, false); case 3: G(vc_x3, float, float, float, true, true); }
-    } else if (lay == 3) {            // wgrad: fp32 output always; either operand may be an fp32 tensor (converted while staging)
+    if (c.ct == VC_F32) return vc_gemm_launch_f32(c, nsplit, lay, s);
+    if (c.ct == VC_X3) return vc_gemm_launch_x3(c, nsplit, lay, s);
+    if (lay == 3) {            // wgrad: fp32 output always; either operand may be an fp32 tensor (converted while staging)
         if (c.to != VC_F32) { vc_set_error("vc_gemm: wgrad (tra=trb=1) writes fp32"); return VC_ERR_UNSUPPORTED; }
-        switch ((c.sa == VC_F32) * 2 + (c.sb == VC_F32)) {
-            case 0: G(vc_bf16, vc_bf16, vc_bf16, float, true, true); case 1: G(vc_bf16, vc_bf16, float, float, true, true);
-            case 2: G(vc_bf16, float, vc_bf16, float, true, true);   case 3: G(vc_bf16, float, float, float, true, true); }
-    } else if (c.sb == VC_BF16 && lay != 2) {
-        const int key = (c.sa == VC_F32) * 2 + (c.to == VC_F32);
-        if (lay == 0) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, false, false); case 1: G(vc_bf16, vc_bf16, vc_bf16, float, false, false);
-                                     case 2: G(vc_bf16, float, vc_bf16, vc_bf16, false, false);   case 3: G(vc_bf16, float, vc_bf16, float, false, false); }
-        if (lay == 1) switch (key) { case 0: G(vc_bf16, vc_bf16, vc_bf16, vc_bf16, false, true);  case 1: G(vc_bf16, vc_bf16, vc_bf16, float, false, true);
-                                     case 2: G(vc_bf16, float, vc_bf16, vc_bf16, false, true);    case 3: G(vc_bf16, float, vc_bf16, float, false, true); }
+        return vc_gemm_launch_bf16_wgrad(c, nsplit, s);
     }
-#undef G
+    if (c.sb == VC_BF16 && lay != 2) return vc_gemm_launch_bf16(c, nsplit, lay, s);
     vc_set_error("vc_gemm: unsupported combination ct=%d sa=%d sb=%d to=%d tra=%d trb=%d", c.ct, c.sa, c.sb, c.to, c.tra, c.trb);
     return VC_ERR_UNSUPPORTED;
 }

@@ -1,0 +1,11 @@
+// ops_gemm_x3.hip — bf16x3 (VCAD_BF16X3: fp32 tensors, hi/lo-split bf16 MFMAs) instantiations of the register-staged GEMM
+#include "gemm_launch.h"
+
+int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s) {
+    switch (lay) {
+        case 0: return gemm_launch<vc_x3, float, float, float, false, false>(c, nsplit, s);
+        case 1: return gemm_launch<vc_x3, float, float, float, false, true>(c, nsplit, s);
+        case 2: return gemm_launch<vc_x3, float, float, float, true, false>(c, nsplit, s);
+        default: return gemm_launch<vc_x3, float, float, float, true, true>(c, nsplit, s);
+    }
+}

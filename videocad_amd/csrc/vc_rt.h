@@ -69,6 +69,8 @@ VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
 }
 VC_DEV float vc_expf_fast(float x) { return __expf(x); }
+// a product that is rounded on its own: hipcc contracts `a * b - c` (and __fmul_rn, which is a plain multiply in the IR) into one FMA
+VC_DEV float vc_mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 VC_DEV int vc_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }     // x is known to be wave-uniform: keep it in an SGPR
 VC_DEV uint64_t vc_uniform64(uint64_t x) {     // 64-bit value known to be wave-uniform: both halves into SGPRs
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
@@ -208,6 +210,7 @@ VC_DEV vc_f32x16 vc_mfma_mx8_32x32x64(vc_i32x8 a, vc_i32x8 b, vc_f32x16 c, int s
 VC_DEV vc_s16x4 vc_ds_read_tr16(const void* p) { vc_s16x4 r; vcemu::ds_read_tr16(p, r.v); return r; }
 VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) { vcemu::dma16(gsrc, lds_piece); }
 VC_DEV float vc_expf_fast(float x) { return expf(x); }
+VC_DEV float vc_mul_rn(float a, float b) { volatile float r = a * b; return r; }
 VC_DEV void vc_sched_fence() {}
 template <int P> VC_DEV void vc_setprio() {}
 VC_DEV uint32_t vc_hload_b32(const void* sbase, uint32_t voff) { uint32_t v; memcpy(&v, (const char*)sbase + voff, 4); return v; }
