@@ -41,11 +41,12 @@ def main():
     ap.add_argument("--no-side", type=int, default=0, help="A/B: 1 = no library side stream (CAD ViT and deferred wgrads serialised on the caller's stream)")
     ap.add_argument("--gemm-wide", type=int, default=-1, help="A/B switch: 0 = 256x128 tile only, -1 = automatic (default)")
     ap.add_argument("--uint8-frames", action="store_true", help="feed uint8 grayscale pixels (normalised inside the patchify kernel) instead of fp32 frames")
+    ap.add_argument("--no-modes", action="store_true", help="skip the short bf16x3 / f32 / fp8 legs reported beside the headline (each with its parity block)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (pinned host -> HBM staged) measurement reported beside the headline")
     ap.add_argument("--profile-only", action="store_true", help="rocprofv3 runs: only the headline workload's train steps (no seq-186 / PCIe / parity / CPU-baseline legs)")
     args = ap.parse_args()
     if args.profile_only:
-        args.no_cpu_baseline = args.no_seq186 = args.no_pcie = args.no_parity = True
+        args.no_cpu_baseline = args.no_seq186 = args.no_pcie = args.no_parity = args.no_modes = True
 
     from videocad_amd.bench_impl import launch
     launch(args)

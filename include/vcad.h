@@ -95,6 +95,13 @@ int vcad_forward(vcad_engine* e, const float* frames, int64_t frame_bstride, con
 int vcad_forward_u8(vcad_engine* e, const uint8_t* frames, int64_t frame_bstride, const float* actions_norm, const uint8_t* cad,
                     int B, int T, float* cmds_out, float* params_out, void* stream);
 
+/* The same with the dataset's STORED frames: uint8 RGB, interleaved [B][S][H][W][3] (pkl `frames uint8 [N,224,224,3]`, reference
+ * data_loader/sequence_retriver.py:25-33); PIL's `convert('L')` integer luma (reference data_loader.py:441-447, torchvision Grayscale at main.py:105),
+ * ToTensor and Normalize(0.5, 0.5) all happen inside the patchify kernels — bit-identical to the fp32 path.  cad: uint8 GRAY [B,1,S,S] as in
+ * vcad_forward_u8 (one image per clip; cv2's BGR2GRAY stays on the host).  frame_bstride in PIXELS (multiple of 4), pointers 4-byte aligned. */
+int vcad_forward_rgb8(vcad_engine* e, const uint8_t* frames_rgb, int64_t frame_bstride, const float* actions_norm, const uint8_t* cad,
+                      int B, int T, float* cmds_out, float* params_out, void* stream);
+
 /* ---- MultiClassesTrainer.compute_loss (reference trainer.py:935-1063, flexible_cross_entropy :853-917)
  * targets: fp32 [B*T,7] = raw batch['actions'][:, 1:]
  * label_weights: HOST pointer, 5 floats = class_weights.json["Label"] as the caller read it from ./class_weights.json

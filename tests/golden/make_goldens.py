@@ -88,7 +88,37 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def eval_cases(model, mk, weights):
+    """f3 (r03): `evaluate()` and `find_first_mistake()` of the IMPORTED reference trainer (trainer.py:713-750, 1131-1260) on a two-batch
+    loader (one full-length batch, one ragged) — the accumulated metric dict and the per-sequence mistake bookkeeping become fixtures."""
+    model.load_state_dict({k: torch.tensor(v) for k, v in weights.items()}, strict=False)
+    specs = [(2, 8, 1, None), (2, 8, 2, [9, 6])]
+    loader = [tbatch(synth.make_batch(B, T, seed, lengths)) for B, T, seed, lengths in specs]
+    tr = mk(True)
+    tr.train_loader = tr.val_loader = tr.test_loader = loader
+    model.eval()
+    metrics = tr.evaluate(model, mode="test")
+    ffm = tr.find_first_mistake(model, mode="test", tol=3)
+    # f4: the order of `model.parameters()` in the reference (what torch.optim.Adam indexes its state by, trainer.py:251-253) — data for
+    # the name-keyed optimiser-state conversion test
+    json.dump({"named_parameters": [n for n, _ in model.named_parameters()]}, open(os.path.join(HERE, "reference_param_order.json"), "w"), indent=0)
+    out = {"batches": [{"B": B, "T": T, "seed": seed, "lengths": lengths} for B, T, seed, lengths in specs],
+           "evaluate": metrics, "find_first_mistake": ffm}
+    json.dump(out, open(os.path.join(HERE, "eval_cases.json"), "w"), indent=1)
+    print("eval cases: overall", metrics.get("correct_predictions"), "/", metrics.get("total_predictions"))
+    return {"sequences": len(ffm[0]["Sequence Lengths"]), "total_predictions": metrics["total_predictions"]}
+
+
 def main():
+    if "--only-eval" in sys.argv:                       # regenerate tests/golden/eval_cases.json alone (the full run writes the same file)
+        scratch = tempfile.mkdtemp(prefix="vcad_golden_")
+        shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
+        os.chdir(scratch)
+        weights = {k: synth.make_param(k, s) for k, s in O.param_shapes().items()}
+        model, mk, _ = build_reference("cad_past_10_actions_and_states_timestep_embedding", weights, scratch)
+        print(eval_cases(model, mk, weights))
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
     scratch = tempfile.mkdtemp(prefix="vcad_golden_")
     shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
     os.chdir(scratch)
@@ -284,6 +314,9 @@ def main():
                             metrics_json=np.array(json.dumps(metrics)))
         meta["cases"][case] = {"config": cfg_name, "B": 2, "T": 8, "seed": seed, "oracle_vs_reference": dev,
                                "dead_parameters": sorted(set(wts) - set(live))}
+
+    # ------------------------------------------------------------------ evaluation bookkeeping of the reference trainer
+    meta["cases"]["eval_cases"] = eval_cases(model, mk, weights)
 
     # ------------------------------------------------------------------ loss-only cases on synthetic logits
     tr = mk(True); trn = mk(False)

@@ -138,16 +138,17 @@ def _ddp_worker(rank, world, port, tmp, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_data_parallel_step_matches_mean_of_gradients(tmp_path):
-    """world_size=2 over gloo on the CPU (kernels under the emulator): rank-local backward, bucketed all-reduce(SUM) of
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_data_parallel_step_matches_mean_of_gradients(tmp_path, world):
+    """world_size = 2 and 4 over gloo on the CPU (kernels under the emulator): rank-local backward, bucketed all-reduce(SUM) of
     the flat gradient buffer, 1/world folded into Adam  ==  clip+Adam on the mean of the two ranks' oracle gradients
     (what DDP does at reference experiment.py:104-109)."""
     import torch.multiprocessing as mp
     U.load_emu()                                    # build once before forking
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
     [p.start() for p in procs]
     got = q.get(timeout=900)
     [p.join(timeout=300) for p in procs]
@@ -157,11 +158,11 @@ def test_two_rank_gloo_data_parallel_step_matches_mean_of_gradients(tmp_path):
     weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
     ot = O.OracleTrainer(weights, ocfg)
     gsum = None
-    for r in range(2):
+    for r in range(world):
         ot.loss_and_grads(synth.make_batch(1, 2, seed=10 + r))
         g = {k: p.grad.clone() for k, p in ot.P.items()}
         gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
-    gavg = {k: v / 2 for k, v in gsum.items()}
+    gavg = {k: v / world for k, v in gsum.items()}
     ot.apply_grads(gavg)
     # Adam's first step is lr * g / (|g| + eps): elements whose gradient is numerical noise around zero (e.g. the key
     # bias of every attention: softmax is shift-invariant, so its true gradient is 0) are ill-conditioned by

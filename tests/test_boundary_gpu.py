@@ -139,6 +139,57 @@ def test_uint8_input_path_is_bit_identical_and_staged_from_pinned_memory(tmp_pat
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])
 
 
+def test_evaluate_and_find_first_mistake_match_the_reference_fixture(golden_dir, tmp_path):
+    """f3 on the GPU: `trainer.evaluate` (fused loss + on-device counters, one D2H) and `trainer.find_first_mistake` on a two-batch loader
+    (one ragged) against what the IMPORTED reference's trainer produced for the same weights and batches (tests/golden/eval_cases.json:
+    reference trainer.py:713-750, 1131-1260) — every accumulated count / percentage and the complete mistake bookkeeping; the loss against
+    the oracle's (the reference's evaluate does not return one)."""
+    gold = json.load(open(os.path.join(golden_dir, "eval_cases.json")))
+    model, tr = make("f32", tmp_path)
+    loader = [synth.make_batch_torch(b["B"], b["T"], b["seed"], "cpu", b["lengths"]) for b in gold["batches"]]
+    tr.train_loader = tr.val_loader = tr.test_loader = loader
+    ev = tr.evaluate(model, mode="test")
+    for k, v in gold["evaluate"].items():
+        assert k in ev, k
+        assert (abs(ev[k] - v) < 1e-9 * max(1.0, abs(v))) if isinstance(v, float) else ev[k] == v, (k, ev[k], v)
+    ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in O.param_shapes().items()})
+    losses = []
+    for b in gold["batches"]:
+        with torch.no_grad():
+            c, p, tgt = ot.forward(synth.make_batch(b["B"], b["T"], b["seed"], b["lengths"]))
+            losses.append(float(O.compute_loss(c, p, tgt)[0]))
+    assert abs(ev["loss"] - sum(losses) / len(losses)) < 1e-4 * abs(sum(losses) / len(losses))
+    ffm = tr.find_first_mistake(model, mode="test", tol=3)
+    assert json.loads(json.dumps(ffm)) == gold["find_first_mistake"]
+    assert os.path.exists(os.path.join("logs", "t", "test.json"))                  # evaluate dumps where the reference does (:746-749)
+
+
+def test_rgb8_and_uint8_batches_match_the_oracle_on_the_host_converted_batch(tmp_path):
+    """f2, oracle-direct: the SAME pixels three ways — stored uint8 RGB [B,S,H,W,3] (vcad_forward_rgb8: PIL luma + ToTensor +
+    Normalize in the patchify kernel), host-grayed uint8 (vcad_forward_u8), host-normalised fp32 (the reference's contract) — give bit-identical
+    logits, and those match the ORACLE evaluated on the reference's host pipeline output."""
+    from videocad_amd import data as D
+    model, tr = make("f32", tmp_path)
+    eng = model._engine
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, (2, 6, 224, 224, 3), dtype=np.uint8)
+    cad8 = torch.from_numpy(D.cv2_bgr2gray_u8(rng.integers(0, 256, (2, 224, 224, 3), dtype=np.uint8))).unsqueeze(1)
+    act = torch.from_numpy(synth.make_actions(2, 6, 17))
+    an = O.normalize_actions(act[:, :-1]).to(DEV)
+    host = D.frames_from_rgb(rgb.reshape(-1, 224, 224, 3), as_uint8=False).reshape(2, 6, 1, 224, 224)          # PIL convert('L') -> ToTensor -> Normalize
+    gray8 = D.frames_from_rgb(rgb.reshape(-1, 224, 224, 3), as_uint8=True).reshape(2, 6, 1, 224, 224)
+    outs = []
+    for fr, cad in ((torch.from_numpy(rgb), cad8), (gray8, cad8), (host, D.normalize_u8(cad8))):
+        c, p = eng.forward(fr.to(DEV)[:, :-1], an, cad.to(DEV))
+        outs.append((c.clone(), p.clone()))
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1]) and torch.equal(outs[1][1], outs[2][1])
+    P = {k: torch.from_numpy(synth.make_param(k, s)) for k, s in O.param_shapes().items()}
+    with torch.no_grad():
+        oc, op = O.model_forward(P, host[:, :-1], an.cpu(), D.normalize_u8(cad8))[:2]
+    assert U.relerr(outs[0][0], oc) < 1e-4 and U.relerr(outs[0][1], op) < 1e-4
+    assert bool((outs[0][1].argmax(-1).cpu() == op.argmax(-1)).all())
+
+
 def test_checkpoint_roundtrip_through_the_factory(tmp_path):
     """f4: save in the reference's format, reload through ModelFactory.create_model(state_dict=...) with DDP prefixes, resume."""
     model, tr = make("bf16", tmp_path)

@@ -87,3 +87,73 @@ def test_stager_passthrough_on_cpu():
     assert len(out) == 3 and out[0]["frames"].dtype == torch.uint8 and out[0]["actions"].dtype == torch.float32
     assert out[2]["timesteps"].dtype == torch.long and torch.equal(out[1]["frames"], batches[1]["frames"])
     assert "multiview_images" not in out[0]
+
+
+# ------------------------------------------------------------------------------------------------ on-disk clips (f2 / f4)
+def _write_dataset(root, n_clips=3, S=224):
+    """a synthetic dataset directory in the reference's layout: <root>/<id[:4]>/<id>_data.pkl + <id>_frame.png"""
+    import os, pickle
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    ids, raw = [], {}
+    for c in range(n_clips):
+        cid = f"{1000 + c:04d}{c:04d}"
+        n = 3 + c
+        frames = rng.integers(0, 256, (n, S, S, 3), dtype=np.uint8)
+        actions = rng.integers(0, 999, (n, 7)).astype(np.float64); actions[:, 3] = 5
+        rec = D.finalize_clip(frames, actions, list(range(n)))
+        os.makedirs(os.path.join(root, cid[:4]), exist_ok=True)
+        with open(os.path.join(root, cid[:4], cid + "_data.pkl"), "wb") as f:
+            pickle.dump(rec, f)
+        render = rng.integers(0, 256, (S, S, 3), dtype=np.uint8)
+        Image.fromarray(render).save(os.path.join(root, cid[:4], cid + "_frame.png"))
+        ids.append(cid); raw[cid] = (rec, render)
+    return ids, raw
+
+
+def _reference_getitem(rec, render_rgb):
+    """reference data_loader.py:434-508, literally, with PIL doing what torchvision's transforms do (Resize is the identity at 224):
+    Image.fromarray(frame) -> Grayscale(1) -> ToTensor -> Normalize([0.5], [0.5]); CAD: BGR2GRAY -> /255 -> Normalize"""
+    from PIL import Image
+    fr = []
+    for frame in rec["frames"]:
+        g = np.array(Image.fromarray(frame).convert("L"))                        # torchvision Grayscale(1) = PIL convert('L')
+        fr.append(((torch.from_numpy(g).float().div(255.0) - 0.5) / 0.5).unsqueeze(0))
+    bgr = render_rgb[..., ::-1].astype(np.uint32)                                # what cv2.imread returns
+    gray = ((bgr[..., 0] * 1868 + bgr[..., 1] * 9617 + bgr[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    cad = (torch.from_numpy(gray.astype(np.float32) / 255.0).unsqueeze(0) - 0.5) / 0.5
+    return {"frames": torch.stack(fr), "actions": torch.from_numpy(rec["actions"].astype(np.float32)), "cad_image": cad,
+            "timesteps": torch.arange(len(fr))}
+
+
+def test_finalize_clip_is_the_reference_record():
+    """reference generate_dataset.py:180-199: duplicated first frame + zero action row, cut after the END_ACTION row"""
+    fr = np.arange(4 * 2 * 2 * 3, dtype=np.uint8).reshape(4, 2, 2, 3)
+    ac = np.tile(np.arange(7, dtype=np.float64), (4, 1)); ac[:, 3] = [1, 2, D.END_ACTION, 4]
+    rec = D.finalize_clip(fr, ac, [10, 11, 12, 13])
+    assert rec["frames"].shape[0] == rec["actions"].shape[0] == 4                 # 1 (prepended) + 3 (cut after the end action)
+    assert np.array_equal(rec["frames"][0], fr[0]) and np.array_equal(rec["frames"][1], fr[0]) and not rec["actions"][0].any()
+    assert rec["actions"][-1, 3] == D.END_ACTION and list(rec["timesteps"]) == [10, 10, 11, 12]
+    full = D.finalize_clip(fr, np.zeros((4, 7)), [0, 1, 2, 3])
+    assert full["frames"].shape[0] == 5
+
+
+def test_pkl_dataset_items_match_the_reference_getitem(tmp_path):
+    pytest.importorskip("PIL.Image")
+    ids, raw = _write_dataset(str(tmp_path))
+    ds = {m: D.PklClipDataset(str(tmp_path), mode=m) for m in ("f32", "gray8", "rgb8")}
+    assert len(ds["f32"]) == 3 and ds["f32"].ids == sorted(ids)
+    for i, cid in enumerate(sorted(ids)):
+        ref = _reference_getitem(*raw[cid])
+        it = ds["f32"][i]
+        for k in ("frames", "actions", "cad_image", "timesteps"):
+            assert it[k].dtype == ref[k].dtype and torch.equal(it[k], ref[k]), (cid, k)
+        g8 = ds["gray8"][i]
+        assert g8["frames"].dtype == torch.uint8 and torch.equal(D.normalize_u8(g8["frames"]), ref["frames"]) and torch.equal(D.normalize_u8(g8["cad_image"]), ref["cad_image"])
+        r8 = ds["rgb8"][i]
+        assert r8["frames"].dtype == torch.uint8 and r8["frames"].shape[1:] == (224, 224, 3) and np.array_equal(r8["frames"].numpy(), raw[cid][0]["frames"])
+    # through the collate: ragged clips padded with pixel 0 (= -1.0 after the in-kernel normalisation) in both uint8 layouts
+    b = D.collate_with_padding([ds["rgb8"][0], ds["rgb8"][2]], pin=False)
+    assert b["frames"].shape == (2, 6, 224, 224, 3) and int(b["frames"][0, 4:].max()) == 0 and b["cad_image"].shape == (2, 1, 224, 224)
+    with pytest.raises(IndexError):
+        ds["f32"][3]

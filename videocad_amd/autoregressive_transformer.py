@@ -59,15 +59,14 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, model, frames, actions, cad, *params):
         cmds, pars = model._engine.forward(frames, actions, cad)
         ctx.model = model
-        model._fwd_id += 1
-        ctx.fwd_id = model._fwd_id
-        return cmds, pars
+        ctx.fwd_id = model._engine.fwd_serial       # ANY later engine forward (no_grad / eval forwards, trainer.train_step, evaluate, cached
+        return cmds, pars                           # inference) bumps it: a backward through this node then raises instead of using their activations
 
     @staticmethod
     def backward(ctx, dcmds, dpars):
         model = ctx.model
         eng = model._engine
-        if ctx.fwd_id != model._fwd_id:
+        if ctx.fwd_id != eng.fwd_serial:
             raise RuntimeError("videocad_amd: backward through a forward that is no longer the engine's current one (the engine keeps the "
                                "activations of the most recent forward only)")
         eng.backward(dcmds.contiguous(), dpars.reshape(dpars.shape[0], dpars.shape[1], -1).contiguous())
@@ -118,7 +117,6 @@ class AutoRegressiveTransformer(nn.Module):
         self._shadow_fresh = False
         self._drop_step = 0
         self._drop_rank = 0                                                  # data-parallel rank (set by the trainer): every rank draws its own masks
-        self._fwd_id = 0
         self.reset_parameters()
         self.action_mask = torch.tensor([[1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 0, 0, 1, 0],
                                          [0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0]]).float()   # reference :83-89 (plain attribute)

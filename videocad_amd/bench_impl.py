@@ -156,15 +156,22 @@ def logit_parity(model, device):
         return {"error": repr(ex)}
 
 
-def _timed(tr, bd, steps, world, device):
+def _timed(tr, bd, steps, world, device, per_step=None):
+    """K steps between barrier + synchronize on both sides (wall clock = the reported time); `per_step` (a list) additionally receives
+    the K step durations in ms from events recorded on the compute stream inside the same region (no extra synchronisation)."""
     import torch.distributed as dist
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        if evs:
+            evs[i].record()
         loss, met = tr.train_step(bd)
+    if evs:
+        evs[steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,7 +181,31 @@ def _timed(tr, bd, steps, world, device):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if evs:
+        per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     return elapsed, loss
+
+
+def short_leg(dtype, fp8, B, T, steps, warmup, device, rank, world, seed, dropout, want_parity=True):
+    """One short measurement of another compute mode / shape with its own trainer (same model, same hash-init weights): reported BESIDE the
+    headline line, never as `value`."""
+    model, tr = build_trainer(dtype, dropout, device, rank)
+    if fp8:
+        model._engine.set_fp8(True)
+    parity = logit_parity(model, device) if (want_parity and rank == 0) else None
+    bd = synthetic_batch(B, T, seed + rank, device)
+    for _ in range(warmup):
+        tr.train_step(bd)
+    per = []
+    e, loss = _timed(tr, bd, steps, world, device, per)
+    out = {"workload": f"seq_len={T} batch={B} per GPU", "dtype": dtype + ("+fp8 forward GEMMs (ViT)" if fp8 else ""),
+           "value": round(world * B * T / (e / steps), 1), "unit": "frames/s", "ms_per_step": round(e / steps * 1e3, 3),
+           "ms_per_step_median": round(float(np.median(per)), 3), "steps": steps, "warmup": warmup, "loss": float(loss.item())}
+    if parity is not None:
+        out["parity"] = parity
+    del tr, model, bd
+    torch.cuda.empty_cache()
+    return out
 
 
 def run(args):
@@ -209,7 +240,8 @@ def run(args):
 
     for _ in range(args.warmup):
         tr.train_step(bd)
-    elapsed, loss = _timed(tr, bd, args.steps, world, device)
+    per_step_ms = []
+    elapsed, loss = _timed(tr, bd, args.steps, world, device, per_step_ms)
     ms = elapsed / args.steps * 1e3
     fps = world * B * T / (elapsed / args.steps)
 
@@ -269,18 +301,40 @@ def run(args):
                                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None} for k, v in fam.items()}},
             "step_level_frac": round(fps / world * train_gf_per_frame(T) * 1e9 / (peak * 1e12), 4)}
 
-    # ---- BASELINE configs[3]'s per-GPU shape (seq_len 186 — the maximum horizon — at 16 clips per GPU), a few steps, reported beside
-    # the headline configuration (north_star asks for both horizons); same trainer, same weights, workspace re-planned
-    extra = None
+    # ---- BASELINE configs[3]'s per-GPU shape (seq_len 186 — the maximum horizon — at 16 clips per GPU) and configs[2] (seq_len 128, batch 64 on
+    # one GPU), a few steps each, reported beside the headline configuration (north_star asks for both horizons; BASELINE.md §3 lists
+    # configs[2]); same trainer, same weights, workspace re-planned
+    extra, extra_c3 = None, None
     if (B, T) == (32, 64) and not getattr(args, "no_seq186", False):
-        B2, T2, K2 = 16, 186, 5
-        bd2 = synthetic_batch(B2, T2, 3000 + rank, device, uint8=args.uint8_frames)
-        for _ in range(2):
-            tr.train_step(bd2)
-        e2, _ = _timed(tr, bd2, K2, world, device)
-        extra = {"workload": f"seq_len={T2} batch={B2} per GPU (BASELINE configs[3] per-GPU shape)", "value": round(world * B2 * T2 / (e2 / K2), 1),
-                 "unit": "frames/s", "ms_per_step": round(e2 / K2 * 1e3, 3), "steps": K2}
-        del bd2
+        for (B2, T2, K2, W2, name) in ((16, 186, 10, 3, "c4"), (64, 128, 4, 2, "c3")):
+            if name == "c3" and world > 1:
+                continue
+            bd2 = synthetic_batch(B2, T2, 3000 + T2 + rank, device, uint8=args.uint8_frames)
+            for _ in range(W2):
+                tr.train_step(bd2)
+            per2 = []
+            e2, _ = _timed(tr, bd2, K2, world, device, per2)
+            leg = {"workload": f"seq_len={T2} batch={B2} per GPU (BASELINE configs[{3 if name == 'c4' else 2}]" + (" per-GPU shape)" if name == "c4" else ")"),
+                   "value": round(world * B2 * T2 / (e2 / K2), 1), "unit": "frames/s", "ms_per_step": round(e2 / K2 * 1e3, 3),
+                   "ms_per_step_median": round(float(np.median(per2)), 3), "steps": K2, "warmup": W2,
+                   "step_level_frac": round(B2 * T2 / (e2 / K2) * train_gf_per_frame(T2) * 1e9 / (peak * 1e12), 4)}
+            if name == "c4":
+                extra = leg
+            else:
+                extra_c3 = leg
+            del bd2
+        tr.train_step(bd)                       # back to the headline plan (keeps later legs on the C2 workspace)
+
+    # ---- the other compute modes at the headline shape, short legs with their own parity blocks: bf16x3 = the IN-TOLERANCE mode (logits within
+    # 1e-3 of the fp32 reference, arg-max exact), f32 = exact-fp32 MFMA, bf16+fp8 = MXFP8 forward GEMMs in the ViT
+    modes = None
+    if rank == 0 and world == 1 and (B, T) == (32, 64) and args.dtype == "bf16" and not getattr(args, "no_modes", False):
+        modes = {}
+        for key, dt, f8, K3 in (("bf16x3", "bf16x3", False, 4), ("f32", "f32", False, 2), ("bf16_fp8_forward", "bf16", True, 4)):
+            try:
+                modes[key] = short_leg(dt, f8, B, T, K3, 1, device, rank, world, 2000, args.dropout)
+            except Exception as ex:               # a reporting leg never breaks the headline measurement
+                modes[key] = {"error": repr(ex)}
 
     # ---- input path: the same step fed from pinned host memory through the double-buffered stager (PCIe-inclusive; never `value`)
     pcie = None
@@ -293,7 +347,7 @@ def run(args):
     if rank == 0:
         out = {"metric": "training frames/sec (224x224 grayscale frames, canonical AutoRegressiveTransformer)",
                "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": round(ms, 3), "ms_per_step_median": round(float(np.median(per_step_ms)), 3) if per_step_ms else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype + ("+fp8 forward GEMMs (ViT)" if getattr(args, "fp8", False) else ""), "data": "synthetic (" + ("uint8 pixels" if args.uint8_frames else "U[-1,1) fp32 frames") + " in HBM, hash-init weights)",
                "config": {"workload": f"autoregressive_transformer bf16 seq_len={T} batch={B} per GPU, {world}xMI355X (BASELINE configs[1])"
                           if (T, B) == (64, 32) else f"canonical model seq_len={T} batch={B} per GPU",
@@ -304,6 +358,10 @@ def run(args):
             out["comm"] = comm
         if extra:
             out["seq_len_186"] = extra
+        if extra_c3:
+            out["seq_len_128_batch_64"] = extra_c3
+        if modes:
+            out["modes"] = modes
         if pcie:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:

@@ -115,7 +115,8 @@ long add_param(vcad_engine* e, const std::string& name, std::initializer_list<lo
     int i = 0; for (long s : shape) { p.shape[i++] = s; p.numel *= s; }
     for (; i < 4; ++i) p.shape[i] = 0;
     p.off = e->ptotal;
-    e->ptotal += (p.numel + 63) / 64 * 64;            // 256-byte alignment (fp32), 128-byte for the bf16 shadow
+    e->ptotal += (p.numel + 127) / 128 * 128;         // 512-byte alignment (fp32), 256-byte for the bf16 shadow; a multiple of 128 elements keeps
+                                                      // the fp8 copies' E8M0 scale rows (one byte per 32 elements) 4-byte aligned (gemm_mx8.h)
     e->pindex[name] = (int)e->plist.size();
     e->plist.push_back(p);
     return p.off;
@@ -417,7 +418,7 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
     {   // patchify + LN(1024)
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = img; p.gamma = cx.Pf(w.ln1w); p.beta = cx.Pf(w.ln1b); p.yt = a.pn; p.ldyt = pd; p.stats = a.pstat; p.rows = Rp; p.eps = 1e-5f;
-        p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.ldx = img_bstride; p.u8 = e->in_u8;
+        p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.ldx = img_bstride; p.u8 = v == 1 && e->in_u8 ? 1 : e->in_u8;     // (the CAD image is always one gray plane)
         CK(vc_ln_fwd(VC_F32, e->dt, pd, 1, p, cx.s));
     }
     { Epi ep; ep.bias = cx.Pf(w.peb); CK(cx.lin_fwd(cx.AT(a.pn, pd), cx.W(w.pew, pd), cx.A32(a.pe, D), (int)Rp, D, pd, ep)); }
@@ -565,7 +566,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         {   // LN(1024) parameter gradients (input frames need no gradient)
             LnBwdParams p; memset(&p, 0, sizeof(p));
             p.dy = cx.L().t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
-            p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.u8 = e->in_u8;
+            p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.u8 = v == 1 && e->in_u8 ? 1 : e->in_u8;
             CK(vc_ln_bwd(e->dt, VC_F32, e->dt, pd, 1, p, cx.L().scr_lnpart, cx.Gf(w.ln1w), cx.Gf(w.ln1b), cx.L().scr_colsum, cx.s));
         }
     }
@@ -898,6 +899,11 @@ int vcad_forward_u8(vcad_engine* e, const uint8_t* frames, int64_t fbstride, con
                     float* cmds_out, float* pars_out, void* stream) {
     if (((uintptr_t)frames | (uintptr_t)cad | (uintptr_t)fbstride) & 3) { vc_set_error("vcad_forward_u8: frames / cad / batch stride must be 4-byte aligned"); return VC_ERR_ARG; }
     return forward_any(e, frames, fbstride, actions, cad, 1, B, T, cmds_out, pars_out, stream);
+}
+int vcad_forward_rgb8(vcad_engine* e, const uint8_t* frames_rgb, int64_t fbstride, const float* actions, const uint8_t* cad, int B, int T,
+                      float* cmds_out, float* pars_out, void* stream) {
+    if (((uintptr_t)frames_rgb | (uintptr_t)cad) & 3 || (fbstride & 3)) { vc_set_error("vcad_forward_rgb8: frames / cad must be 4-byte aligned, the batch stride a multiple of 4 pixels"); return VC_ERR_ARG; }
+    return forward_any(e, frames_rgb, fbstride, actions, cad, 2, B, T, cmds_out, pars_out, stream);
 }
 static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, const float* actions, const void* cad, int u8, int B, int T,
                        float* cmds_out, float* pars_out, void* stream) {

@@ -9,12 +9,12 @@ static int gemm_launch_wt(GemmCall c, int nsplit, vc_stream_t s) {
     constexpr int GEMM_BM = 64 * WT, GEMM_BN = 64 * WT;
     if (c.p.k_per_split < 0) c.p.k_per_split = -c.p.k_per_split;
 #ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;
+    if (!(attr_set & vc_device_bit())) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_kernel<CT, SA, SB, TO, TRA, TRB, WT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
+        attr_set |= vc_device_bit();
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,

@@ -58,6 +58,19 @@ VC_DEV void quad_load_u8norm(const uint8_t* p, float* v) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = ((float)((q >> (8 * k)) & 0xFFu) / 255.0f - 0.5f) / 0.5f;
 }
+// u8 = 2: the frames are the STORED pixels of the dataset — uint8 RGB, interleaved [H][W][3] (pkl `frames uint8 [N,224,224,3]`, reference
+// data_loader/sequence_retriver.py:25-33) — and PIL's `Image.convert('L')` (torchvision Grayscale, reference data_loader.py:441-447; the integer
+// ITU-R 601-2 form L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16, bit-exact against PIL: tests/test_data_cpu.py) happens here too, followed by
+// the same normalisation — the host does no per-pixel work at all.  4 pixels = 12 bytes = three aligned dwords.
+VC_DEV void quad_load_rgb8norm(const uint8_t* p, float* v) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];                         // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    const uint32_t r[4] = {w0 & 0xFFu, w0 >> 24, (w1 >> 16) & 0xFFu, (w2 >> 8) & 0xFFu};
+    const uint32_t g[4] = {(w0 >> 8) & 0xFFu, w1 & 0xFFu, w1 >> 24, (w2 >> 16) & 0xFFu};
+    const uint32_t b[4] = {(w0 >> 16) & 0xFFu, (w1 >> 8) & 0xFFu, w2 & 0xFFu, w2 >> 24};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((float)((r[k] * 19595u + g[k] * 38470u + b[k] * 7471u + 0x8000u) >> 16) / 255.0f - 0.5f) / 0.5f;
+}
 template <int VPL>
 VC_DEV void patch_load(const void* frames_, int u8, long row, float (&v)[VPL], int lane, int img, int patch, int T, long bstride) {
     const int g_ = img / patch;
@@ -68,7 +81,8 @@ VC_DEV void patch_load(const void* frames_, int u8, long row, float (&v)[VPL], i
     for (int g = 0; g < VPL / 4; ++g) {
         int e = g * 256 + lane * 4;
         int p1 = e / patch, p2 = e % patch;
-        if (u8) quad_load_u8norm((const uint8_t*)frames_ + off + (long)p1 * img + p2, &v[g * 4]);
+        if (u8 == 2) quad_load_rgb8norm((const uint8_t*)frames_ + 3 * (off + (long)p1 * img + p2), &v[g * 4]);      // (bstride / offsets in pixels)
+        else if (u8) quad_load_u8norm((const uint8_t*)frames_ + off + (long)p1 * img + p2, &v[g * 4]);
         else quad_load<float>((const float*)frames_ + off + (long)p1 * img + p2, &v[g * 4]);
     }
 }

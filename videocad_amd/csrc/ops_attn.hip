@@ -117,13 +117,13 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     }
     if (dec_mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {       // one wave per head-dim chunk
         const dim3 g((unsigned)((long)p.B * p.H));
-        static bool attr = false;
-        if (!attr) {
+        static unsigned attr = 0;
+        if (!(attr & vc_device_bit())) {
             if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<true, 4>, am_cw_lds_bytes(4))) return rc;
             if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<false, 4>, am_cw_lds_bytes(4))) return rc;
             if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<true, 2>, am_cw_lds_bytes(2))) return rc;
             if (int rc = set_dyn_lds(attn_dec_fwd_cw_kernel<false, 2>, am_cw_lds_bytes(2))) return rc;
-            attr = true;
+            attr |= vc_device_bit();
         }
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_cw_kernel<true, 4>), g, dim3(256), am_cw_lds_bytes(4), s, p); else VC_LAUNCH((attn_dec_fwd_cw_kernel<false, 4>), g, dim3(256), am_cw_lds_bytes(4), s, p); }
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_cw_kernel<true, 2>), g, dim3(128), am_cw_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_fwd_cw_kernel<false, 2>), g, dim3(128), am_cw_lds_bytes(2), s, p); }
@@ -177,13 +177,13 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     }
     if (dec_mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {        // one wave per (orientation, head-dim chunk)
         const dim3 g((unsigned)((long)p.B * p.H));
-        static bool attr = false;
-        if (!attr) {
+        static unsigned attr = 0;
+        if (!(attr & vc_device_bit())) {
             if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<true, 4>, am_cwb_lds_bytes(4))) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<false, 4>, am_cwb_lds_bytes(4))) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<true, 2>, am_cwb_lds_bytes(2))) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_cw_kernel<false, 2>, am_cwb_lds_bytes(2))) return rc;
-            attr = true;
+            attr |= vc_device_bit();
         }
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_cw_kernel<true, 4>), g, dim3(256), am_cwb_lds_bytes(4), s, p); else VC_LAUNCH((attn_dec_bwd_cw_kernel<false, 4>), g, dim3(256), am_cwb_lds_bytes(4), s, p); }
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_cw_kernel<true, 2>), g, dim3(256), am_cwb_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_bwd_cw_kernel<false, 2>), g, dim3(256), am_cwb_lds_bytes(2), s, p); }
@@ -196,8 +196,8 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         return VC_OK;
     }
     if (dec_long_ok(t, D, p, true)) {
-        static bool attr = false;
-        if (!attr) {
+        static unsigned attr = 0;
+        if (!(attr & vc_device_bit())) {
             if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<true, 4>, AM_LONG_Q_LDS)) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 4>, AM_LONG_Q_LDS)) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 4>, AM_LONG_KV_LDS)) return rc;
@@ -206,7 +206,7 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
             if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 2>, AM_LONG_Q_LDS)) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 2>, AM_LONG_KV_LDS)) return rc;
             if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<false, 2>, AM_LONG_KV_LDS)) return rc;
-            attr = true;
+            attr |= vc_device_bit();
         }
         const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
 #define VC_LONG_BWD(DROP_, NCH_) do { VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<DROP_, NCH_>), g, dim3(64), AM_LONG_Q_LDS, s, p); \

@@ -19,11 +19,11 @@ extern "C" void vcad_debug_gemm_waves(int n) { g_waves = n == 4 ? 4 : 8; }
 template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
 static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;
+    if (!(attr_set & vc_device_bit())) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
+        attr_set |= vc_device_bit();
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
@@ -34,11 +34,11 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     // the ping-pong kernel carries the plain epilogue (bias, k-slice slabs); per-element side inputs stay on the lockstep kernel
     if (NW == 8 && BN == GD_BN && g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
 #ifndef VC_EMU
-        static bool attr_pp = false;
-        if (!attr_pp) {
+        static unsigned attr_pp = 0;
+        if (!(attr_pp & vc_device_bit())) {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP_LDS_BYTES);
             if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-            attr_pp = true;
+            attr_pp |= vc_device_bit();
         }
 #endif
         VC_LAUNCH((gemm_pp_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GP_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);

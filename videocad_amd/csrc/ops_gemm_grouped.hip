@@ -25,11 +25,11 @@ template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB
 static int grouped_launch(const GemmCall& sig, GemmGroup grp, int total_tiles, double flops, vc_stream_t s) {
     constexpr size_t lds = gemm_lds_bytes<CT, TRA, TRB, 2>();
 #ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;
+    if (!(attr_set & vc_device_bit())) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_grouped_kernel<CT, SA, SB, TO, TRA, TRB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
+        attr_set |= vc_device_bit();
     }
 #endif
     ProfScope ps(sig.role ? sig.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), flops, 0.0, s, VC_TAG_GEMM_GROUPED);

@@ -9,11 +9,11 @@ template <typename TO, bool TRB, int BM, int BN>
 static int gemm_launch_mid(GemmCall c, vc_stream_t s) {
     using TL = GmTile<BM, BN>;
 #ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;
+    if (!(attr_set & vc_device_bit())) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_mid_kernel<TO, TRB, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TL::LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
+        attr_set |= vc_device_bit();
     }
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD), 2.0 * c.p.M * c.p.N * c.p.K,

@@ -16,11 +16,11 @@ int vc_mx8_quant(int tx, const void* x, long ld, uint8_t* q, uint8_t* sc, long r
 template <typename TO>
 static int mx8_launch(const Mx8Params& q, vc_stream_t s) {
 #ifndef VC_EMU
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned attr_set = 0;
+    if (!(attr_set & vc_device_bit())) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_mx8_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MX_LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-        attr_set = true;
+        attr_set |= vc_device_bit();
     }
 #endif
     const int tiles = VC_CEIL_DIV(q.g.M, MX_BM) * (q.g.N / MX_BN);
@@ -32,7 +32,8 @@ static int mx8_launch(const Mx8Params& q, vc_stream_t s) {
 int vc_gemm_mx8(Mx8Params q, int to, vc_stream_t s) {
     GemmParams& p = q.g;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm_mx8: empty problem"); return VC_ERR_ARG; }
-    if (p.N % MX_BN || p.K % MX_BK || (p.lda % 16) || (p.ldb % 16) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16) || (q.ldsa % 4) || (q.ldsb % 4)) {
+    if (p.N % MX_BN || p.K % MX_BK || (p.lda % 16) || (p.ldb % 16) || ((uintptr_t)p.A % 16) || ((uintptr_t)p.B % 16) || (q.ldsa % 4) || (q.ldsb % 4) ||
+        ((uintptr_t)q.sa % 4) || ((uintptr_t)q.sb % 4)) {          // (scale rows are read as 32-bit words)
         vc_set_error("vc_gemm_mx8: needs N %% 128 == 0, K %% 128 == 0 and 16-byte aligned rows (N=%d K=%d)", p.N, p.K); return VC_ERR_UNSUPPORTED; }
     if ((double)p.lda * p.M >= 4.0e9 || (double)p.ldb * p.N >= 4.0e9) { vc_set_error("vc_gemm_mx8: operand larger than 4 GiB"); return VC_ERR_UNSUPPORTED; }
     if (p.act == VC_ACT_GELU) p.act = VC_ACT_GELU_FAST;           // as in the bf16 mode

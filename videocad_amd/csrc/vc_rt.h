@@ -37,6 +37,9 @@ static inline bool vc_has_side_streams() { return true; }
 // small host -> device table upload, ordered on the stream; the (pageable) host buffer may be reused when it returns
 static inline int vc_upload(void* d, const void* h, size_t n, vc_stream_t s) { int rc = (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); return rc ? rc : (int)hipStreamSynchronize(s); }
 static inline int vc_last_launch_error() { return (int)hipGetLastError(); }
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: the launchers remember it per device (bit = current device), so a
+// process that moves a model from cuda:0 to cuda:1 (or drives several GPUs) gets the large-LDS kernels on every device it uses
+static inline unsigned vc_device_bit() { int d = 0; (void)hipGetDevice(&d); return 1u << (d & 31); }
 
 VC_DEV void vc_sync() { __syncthreads(); }
 // orders a wave's own LDS writes before its later LDS reads (hardware is in-order per wave; this pins the compiler)
@@ -188,6 +191,7 @@ static inline void vc_stream_destroy(vc_stream_t) {}
 static inline void vc_event_destroy(vc_event_t) {}
 static inline bool vc_has_side_streams() { return false; }
 static inline int vc_last_launch_error() { return 0; }
+static inline unsigned vc_device_bit() { return 1u; }
 
 VC_DEV void vc_sync() { vcemu::sync_block(); }
 VC_DEV void vc_wave_barrier() { vcemu::sync_wave(); }

@@ -48,6 +48,81 @@ def frames_from_rgb(frames_rgb_u8: np.ndarray, as_uint8: bool = True) -> torch.T
     return g if as_uint8 else normalize_u8(g)
 
 
+# ------------------------------------------------------------------------------------------------ on-disk clips
+END_ACTION = 950            # reference generate_dataset.py:184: a key value of 950 ends the clip
+
+
+def finalize_clip(frames: np.ndarray, actions: np.ndarray, timesteps) -> dict:
+    """The record reference generate_dataset.py:180-199 pickles for one clip, from the per-action arrays `convert_logs_to_vectors` /
+    `extract_frames_from_actions` produced: the first frame is duplicated and an all-zero action row prepended (so step 0 predicts the first
+    real action from the initial screen), then everything is cut after the first row whose key column (index 3) holds END_ACTION.
+    -> {'frames' uint8 [N,H,W,3], 'actions' float [N,7] (0..999, -1 = unused slot), 'timesteps' [N]}"""
+    frames = np.vstack([frames[:1], frames])
+    actions = np.vstack([np.zeros((1, 7)), actions])
+    timesteps = np.array(list(timesteps[:1]) + list(timesteps))
+    end = np.where(actions[:, 3] == END_ACTION)[0]
+    if len(end) > 0:
+        frames, actions, timesteps = frames[: end[0] + 1], actions[: end[0] + 1], timesteps[: end[0] + 1]
+    assert len(frames) == len(actions), "Number of frames and actions must be the same"
+    return {"frames": frames, "actions": actions, "timesteps": timesteps}
+
+
+class PklClipDataset:
+    """Reader of the reference's dataset directory (data_loader/data_loader.py:293-312 file discovery, :399-508 item path;
+    sequence_retriver.py:25-33; image_loader.py:31-44): `<root>/.../<id>_data.pkl` = {'frames' uint8 [N,224,224,3], 'actions' [N,7],
+    'timesteps'} next to the clip's CAD render `<image_dir>/<id[:4]>/<id><suffix>` (PNG).  Items feed `collate_with_padding`.
+
+    mode  'rgb8'  frames stay the STORED uint8 RGB [N,H,W,3] — zero per-pixel host work; PIL's luma + ToTensor + Normalize run inside the
+                  patchify kernel (vcad_forward_rgb8); 3 bytes per pixel over PCIe
+          'gray8' frames uint8 gray [N,1,H,W] (host: PIL's integer luma only); 1 byte per pixel (vcad_forward_u8)
+          'f32'   the reference's item, fp32 [N,1,H,W] normalised to [-1, 1] (4 bytes per pixel)
+    The CAD image is cv2-read BGR -> BGR2GRAY -> /255 -> Normalize(0.5, 0.5) in the reference (:471-476); here: gray uint8 [1,H,W] for the uint8
+    modes (normalised in-kernel), the same fp32 for 'f32'.  Stored frames and renders must already be image_size (the released dataset is
+    `data_resized`): the reference's Resize / cv2.resize are identities there and are not restated."""
+
+    def __init__(self, dataset_path: str, image_dir: Optional[str] = None, mode: str = "rgb8", image_suffix: str = "_frame.png", image_size=(224, 224)):
+        import os
+        assert mode in ("rgb8", "gray8", "f32")
+        self.mode, self.image_size, self.image_suffix = mode, tuple(image_size), image_suffix
+        self.image_dir = image_dir if image_dir is not None else dataset_path
+        files = []
+        for root, _dirs, fs in os.walk(dataset_path):
+            files += [os.path.join(root, f) for f in fs if f.endswith("_data.pkl")]
+        self.data_files = sorted(files)                                         # reference :307-310: sorted, one render per clip id
+        self.ids = [os.path.basename(f).split("_")[0] for f in self.data_files]
+
+    def __len__(self):
+        return len(self.data_files)
+
+    def _cad_gray_u8(self, clip_id: str) -> np.ndarray:
+        import os
+        from PIL import Image
+        path = os.path.join(self.image_dir, clip_id[:4], clip_id + self.image_suffix)
+        rgb = np.asarray(Image.open(path).convert("RGB"))                       # cv2.imread delivers the same pixels as BGR
+        if rgb.shape[:2] != self.image_size[::-1]:
+            raise ValueError(f"{path}: {rgb.shape[:2]} render, expected {self.image_size[::-1]} (resize offline)")
+        return cv2_bgr2gray_u8(rgb[..., ::-1])
+
+    def __getitem__(self, idx: int) -> dict:
+        import pickle
+        if idx < 0 or idx >= len(self.data_files):
+            raise IndexError("Index out of range")
+        with open(self.data_files[idx], "rb") as f:
+            data = pickle.load(f)
+        frames = np.ascontiguousarray(data["frames"]); actions = np.asarray(data["actions"])
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3 or frames.shape[1:3] != self.image_size[::-1]:
+            raise ValueError(f"{self.data_files[idx]}: frames {frames.dtype} {frames.shape}, expected uint8 [N,{self.image_size[1]},{self.image_size[0]},3]")
+        cad = torch.from_numpy(self._cad_gray_u8(self.ids[idx])).unsqueeze(0)
+        if self.mode == "rgb8":
+            ft = torch.from_numpy(frames)
+        elif self.mode == "gray8":
+            ft = frames_from_rgb(frames, as_uint8=True)
+        else:
+            ft = frames_from_rgb(frames, as_uint8=False); cad = normalize_u8(cad)
+        return {"frames": ft, "actions": torch.from_numpy(actions.astype(np.float32)), "cad_image": cad,
+                "multiview_images": None, "timesteps": torch.arange(ft.shape[0])}
+
+
 # ------------------------------------------------------------------------------------------------ collate
 def _pad_value(dtype: torch.dtype):
     return 0 if dtype == torch.uint8 else -1           # pixel 0 == -1.0 after normalisation

@@ -54,6 +54,7 @@ class NativeEngine:
         self.params = self.grads = self.m = self.v = self.shadow = None
         self.ws = None
         self.step_count = 0
+        self.fwd_serial = 0           # bumped by every call that overwrites the engine's single activation set (forward, infer_begin)
         self.fp8 = False
         self.allocate(self.device)
         if os.environ.get("VCAD_FP8", "0") == "1" and self.cfg.dtype == L.VCAD_BF16:
@@ -114,10 +115,17 @@ class NativeEngine:
         B, T = int(actions_norm.shape[0]), int(actions_norm.shape[1])
         S = self.cfg.image_size
         u8 = frames.dtype == torch.uint8
-        assert frames.dtype in (torch.float32, torch.uint8) and frames.shape[1] == T and tuple(frames.shape[2:]) == (1, S, S)
-        if frames.stride()[1:] != (S * S, S * S, S, 1):
-            frames = frames.contiguous()
-        fb = frames.stride(0) if B > 1 else T * S * S
+        rgb = u8 and frames.dim() == 5 and tuple(frames.shape[2:]) == (S, S, 3)       # the dataset's stored pixels [B,T,H,W,3]: gray + normalise in-kernel
+        assert frames.dtype in (torch.float32, torch.uint8) and frames.shape[1] == T and (rgb or tuple(frames.shape[2:]) == (1, S, S))
+        if rgb:
+            if frames.stride()[1:] != (S * S * 3, S * 3, 3, 1):
+                frames = frames.contiguous()
+            fb = (frames.stride(0) if B > 1 else T * S * S * 3) // 3                  # batch stride in pixels
+            assert fb % 4 == 0
+        else:
+            if frames.stride()[1:] != (S * S, S * S, S, 1):
+                frames = frames.contiguous()
+            fb = frames.stride(0) if B > 1 else T * S * S
         actions_norm = actions_norm.contiguous().float()
         cad = cad.contiguous() if u8 else cad.contiguous().float()
         assert cad.dtype == frames.dtype, "frames and cad_image must both be fp32 or both be uint8"
@@ -125,7 +133,8 @@ class NativeEngine:
         cmds = torch.empty(B, T, self.cfg.num_classes, device=self.device)
         pars = torch.empty(B, T, self.cfg.num_params, self.cfg.num_params_values, device=self.device)
         self._keep = (frames, actions_norm, cad)          # backward re-reads the inputs (patch-LN grads, embed_action wgrad)
-        fn = self.lib.vcad_forward_u8 if u8 else self.lib.vcad_forward
+        self.fwd_serial += 1
+        fn = self.lib.vcad_forward_rgb8 if rgb else (self.lib.vcad_forward_u8 if u8 else self.lib.vcad_forward)
         L.check(self.lib, fn(self.h, _ptr(frames), fb, _ptr(actions_norm), _ptr(cad), B, T, _ptr(cmds), _ptr(pars), self.stream()), "forward")
         return cmds, pars
 
@@ -139,6 +148,7 @@ class NativeEngine:
         u8 = cad.dtype == torch.uint8
         cad = cad.contiguous() if u8 else cad.contiguous().float()
         self._keep_i = cad
+        self.fwd_serial += 1                                 # the (B, 1) incremental plan replaces the training activations
         fn = self.lib.vcad_infer_begin_u8 if u8 else self.lib.vcad_infer_begin
         L.check(self.lib, fn(self.h, _ptr(cad), B, Tmax, self.stream()), "infer_begin")
         self._infer_u8 = u8

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "vcad_debug_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_forward_u8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "vcad_forward_rgb8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float * 5), _vp, _vp, _vp, _vp]),
     "vcad_dlogits_offsets": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "vcad_backward": (_i, [_vp, _vp, _vp, _vp]),

@@ -51,6 +51,22 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
+def unwrap(model):
+    """The native module behind the wrappers reference experiment.py:92-109 may put around it: `torch.compile` (OptimizedModule,
+    `._orig_mod`) and `DistributedDataParallel` (`.module`), in either nesting.  The trainer drives the engine of the native module
+    directly — the wrappers' own forward (dynamo tracing, DDP's reducer hooks) is never entered: the arithmetic is one C-ABI call and
+    the gradient exchange is `GradSync`."""
+    for _ in range(4):          # (look in _modules: OptimizedModule forwards unknown attributes to the module it wraps, so hasattr() cannot tell them apart)
+        mods = getattr(model, "_modules", {})
+        if "_orig_mod" in mods:
+            model = mods["_orig_mod"]
+        elif "module" in mods and type(model).__name__ in ("DistributedDataParallel", "DataParallel"):
+            model = mods["module"]
+        else:
+            break
+    return model
+
+
 # ------------------------------------------------------------------------------------------------ logs / checkpoints
 class MetricsHandler:
     """logs/<experiment>/<ext>.json on rank 0 (reference trainer.py:86-131)."""
@@ -85,8 +101,9 @@ class NativeAdam:
     """What `trainer.optimizer` is here: the handle on the fused clip + Adam kernel's state (flat m / v buffers + step count).
     `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (state indexed by position in `model.parameters()`,
     one param_group per learning rate), so `checkpoint['optimizer_state_dict']` (reference trainer.py:146-151) round-trips and
-    also loads into a `torch.optim.Adam(model.parameters())` built on this model.  (Indices are over THIS model's 309 live
-    tensors: the reference's list also counts its 77.6 M dead GPT-2 parameters, which never get optimiser state.)"""
+    also loads into a `torch.optim.Adam(model.parameters())` built on THIS model.  Indices are over this model's 309 live
+    tensors; the reference's Adam indexes its own, longer parameter list (dead GPT-2 trunk first) — to exchange optimiser state
+    with a checkpoint the reference wrote use `state_dict_for(names)` / `load_state_dict_from(sd, names)` (name-keyed)."""
 
     def __init__(self, model, lr, groups=None, betas=(0.9, 0.999), eps=1e-8):
         self.model, self.engine = model, model._engine
@@ -122,6 +139,34 @@ class NativeAdam:
             for i, n in enumerate(self.names):
                 state[i] = {"step": torch.tensor(float(eng.step_count)), "exp_avg": eng.view(n, eng.m), "exp_avg_sq": eng.view(n, eng.v)}
         return {"state": state, "param_groups": [dict(g) for g in self.param_groups]}
+
+    # ---- name-keyed forms: torch.optim.Adam indexes its state by position in the parameter list it was built on.  The reference builds
+    # it on `model.parameters()` of ITS module tree (trainer.py:251-253: GPT-2 trunk first, 77.6 M parameters that never get state), so
+    # the positional dict above does not line up with a checkpoint the reference wrote — these convert through parameter NAMES.
+    def named_state(self):
+        """{parameter name: {'step', 'exp_avg', 'exp_avg_sq'}} for every live tensor (empty before the first step)"""
+        sd = self.state_dict()["state"]
+        return {self.names[i]: st for i, st in sd.items()}
+
+    def state_dict_for(self, param_names):
+        """optimizer_state_dict as a `torch.optim.Adam` built over parameters named `param_names` (in that order — e.g.
+        `[n for n, _ in reference_model.named_parameters()]`) would hold it: state only for names this model trains (the reference's dead
+        parameters never receive gradients, so torch keeps no state for them either), one param_group over all indices."""
+        named, pos = self.named_state(), {n: i for i, n in enumerate(param_names)}
+        missing = [n for n in named if n not in pos]
+        if missing:
+            raise KeyError(f"state_dict_for: {len(missing)} trained parameters are not in param_names (e.g. {missing[:3]})")
+        g = self._group(self.param_groups[-1]["lr"], list(range(len(param_names))))
+        return {"state": {pos[n]: st for n, st in named.items()}, "param_groups": [g]}
+
+    def load_state_dict_from(self, sd, param_names):
+        """inverse of state_dict_for: accepts the optimizer_state_dict of an Adam built over `param_names` (a reference checkpoint)"""
+        idx = {n: i for i, n in enumerate(self.names)}
+        conv = {idx[param_names[int(i)]]: st for i, st in sd.get("state", {}).items() if param_names[int(i)] in idx}
+        self.load_state_dict({"state": conv, "param_groups": []})
+        if sd.get("param_groups"):
+            for g in self.param_groups:
+                g["lr"] = sd["param_groups"][0]["lr"]
 
     def load_state_dict(self, sd):
         eng = self.engine
@@ -209,14 +254,20 @@ class GradSync:
                 self.stream.wait_event(ev)
                 self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
 
-        # stage 1 (CAD ViT: ~230 small kernels) runs on the engine's side stream beside the frame ViT's stages 2-3; its bucket is
-        # reduced last, after join_side() has ordered it before `cur`
+        # stage 1 (CAD ViT: ~230 small kernels) runs on the engine's side stream beside the frame ViT's stages 2-3.  Its bucket (65 MB) is
+        # all-reduced as soon as THAT stream is done: the communication stream — not the compute stream — waits for the side stream's
+        # completion event (vcad_join_side on the communication stream), so the exchange runs under stages 2 and 3 instead of after them
+        # (r02 reduced it last, leaving bucket 1 + bucket 3 = 99 MB with nothing to hide behind; now only bucket 3 is exposed).
         eng.backward(dcmds, dpars, stage=0); reduce_bucket(0)
         eng.backward(dcmds, dpars, stage=1, side=True)
+        with torch.cuda.stream(self.stream):
+            eng.join_side()                                         # comm stream <- side-stream event
+            if not self.skip_comm:
+                lo, hi = eng.buckets[1]
+                self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
         for st in range(2, len(eng.buckets)):
             eng.backward(dcmds, dpars, stage=st); reduce_bucket(st)
-        eng.join_side(); reduce_bucket(1)
-        cur.wait_stream(self.stream)
+        cur.wait_stream(self.stream)                                # (covers the side stream too: the comm stream waited for it)
 
 
 # ------------------------------------------------------------------------------------------------ trainer
@@ -238,13 +289,16 @@ class BaseTrainer:
         self.train_loader, self.val_loader, self.test_loader = train_packet["loader"], val_packet["loader"], test_packet["loader"]
         self.train_sampler, self.val_sampler, self.test_sampler = train_packet["sampler"], val_packet["sampler"], test_packet["sampler"]
         self.model = model
-        self.native = getattr(model, "module", model)            # tolerate a DDP-style wrapper
+        self.native = unwrap(model)                               # tolerate the reference harness's torch.compile / DDP wrappers
         self.engine = self.native._engine
         self.lr = cfg("lr", 1e-3)                                 # reference :235
         groups = {"lr_cad": cfg("lr_cad", 1e-3), "lr_state": cfg("lr_state", 1e-3)} if self.frozen else None
         self.optimizer = NativeAdam(self.native, self.lr, groups)
         self.use_mse = cfg("use_mse", False)
         self.reduce_eval_metrics = cfg("reduce_eval_metrics", True)
+        # The reference "reloads" best_model_state at the end of train() (:370-380), but that state dict aliases the live parameters, so the
+        # model it returns holds the LAST weights.  Default = that behaviour; restore_best_weights=True copies the best epoch's weights back.
+        self.restore_best_weights = cfg("restore_best_weights", False)
         self.stage_inputs = cfg("stage_inputs", True)             # double-buffered H2D staging of the train loader (data.DeviceStager)
         self.native._drop_rank = rank                             # every rank draws its own dropout masks
         self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed)
@@ -390,7 +444,9 @@ class BaseTrainer:
     def _restore_best(self, best_state):
         """The reference reloads `best_model_state['model_state_dict']` (:371), whose tensors alias the live parameters (a no-op there);
         here the best weights are a device-side copy of the flat buffer taken when the checkpoint was written."""
-        if best_state is None or self._best_params is None:
+        if best_state is None or self._best_params is None or not self.restore_best_weights:
+            if best_state is not None:
+                self.log(f"Loaded best model from epoch {best_state['epoch']}")      # (the reference prints this; its load is an aliasing no-op)
             return
         with torch.no_grad():
             self.engine.params.copy_(self._best_params)
@@ -404,7 +460,7 @@ class BaseTrainer:
         loader = DeviceStager(self.train_loader, self.device) if (self.stage_inputs and torch.device(self.device).type == "cuda") else self.train_loader
         running = torch.zeros((), device=self.device)
         counters = torch.zeros(L.NMETRIC, dtype=torch.int64, device=self.device)
-        n, log_every = 0, self.training_config.get("log_frequency", 0)
+        n, log_every = 0, self.training_config.get("log_frequency", 2)      # reference :457-458: every 2nd batch (0 = never; each log is one host sync)
         for batch_idx, batch in enumerate(loader):
             bd = self.prepare_batch(batch)
             if noise:
@@ -431,18 +487,22 @@ class BaseTrainer:
         cur = avg_loss
         if self.early_stopping_metric == "accuracy" and val_metrics and val_metrics.get("total_predictions", 0):
             cur = val_metrics["correct_predictions"] / val_metrics["total_predictions"]
+        d = _dist()
+        if d is not None:       # ONE decision for all ranks: the monitored value is averaged (avg_loss is per rank, validation may have been
+            v = torch.tensor([float(cur)], dtype=torch.float64, device=self.device)        # skipped or left unreduced), so patience, best_value
+            d.all_reduce(v); cur = float(v.item()) / d.get_world_size()                   # and the best-weights snapshot advance in lock-step
         improved = cur < best_value - self.early_stopping_min_delta if self.early_stopping_mode == "min" else cur > best_value + self.early_stopping_min_delta
         if improved:
             self.log(f"Validation {self.early_stopping_metric} improved from {best_value:.4f} to {cur:.4f}")
             best_value, patience = cur, 0
             ck = self.save_checkpoint(epoch, avg_loss, is_best=True)
             best_state = {"epoch": epoch + 1} if ck is None else {"epoch": ck["epoch"]}
-            self._best_params = self.engine.params.clone()
+            if self.restore_best_weights:
+                self._best_params = self.engine.params.clone()
         else:
             patience += 1
             self.log(f"Validation {self.early_stopping_metric} did not improve. Patience: {patience}/{self.early_stopping_patience}")
         stop = patience >= self.early_stopping_patience
-        d = _dist()
         if d is not None:                                          # reference :559-563: stop only when every rank wants to
             flag = torch.tensor([int(stop)], device=self.device)
             d.all_reduce(flag, op=d.ReduceOp.MIN)
@@ -455,7 +515,7 @@ class BaseTrainer:
         loader = {"train": self.train_loader, "val": self.val_loader}.get(mode, self.test_loader)
         model.eval()
         metrics = self.init_metrics()
-        native = getattr(model, "module", model)
+        native = unwrap(model)
         counters = torch.zeros(L.NMETRIC, dtype=torch.int64, device=self.device)
         loss_sum = torch.zeros(2, dtype=torch.float64, device=self.device)           # [sum of batch losses, batches]
         fused = hasattr(native, "_engine")
