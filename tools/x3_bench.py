@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
 
+if os.environ.get("VCAD_LIB"):          # an experiment build of the library (timing only)
+    L._lib = L.declare(C.CDLL(os.environ["VCAD_LIB"]))
 lib = L.load()
 dev = "cuda:0"
 scratch = torch.empty(256 << 20, dtype=torch.uint8, device=dev)

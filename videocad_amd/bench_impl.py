@@ -112,14 +112,14 @@ def _cpu_baseline_worker(q, threads, seconds_budget):
            "value_B2_T8": round(v8, 2), "host_cores": os.cpu_count(),
            "sample": f"{n64} full train steps of the oracle restatement at B=2,T=64 (value) and {n8} at B=2,T=8 (value_B2_T8); fp32, "
                      f"torch {torch.__version__} CPU, torch.set_num_threads({threads}) on a {os.cpu_count()}-core host "
-                     f"(the intra-op pool is capped at 32 threads: beyond that one step of this model gets slower, not faster)"})
+                     f"(thread count from the measured sweep in profiles/r03_cpu_thread_sweep.txt: more threads make one step of this model slower)"})
 
 
 def cpu_baseline(seconds_budget=24.0, hard_limit=240.0):
     """The oracle restatement (fp32 PyTorch-CPU, validated against the imported reference) timed on this host's cores on a
     bounded sample of the same workload, in a child process with a hard wall-clock limit.  Reported baseline only."""
     import multiprocessing as mp
-    threads = min(os.cpu_count() or 1, 32)
+    threads = min(os.cpu_count() or 1, 16)        # the thread count the sweep picks on the GPU box's 256-core host (profiles/r03_cpu_thread_sweep.txt: 8 / 16 / 32 / 64 threads -> 108 / 157 / 103 / 54 frames/s)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     pr = ctx.Process(target=_cpu_baseline_worker, args=(q, threads, seconds_budget))

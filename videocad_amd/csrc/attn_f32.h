@@ -3,10 +3,10 @@
 // The fp32-storage modes (VCAD_F32 parity mode, VCAD_BF16X3 in-tolerance mode) ran every attention on the wave-per-row kernels of
 // attn.h, where each lane walks a whole K row from global memory: 88 of the 203 ms of a C2 step (profiles/r02_bench_f32.json).  These
 // kernels keep the same mask rule and the same two-kernel backward split (no atomics, deterministic) but put one wave on a
-// 32-query (or 32-key) block and all four contractions on the matrix cores.  They need no LDS and no barrier:
+// 32-query (or 32-key) block and all four contractions on the matrix cores.  They need no workgroup barrier and use LDS only as a wave-private 8.5 KiB transposer for the row tiles:
 //
 //   * the score product is issued SWAPPED, S^T = K Q^T, with the k-index of one MFMA step paired as (d, d + 32): lane (row, half)
-//     supplies elements [half*32 + kk] of ITS OWN K / Q row — 32 consecutive floats, loaded as eight 16-byte pieces into registers;
+//     supplies elements [half*32 + kk] of ITS OWN K / Q row — 32 consecutive floats in registers (fetched coalesced, af_ld32_rows);
 //   * in the S^T accumulator a lane owns one query (column) — softmax statistics are lane-local plus ONE exchange with lane ^ 32;
 //   * accumulator register r of a tile holds P[i][j_r] in lanes 0-31 and P[i][j_r + 4] in lanes 32-63 — exactly an MFMA A fragment
 //     whose two k-steps are keys (j_r, j_r + 4), so P (and dS) feed the second product straight from the accumulator registers;
@@ -26,6 +26,34 @@ VC_DEV void af_ld32(const float* p, float (&v)[32]) {            // 32 consecuti
         const vc_u32x4 c = reinterpret_cast<const vc_u32x4*>(p)[q];
         v[4 * q] = vc_bits_f32(c.x); v[4 * q + 1] = vc_bits_f32(c.y); v[4 * q + 2] = vc_bits_f32(c.z); v[4 * q + 3] = vc_bits_f32(c.w);
     }
+}
+// The same 32 floats [half*32, half*32 + 32) of row (row0 + lane % 32) of a [rows][64-float chunk] block at g0 — but fetched COALESCED:
+// 16 lanes cover one 256-byte row piece, four rows per load instruction, then transposed through a wave-private LDS tile (row pitch 68
+// floats: the 16-byte reads of 16 different rows hit 64 different banks).  When every lane read its own row straight from memory a load
+// instruction touched 64 different cache lines for 1 KiB; the score phases then ran at 2.5 TB/s and cost 35-40 % of the kernels
+// (profiles/r03_attn_rowload_ab.txt).  Rows past nvalid repeat row nvalid - 1 (masked later, never stored).
+constexpr int AF_PITCH = 68;
+// (two halves: the coalesced loads into eight staging quads, then the trip through the LDS tile into the operand registers)
+VC_DEV void af_gload(vc_u32x4 (&stg)[8], const float* g0, long ld, int row0, int nvalid, int lane) {
+    const int r = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        int rr = row0 + it * 4 + r; rr = rr < nvalid ? rr : nvalid - 1;
+        stg[it] = *reinterpret_cast<const vc_u32x4*>(g0 + (long)rr * ld + c4);
+    }
+}
+VC_DEV void af_transpose(float* tile, const vc_u32x4 (&stg)[8], float (&v)[32], int lane) {
+    const int r = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *reinterpret_cast<vc_u32x4*>(tile + (it * 4 + r) * AF_PITCH + c4) = stg[it];
+    vc_wave_barrier();
+    af_ld32(tile + (lane & 31) * AF_PITCH + (lane >> 5) * 32, v);
+    vc_wave_barrier();                                  // the next tile's writes stay behind these reads
+}
+VC_DEV void af_ld32_rows(float* tile, const float* g0, long ld, int row0, int nvalid, float (&v)[32], int lane) {
+    vc_u32x4 stg[8];
+    af_gload(stg, g0, ld, row0, nvalid, lane);
+    af_transpose(tile, stg, v, lane);
 }
 VC_DEV void af_zero(vc_f32x16& a) {
 #pragma unroll
@@ -64,18 +92,23 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_f32_fwd_kernel(AttnParams p) {
     // key tiles this block needs (wave-uniform): tile t holds keys 32t .. 32t+31
     const int i_first = qb * 32, i_last = (qb * 32 + 31 < p.Tq ? qb * 32 + 31 : p.Tq - 1);
     const int j_min = i_first - p.window + 1 > 0 ? i_first - p.window + 1 : 0, j_max = p.causal ? (i_last < p.Tk - 1 ? i_last : p.Tk - 1) : p.Tk - 1;
-    const float* qrow = (const float*)p.q + (b * p.Tq + iq) * p.ldq + (long)h * D + half * 32;
+    VC_SHARED float af_tile[4][32 * AF_PITCH];
+    float* tile = af_tile[wave];
+    const float* qblk = (const float*)p.q + (b * p.Tq) * p.ldq + (long)h * D;
+    const float* kblk = (const float*)p.k + (b * p.Tk) * p.ldk + (long)h * D;
     vc_f32x16 st[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) af_zero(st[t]);
+    // (requesting tile n + 1's rows into staging registers before tile n's MFMAs, with the order pinned, was measured: 860 us against 596 us
+    // for the ViT forward — the fences that pin it also stop hipcc from interleaving the LDS reads with the matrix-core work; left to the
+    // compiler and the second wave on the SIMD)
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        float qf[32]; af_ld32(qrow + c * 64, qf);
+        float qf[32]; af_ld32_rows(tile, qblk + c * 64, p.ldq, qb * 32, p.Tq, qf, lane);
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
-            const int jk = t * 32 + il < p.Tk ? t * 32 + il : p.Tk - 1;
-            float kf[32]; af_ld32((const float*)p.k + (b * p.Tk + jk) * p.ldk + (long)h * D + c * 64 + half * 32, kf);
+            float kf[32]; af_ld32_rows(tile, kblk + c * 64, p.ldk, t * 32, p.Tk, kf, lane);
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) st[t] = vc_mfma_32x32x2_f32(kf[kk], qf[kk], st[t]);
         }
@@ -153,23 +186,25 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(AttnParams p) {
     const int lo = iq - p.window + 1 > 0 ? iq - p.window + 1 : 0, hi = p.causal ? (iq < p.Tk - 1 ? iq : p.Tk - 1) : p.Tk - 1;
     const int i_first = qb * 32, i_last = (qb * 32 + 31 < p.Tq ? qb * 32 + 31 : p.Tq - 1);
     const int j_min = i_first - p.window + 1 > 0 ? i_first - p.window + 1 : 0, j_max = p.causal ? (i_last < p.Tk - 1 ? i_last : p.Tk - 1) : p.Tk - 1;
-    const float* qrow = (const float*)p.q + (b * p.Tq + iq) * p.ldq + (long)h * D + half * 32;
-    const float* dorow = (const float*)p.dout + (b * p.Tq + iq) * p.lddo + (long)h * D + half * 32;
+    VC_SHARED float af_tile[4][32 * AF_PITCH];
+    float* tile = af_tile[wave];
+    const float* qblk = (const float*)p.q + (b * p.Tq) * p.ldq + (long)h * D;
+    const float* doblk = (const float*)p.dout + (b * p.Tq) * p.lddo + (long)h * D;
+    const float* kblk = (const float*)p.k + (b * p.Tk) * p.ldk + (long)h * D;
+    const float* vblk = (const float*)p.v + (b * p.Tk) * p.ldv + (long)h * D;
     vc_f32x16 st[NKT], dpt[NKT];          // S^T and dP^T = V dO^T, same layout
 #pragma unroll
     for (int t = 0; t < NKT; ++t) { af_zero(st[t]); af_zero(dpt[t]); }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        float qf[32], df[32]; af_ld32(qrow + c * 64, qf); af_ld32(dorow + c * 64, df);
+        float qf[32], df[32]; af_ld32_rows(tile, qblk + c * 64, p.ldq, qb * 32, p.Tq, qf, lane); af_ld32_rows(tile, doblk + c * 64, p.lddo, qb * 32, p.Tq, df, lane);
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             if (t * 32 > j_max || t * 32 + 31 < j_min) continue;
-            const int jk = t * 32 + il < p.Tk ? t * 32 + il : p.Tk - 1;
-            const long ko = (b * p.Tk + jk);
-            float kf[32]; af_ld32((const float*)p.k + ko * p.ldk + (long)h * D + c * 64 + half * 32, kf);
+            float kf[32]; af_ld32_rows(tile, kblk + c * 64, p.ldk, t * 32, p.Tk, kf, lane);
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) st[t] = vc_mfma_32x32x2_f32(kf[kk], qf[kk], st[t]);
-            float vf[32]; af_ld32((const float*)p.v + ko * p.ldv + (long)h * D + c * 64 + half * 32, vf);
+            float vf[32]; af_ld32_rows(tile, vblk + c * 64, p.ldv, t * 32, p.Tk, vf, lane);
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) dpt[t] = vc_mfma_32x32x2_f32(vf[kk], df[kk], dpt[t]);
         }
@@ -238,22 +273,25 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_f32_bwd_kv_kernel(AttnParams p) {
     const int j_first = kb * 32, j_last = (kb * 32 + 31 < p.Tk ? kb * 32 + 31 : p.Tk - 1);
     const int i_min = p.causal ? j_first : 0;
     int i_max = j_last + p.window - 1; if (i_max > p.Tq - 1) i_max = p.Tq - 1;
-    const float* krow = (const float*)p.k + (b * p.Tk + jk) * p.ldk + (long)h * D + half * 32;
-    const float* vrow = (const float*)p.v + (b * p.Tk + jk) * p.ldv + (long)h * D + half * 32;
+    VC_SHARED float af_tile[4][32 * AF_PITCH];
+    float* tile = af_tile[wave];
+    const float* qblk = (const float*)p.q + (b * p.Tq) * p.ldq + (long)h * D;
+    const float* doblk = (const float*)p.dout + (b * p.Tq) * p.lddo + (long)h * D;
+    const float* kblk = (const float*)p.k + (b * p.Tk) * p.ldk + (long)h * D;
+    const float* vblk = (const float*)p.v + (b * p.Tk) * p.ldv + (long)h * D;
     vc_f32x16 s[NQT], dp[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) { af_zero(s[t]); af_zero(dp[t]); }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        float kf[32], vf[32]; af_ld32(krow + c * 64, kf); af_ld32(vrow + c * 64, vf);
+        float kf[32], vf[32]; af_ld32_rows(tile, kblk + c * 64, p.ldk, kb * 32, p.Tk, kf, lane); af_ld32_rows(tile, vblk + c * 64, p.ldv, kb * 32, p.Tk, vf, lane);
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
             if (t * 32 > i_max || t * 32 + 31 < i_min) continue;
-            const int iq = t * 32 + il < p.Tq ? t * 32 + il : p.Tq - 1;
-            float qf[32]; af_ld32((const float*)p.q + (b * p.Tq + iq) * p.ldq + (long)h * D + c * 64 + half * 32, qf);
+            float qf[32]; af_ld32_rows(tile, qblk + c * 64, p.ldq, t * 32, p.Tq, qf, lane);
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) s[t] = vc_mfma_32x32x2_f32(qf[kk], kf[kk], s[t]);
-            float df[32]; af_ld32((const float*)p.dout + (b * p.Tq + iq) * p.lddo + (long)h * D + c * 64 + half * 32, df);
+            float df[32]; af_ld32_rows(tile, doblk + c * 64, p.lddo, t * 32, p.Tq, df, lane);
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) dp[t] = vc_mfma_32x32x2_f32(df[kk], vf[kk], dp[t]);
         }

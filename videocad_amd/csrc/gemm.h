@@ -401,7 +401,7 @@ VC_DEV vc_s16x8 gemm_frag_bf16(const CT* tile, int row0, int ks, int lane) {
 // The tile program.  (bid, nx, ny) = linear tile id and tile-grid extent of THIS problem, bz = k-slice — the plain kernel
 // passes its own block coordinates, the grouped kernel the position inside the problem a workgroup was assigned to.
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
-VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, const int ny, const int bz, const bool slice_on_xcd = false) {
+VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, const int ny, const int bz) {
     constexpr int BK = GemmCfg<CT>::BK, STRIDE = GemmCfg<CT>::STRIDE;
     constexpr int GEMM_BM = 64 * WT, GEMM_BN = 64 * WT, WS = 32 * WT;     // block tile, per-wave sub-tile
     VC_DYN_SHARED(CT, lds);
@@ -417,8 +417,7 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
     {
         const int total = nx * ny;
         const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
-        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any total
-        if (slice_on_xcd) t = bid;       // (the caller already put every tile of this k-slice on one XCD: see gemm_kernel)
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any total
         tile_m = t / nx; tile_n = t - tile_m * nx;
     }
     const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
@@ -657,17 +656,9 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
 
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
 VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmParams p) {
-    // Split-K launches with few output tiles (the token-reduction weight gradients: 16 tiles x 32 k-slices for the ViT MLP): every tile of a
-    // k-slice reads the same two operand slabs.  With the tiles of a slice dealt round-robin to the 8 XCDs each private L2 fetched the slabs
-    // again (r02 PMC: 653 MB against 210 MB algorithmic per call); here a k-slice lives on ONE XCD — hardware block h runs on XCD h % 8, so
-    // slice = 8 * (h / (8 T)) + h % 8, tile = (h / 8) % T — and its tiles share the slabs through that L2.
-    const int T_ = gridDim.x * gridDim.y;
-    if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
-        const int h = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int j = h >> 3;
-        gemm_tile_program<CT, SA, SB, TO, TRA, TRB, WT>(p, j % T_, gridDim.x, gridDim.y, (j / T_) * 8 + (h & 7), true);
-        return;
-    }
+    // (r03 experiment, not kept: mapping every tile of a k-slice of the split-K weight gradients onto ONE XCD — slice = 8 (h / 8T) + h % 8 for
+    // hardware block h — so that the 16 tiles of the ViT MLP wgrad share their operand slabs through one L2: PMC fetch 695 MB per call
+    // against 653 MB before, i.e. no reuse gained; the 3.1x over-fetch of that launch stands, profiles/r03_summary.md.)
     gemm_tile_program<CT, SA, SB, TO, TRA, TRB, WT>(p, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
 }
 

@@ -170,7 +170,6 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     int nsplit = 1;
     if (scratch && tiles < 256 && p.K >= 8 * BK) {
         nsplit = (int)VC_CEIL_DIV(512, tiles);
-        if (nsplit >= 8) nsplit = (nsplit + 7) & ~7;          // whole k-slices per XCD (gemm_kernel maps slice -> XCD when the count is a multiple of 8)
         int maxs = p.K / (4 * BK); if (nsplit > maxs) nsplit = maxs;
         size_t per = (size_t)p.M * p.N * sizeof(float);
         if ((size_t)nsplit * per > scratch_bytes) nsplit = (int)(scratch_bytes / per);
