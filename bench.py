@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -33,18 +33,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seq186", action="store_true", help="skip the extra seq_len=186 measurement reported beside the headline config")
     ap.add_argument("--gemm-dma", type=int, default=-1, help="A/B switch: 0 = register-staged GEMM only, -1 = automatic (default)")
-    ap.add_argument("--gemm-policy", type=int, default=0, help="A/B bits of dispatcher rules (vcad_debug_gemm_policy)")
-    ap.add_argument("--attn-variant", type=int, default=0, help="A/B: 1 = r01 ViT attention kernels (one / two waves per head)")
     ap.add_argument("--gemm-mid", type=int, default=-1, help="A/B: 0 = no six-stage DMA-ring kernel for mid-size GEMMs, -1 = automatic")
     ap.add_argument("--fp8", action="store_true", help="VCAD_FP8 forward mode: the ViT Linear layers on the MXFP8 matrix cores (not the headline number)")
-    ap.add_argument("--split-gelu", type=int, default=1, help="A/B: 0 = GELU / GELU' fused into the MLP GEMM epilogues (r01), 1 = own passes behind plain GEMMs")
     ap.add_argument("--no-side", type=int, default=0, help="A/B: 1 = no library side stream (CAD ViT and deferred wgrads serialised on the caller's stream)")
     ap.add_argument("--gemm-wide", type=int, default=-1, help="A/B switch: 0 = 256x128 tile only, -1 = automatic (default)")
     ap.add_argument("--uint8-frames", action="store_true", help="feed uint8 grayscale pixels (normalised inside the patchify kernel) instead of fp32 frames")
     ap.add_argument("--no-modes", action="store_true", help="skip the short bf16x3 / f32 / fp8 legs reported beside the headline (each with its parity block)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (pinned host -> HBM staged) measurement reported beside the headline")
     ap.add_argument("--profile-only", action="store_true", help="rocprofv3 runs: only the headline workload's train steps (no seq-186 / PCIe / parity / CPU-baseline legs)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.profile_only:
         args.no_cpu_baseline = args.no_seq186 = args.no_pcie = args.no_parity = args.no_modes = True
 

@@ -76,8 +76,9 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * vcad_workspace_bytes again).  Replaces nothing in the reference: BASELINE configs[4]'s "fp8 MFMA" variant. */
 int vcad_set_fp8(vcad_engine* e, int on);
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed);
-/* test hook: keep-multipliers of one site (module 1 = frame ViT, 2 = CAD ViT, 3 = decoder; kind ids in engine.hip) -> HOST buffer */
-int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out);
+/* keep-multipliers of one site, recomputed from (seed, site, index); a pure function of the engine's dropout setting (the parity tests hand them to the oracle)
+ *  (module 1 = frame ViT, 2 = CAD ViT, 3 = decoder; kind ids in engine.hip) -> HOST buffer */
+int vcad_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out);
 
 /* ---- AutoRegressiveTransformer.forward (reference model/autoregressive_transformer.py:121-220)
  * frames: fp32, frame (b,t) at frames + b*frame_bstride + t*S*S  (so batch['frames'][:, :-1] needs no copy)
@@ -158,36 +159,48 @@ int vcad_profile_end(double ms[8], double flops[8], double bytes[8], int launche
  * 3 = six-stage ring GEMM, 4 = grouped GEMM; out = {ms, flops, bytes, launches} */
 int vcad_profile_kernel(int family, double out[4]);
 
-/* ---- test / ablation hooks.  These (and the profiler switch above) are the ONLY process-global state of the library; they
- * select between kernels that compute the same result and are never touched by the product path (the videocad_amd Python package).
- * force the GEMM block tile (64 or 128; 0 = automatic choice by problem size) */
-void vcad_debug_force_gemm_tile(int tile);
-/* -1 automatic, 0 never, 1 whenever legal: routes bf16 GEMMs through the persistent DMA-fed kernel (tests, bench A/B) */
-void vcad_debug_gemm_dma(int mode);
-long vcad_debug_gemm_dma_launches(void);
-/* 256 x 256 tile of the persistent kernel (plain epilogues): -1 automatic, 0 never, 1 whenever legal */
+/* ---- kernel-selection flags (0 = automatic).  The shipped library keeps NO process-global switches (the profiler scope above is the
+ * only process-wide state): a test that wants a small problem on the kernel the C2 shapes take passes these per call (vcad_op_gemm) or per
+ * engine (vcad_set_gemm_flags); every kernel they choose between computes the same result.  The product path never sets them. */
+#define VCAD_GEMM_TILE64 1u        /* register-staged kernel: 64 x 64 block tile */
+#define VCAD_GEMM_TILE128 2u       /* register-staged kernel: 128 x 128 block tile */
+#define VCAD_GEMM_DMA_NEVER 4u     /* persistent DMA-fed kernel: never / whenever legal */
+#define VCAD_GEMM_DMA_ALWAYS 8u
+#define VCAD_GEMM_WIDE_NEVER 16u   /* its 256 x 256 tile (plain epilogues): never / whenever legal */
+#define VCAD_GEMM_WIDE_ALWAYS 32u
+#define VCAD_GEMM_MID_NEVER 64u    /* six-stage DMA-ring kernel for mid-size problems: never / whenever legal */
+#define VCAD_GEMM_MID_ALWAYS 128u
+#define VCAD_GEMM_XCD_COLS(n) ((uint32_t)(n) << 8)   /* XCD column groups of the persistent kernel's forward launches: 0 automatic, 1 never, 2 / 4 / 8 forced */
+int vcad_set_gemm_flags(vcad_engine* e, uint32_t flags);
+/* launches so far per kernel family (1 = persistent DMA-fed GEMM, 2 = register-staged, 3 = six-stage ring, 4 = grouped) by this engine */
+int64_t vcad_kernel_launches(const vcad_engine* e, int family);
+/* 0: the CAD tower and the deferred weight gradients stay on the caller's stream instead of the engine's side stream (1 = default) */
+int vcad_set_side_stream(vcad_engine* e, int on);
+
+#ifdef VCAD_AB
+/* ---- A/B build only (`make -C videocad_amd/csrc ab` -> tools/_bin/libvcad_ab.so; csrc/ab.h): process-global selectors of the
+ * measurement scripts under tools/, including the slower kernel variants that are not compiled into libvcad_hip.so. */
+void vcad_debug_force_gemm_tile(int tile);   /* 64 / 128 / 0 */
+void vcad_debug_gemm_dma(int mode);          /* -1 automatic, 0 never, 1 whenever legal */
 void vcad_debug_gemm_wide(int mode);
-void vcad_debug_attn_variant(int v);      /* ViT attention backward: 0 = four waves per (frame, head) (default), 1 = r01 two-wave kernel */
-void vcad_debug_gemm_mid(int mode);        /* six-stage DMA-ring kernel for mid-size GEMMs: -1 automatic, 0 never, 1 whenever legal */
-long vcad_debug_gemm_mid_launches(void);
-void vcad_debug_gemm_waves(int n);         /* 256-wide tile of the persistent kernel: 8 waves (64 x 128 each) or 4 waves (128 x 128 each) */
-void vcad_debug_split_gelu(int on);        /* ViT MLP activation as its own pass behind a plain GEMM (1, default) or fused into the GEMM epilogue (0) */
-void vcad_debug_no_side_stream(int on);    /* A/B: keep the CAD ViT / deferred weight gradients on the caller's stream */
-void vcad_debug_gemm_policy(int bits);   /* A/B of dispatcher rules: 1 = activation epilogues on the persistent kernel, 2 = small-tile-count wgrads too */
-/* XCD column groups of the persistent kernel's forward-layout launches: -1 automatic, 0 never, 2 / 4 / 8 forced */
-void vcad_debug_gemm_xcd_cols(int xn);
-/* epilogue form of the persistent kernel's k-contiguous-B launches: -1 automatic, 0 row-per-lane (r01), 1 column-per-lane */
-void vcad_debug_gemm_epilogue(int mode);
-/* which persistent DMA-fed kernel: 0 = lockstep (default), 1 = ping-pong wave groups + line-coalesced epilogue (A/B experiment, slower) */
-void vcad_debug_gemm_variant(int v);
-/* ablation (tools/gemm_ablate*.py): start-offset of the first wave / bit mask of pipeline stages to skip; 0 = off */
-void vcad_debug_gemm_stagger(int n);
+void vcad_debug_gemm_mid(int mode);
+void vcad_debug_gemm_xcd_cols(int xn);       /* -1 automatic, 0 never, 2 / 4 / 8 forced */
+void vcad_debug_attn_variant(int v);         /* 0 = current attention kernels, 1 = r01 kernels */
+void vcad_debug_gemm_waves(int n);           /* 256-wide tile of the persistent kernel: 8 waves (64 x 128 each) or 4 waves (128 x 128 each) */
+void vcad_debug_split_gelu(int on);          /* ViT MLP activation as its own pass behind a plain GEMM (1, default) or fused into the GEMM epilogue (0) */
+void vcad_debug_no_side_stream(int on);
+void vcad_debug_gemm_policy(int bits);       /* dispatcher rules: 1 = activation epilogues on the persistent kernel, 2 = small-tile-count wgrads too */
+void vcad_debug_gemm_epilogue(int mode);     /* persistent kernel, k-contiguous B: -1 automatic, 0 row-per-lane (r01), 1 column-per-lane */
+void vcad_debug_gemm_variant(int v);         /* 0 = lockstep persistent kernel, 1 = ping-pong wave groups (slower) */
+void vcad_debug_gemm_stagger(int n);         /* ablation (tools/gemm_ablate*.py) */
 void vcad_debug_gemm_skip(int mask);
+#endif
 
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
-                 const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, void* stream);
+                 const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, uint32_t flags /* VCAD_GEMM_* */,
+                 int* kernel_out /* optional: kernel family that ran */, void* stream);
 /* MXFP8 (VCAD_FP8 mode): x [rows, cols] fp32 / bf16 (tx) -> q [rows, cols] OCP e4m3 bytes + scales [rows, cols/32] E8M0 bytes (one
  * power-of-two scale per 32 consecutive elements); C (type `to`) = act(A8 B8^T + bias) + residual on the block-scaled fp8 MFMA */
 int vcad_op_quant_mx8(int tx, const void* x, int64_t ldx, void* q, void* scales, int64_t rows, int cols, void* stream);

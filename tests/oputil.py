@@ -74,9 +74,13 @@ def relerr(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+GEMM_FLAGS = 0        # OR-ed into every check_gemm call (the tile-size fixtures of test_ops_*.py set it)
+
+
 def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0, bias=False, act=0, residual=False, seed=0,
-               pad=0, tol=None, splitk=True):
-    """C = act(opA @ opB^T + bias) + residual ; operands stored with `pad` extra leading-dimension elements."""
+               pad=0, tol=None, splitk=True, flags=0, kernel=None):
+    """C = act(opA @ opB^T + bias) + residual ; operands stored with `pad` extra leading-dimension elements.
+    flags: VCAD_GEMM_* kernel-selection flags of the call; kernel: the kernel family (lib.KERNEL_*) that must have run."""
     x3 = ct == X3
     st = torch.float32 if x3 else ct
     sa = st if sa is None else sa
@@ -99,9 +103,12 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
     res_t = rnd((M, N), device, seed=seed + 4) if residual else None
     Cbuf = torch.full((M, N + pad), 7.0, dtype=to, device=device)
     scratch = torch.empty(8 << 20, dtype=torch.float32, device=device) if splitk else None
+    tag = C.c_int(0)
     rc = lib.vcad_op_gemm(TD[ct], TD[sa], TD[sb], TD[to], tra, trb, ptr(A), ptr(Bm), ptr(Cbuf), M, N, K, lda, ldb, N + pad,
-                          ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, stream_of(device))
+                          ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, flags | GEMM_FLAGS, C.byref(tag), stream_of(device))
     L.check(lib, rc, "gemm")
+    if kernel is not None:
+        assert tag.value == kernel, f"gemm M{M} N{N} K{K} tra={tra} trb={trb} flags={flags}: ran on kernel family {tag.value}, expected {kernel}"
     ref = A_q.double() @ B_q.double().t()
     if bias:
         ref = ref + bias_t.double().cpu()

@@ -25,7 +25,13 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"gfx950" in lib.vcad_version()
     hdr = open(os.path.join(HERE, "..", "include", "vcad.h")).read()
     import re
-    declared = set(re.findall(r"\b(vcad_[a-z0-9_]+)\s*\(", hdr))
+    product, ab = re.split(r"#ifdef VCAD_AB\n", hdr)[0], re.findall(r"#ifdef VCAD_AB\n(.*?)#endif", hdr, re.S)
+    product += re.split(r"#ifdef VCAD_AB\n.*?#endif", hdr, flags=re.S)[1]
+    declared = set(re.findall(r"\b(vcad_[a-z0-9_]+)\s*\(", product))
+    # the A/B-only selectors (csrc/ab.h) are declared under VCAD_AB and must NOT be in the shipped library; nor any process-global switch
+    ab_names = set(re.findall(r"\b(vcad_debug_[a-z0-9_]+)\s*\(", ab[0]))
+    assert ab_names == set(L.AB_PROTOTYPES) and not any(n.startswith("vcad_debug") for n in declared)
+    assert not any(hasattr(lib, n) for n in ab_names), [n for n in ab_names if hasattr(lib, n)]
     assert declared and all(hasattr(lib, n) for n in declared), [n for n in declared if not hasattr(lib, n)]
     assert declared <= set(L.PROTOTYPES) | {"vcad_config", "vcad_engine"}, declared - set(L.PROTOTYPES)
 

@@ -153,7 +153,7 @@ def test_engine_fp8_forward_mode(emu):
 
 
 def engine_masks(eng, cfg, B, T):
-    """Rebuild every dropout keep-multiplier tensor the engine uses (vcad_debug_dropout_mask) in the oracle's tensor shapes.
+    """Rebuild every dropout keep-multiplier tensor the engine uses (vcad_dropout_mask) in the oracle's tensor shapes.
     The last ViT layer computes the cls row only, so its site masks are indexed per frame: cls rows get them, the unused
     rows get 1."""
     M, P1, D, Hh = B * T, 50, cfg["vit_dim"], cfg["vit_heads"]

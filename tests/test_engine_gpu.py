@@ -19,8 +19,14 @@ CFG_KEYS = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "wi
             "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size")
 
 
+ENGINE_GEMM_FLAGS = 0     # set by the gemm_dma_mode fixture; every engine build() makes carries it
+ENGINES = []
+
+
 def build(dtype, cfg=O.CANONICAL_CONFIG):
     eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in CFG_KEYS}), DEV)
+    eng.set_gemm_flags(ENGINE_GEMM_FLAGS)
+    ENGINES.append(eng)
     shapes = O.param_shapes(cfg)
     assert set(eng.table) == set(shapes)
     for k, s in shapes.items():
@@ -168,12 +174,13 @@ def test_f32_window1_forward(golden_dir):
 def gemm_dma_mode(request):
     """bf16 tests run twice: automatic kernel choice (these small batches stay on the register-staged GEMM) and with every
     legal bf16 GEMM forced through the persistent DMA-fed kernel (the one the C2 bench shapes take)."""
-    lib = L.load()
-    lib.vcad_debug_gemm_dma(request.param)
-    n0 = lib.vcad_debug_gemm_dma_launches()
-    used = lambda: lib.vcad_debug_gemm_dma_launches() - n0
+    global ENGINE_GEMM_FLAGS
+    ENGINE_GEMM_FLAGS = L.GEMM_DMA_ALWAYS if request.param == 1 else 0
+    del ENGINES[:]
+    used = lambda: sum(e.kernel_launches(L.KERNEL_GEMM_DMA) for e in ENGINES)
     yield request.param, used
-    lib.vcad_debug_gemm_dma(-1)
+    ENGINE_GEMM_FLAGS = 0
+    del ENGINES[:]
 
 
 def test_bf16_step_close_to_goldens(golden_dir, gemm_dma_mode):
@@ -287,7 +294,7 @@ def _masks_for(eng, B, T):
                                                           (L.VCAD_BF16, 3e-2, 6e-2, 1, 70)],
                          ids=["f32-T4", "bf16-T4", "bf16-T70-long-decoder-attention"])
 def test_train_mode_dropout_matches_oracle_with_same_masks(dtype, tol_logit, tol_grad, B, T, gemm_dma_mode):
-    """Canonical model, p = 0.1 at every site: the engine's masks are exported (vcad_debug_dropout_mask) and applied by the
+    """Canonical model, p = 0.1 at every site: the engine's masks are exported (vcad_dropout_mask) and applied by the
     oracle as explicit multipliers.  fp32 mode must agree tightly; bf16 mode (MFMA attention path with in-register masks)
     within bf16 tolerance."""
     if dtype == L.VCAD_F32 and gemm_dma_mode[0] == 1:

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 import oputil as U
+from videocad_amd import lib as L
 
 F32, BF16 = torch.float32, torch.bfloat16
 
@@ -17,9 +18,9 @@ def emu():
 @pytest.fixture(params=[64, 128], autouse=True)
 def gemm_tile(request, emu):
     """every test in this file runs with both GEMM block tiles (64x64 and 128x128)"""
-    emu.vcad_debug_force_gemm_tile(request.param)
+    U.GEMM_FLAGS = L.GEMM_TILE64 if request.param == 64 else L.GEMM_TILE128
     yield request.param
-    emu.vcad_debug_force_gemm_tile(0)
+    U.GEMM_FLAGS = 0
 
 
 @pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
@@ -70,52 +71,33 @@ def test_gemm_dma_kernel(emu, gemm_tile, tra, trb, to):
     """the persistent DMA-fed kernel (gemm_dma.h): M tail, several tiles per workgroup stream, fused epilogue, k-slices"""
     if gemm_tile != 128:
         pytest.skip("tile-size fixture does not apply to the DMA kernel")
-    emu.vcad_debug_gemm_dma(1)
-    n0 = emu.vcad_debug_gemm_dma_launches()
-    try:
-        M = 264 if tra else 300                       # row-contiguous A needs M % 8 == 0; 300 leaves a ragged last tile
-        U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, act=(0 if tra else 1),
-                     residual=(to == F32), splitk=bool(tra))
-        assert emu.vcad_debug_gemm_dma_launches() == n0 + 1, "the GEMM did not take the DMA kernel"
-        # the same problems without the activation: the ping-pong kernel (gemm_pp.h) — and, switched back, the lockstep one
-        for variant in (1, 0):
-            emu.vcad_debug_gemm_variant(variant)
-            U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, residual=(to == F32), splitk=bool(tra))
-            U.check_gemm(emu, "cpu", M, 128, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
-        assert emu.vcad_debug_gemm_dma_launches() == n0 + 5
-        emu.vcad_debug_gemm_variant(0)
-        if not tra and not trb:      # XCD column groups: 4 tile columns over 4 / 2 XCD columns, 9 tile rows over 2 / 4 XCD rows
-            for xn in (4, 2):
-                emu.vcad_debug_gemm_xcd_cols(xn)
-                U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, residual=(to == F32), splitk=False)
-            emu.vcad_debug_gemm_xcd_cols(-1)
-    finally:
-        emu.vcad_debug_gemm_dma(-1)
+    dma = dict(flags=L.GEMM_DMA_ALWAYS, kernel=L.KERNEL_GEMM_DMA)
+    M = 264 if tra else 300                       # row-contiguous A needs M % 8 == 0; 300 leaves a ragged last tile
+    U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, act=(0 if tra else 1),
+                 residual=(to == F32), splitk=bool(tra), **dma)
+    U.check_gemm(emu, "cpu", M, 256, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=True, residual=(to == F32), splitk=bool(tra), **dma)
+    U.check_gemm(emu, "cpu", M, 128, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False, **dma)      # one k-tile per item
+    if not tra and not trb:      # XCD column groups: 4 tile columns over 4 / 2 XCD columns, 9 tile rows over 2 / 4 XCD rows
+        for xn in (4, 2):
+            U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, residual=(to == F32), splitk=False,
+                         flags=L.GEMM_DMA_ALWAYS | L.gemm_xcd_cols(xn), kernel=L.KERNEL_GEMM_DMA)
 
 
-@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("tra,trb,to", [(0, 0, BF16), (0, 0, F32), (1, 1, F32)])
-def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to, waves):
-    """the 256 x 256 tile of the persistent kernel (two 64 KiB stages): eight waves of 64 x 128 or four waves of 128 x 128; plain
-    epilogues — bias, k-slice slabs"""
+def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
+    """the 256 x 256 tile of the persistent kernel (two 64 KiB stages, eight waves of 64 x 128): plain epilogues — bias, k-slice slabs"""
     if gemm_tile != 128:
         pytest.skip("tile-size fixture does not apply to the DMA kernel")
-    emu.vcad_debug_gemm_dma(1); emu.vcad_debug_gemm_wide(1); emu.vcad_debug_gemm_waves(waves)
-    n0 = emu.vcad_debug_gemm_dma_launches()
-    try:
-        M = 520 if tra else 600                       # three rows of items, ragged last one
-        U.check_gemm(emu, "cpu", M, 512, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=not tra, splitk=bool(tra))
-        U.check_gemm(emu, "cpu", 264, 256, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False)      # one k-tile per item
-        assert emu.vcad_debug_gemm_dma_launches() == n0 + 2, "the GEMM did not take the DMA kernel"
-        if not tra:      # fused epilogue without side inputs (bias + GELU: the MLP's first Linear) — eight-wave column-per-lane form
-            U.check_gemm(emu, "cpu", 600, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, act=1, splitk=False)
-            assert emu.vcad_debug_gemm_dma_launches() == n0 + 3
-        if not tra:      # XCD column groups (forward layout): 2 x 4 and 4 x 2 XCD grids over 3 tile rows x 2 tile columns
-            for xn in (2, 1):
-                emu.vcad_debug_gemm_xcd_cols(xn if xn > 1 else -1)
-                U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, splitk=False)
-    finally:
-        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_wide(-1); emu.vcad_debug_gemm_xcd_cols(-1); emu.vcad_debug_gemm_waves(8)
+    wide = dict(flags=L.GEMM_DMA_ALWAYS | L.GEMM_WIDE_ALWAYS, kernel=L.KERNEL_GEMM_DMA)
+    M = 520 if tra else 600                       # three rows of items, ragged last one
+    U.check_gemm(emu, "cpu", M, 512, 192, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=not tra, splitk=bool(tra), **wide)
+    U.check_gemm(emu, "cpu", 264, 256, 64, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=0, splitk=False, **wide)      # one k-tile per item
+    if not tra:      # fused epilogue without side inputs (bias + GELU: the MLP's first Linear) — column-per-lane form
+        U.check_gemm(emu, "cpu", 600, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, act=1, splitk=False, **wide)
+        # XCD column groups (forward layout): 2 x 4 XCD grid / automatic over 3 tile rows x 2 tile columns
+        for xn in (2, 0):
+            U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, splitk=False,
+                         flags=wide["flags"] | L.gemm_xcd_cols(xn), kernel=L.KERNEL_GEMM_DMA)
 
 
 @pytest.mark.parametrize("trb,to", [(0, BF16), (0, F32), (1, BF16), (1, F32)])
@@ -124,15 +106,9 @@ def test_gemm_mid_kernel(emu, gemm_tile, trb, to):
     fused bias + ReLU / residual epilogues, padded leading dimensions"""
     if gemm_tile != 128:
         pytest.skip("tile-size fixture does not apply to the DMA-ring kernel")
-    emu.vcad_debug_gemm_dma(0); emu.vcad_debug_gemm_mid(1)
-    n0 = emu.vcad_debug_gemm_mid_launches()
-    try:
-        for K in (64, 192, 384, 640):                 # 1, 3, 6 (= stages) and 10 k-tiles
-            U.check_gemm(emu, "cpu", 300, 256, K, BF16, sa=BF16, sb=BF16, to=to, trb=trb, pad=8, bias=True, act=(2 if to == BF16 else 0),
-                         residual=(to == F32), splitk=False)
-        assert emu.vcad_debug_gemm_mid_launches() == n0 + 4, "the GEMM did not take the DMA-ring kernel"
-    finally:
-        emu.vcad_debug_gemm_dma(-1); emu.vcad_debug_gemm_mid(-1)
+    for K in (64, 192, 384, 640):                 # 1, 3, 6 (= stages) and 10 k-tiles
+        U.check_gemm(emu, "cpu", 300, 256, K, BF16, sa=BF16, sb=BF16, to=to, trb=trb, pad=8, bias=True, act=(2 if to == BF16 else 0),
+                     residual=(to == F32), splitk=False, flags=L.GEMM_DMA_NEVER | L.GEMM_MID_ALWAYS, kernel=L.KERNEL_GEMM_MID)
 
 
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16)])

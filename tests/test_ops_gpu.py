@@ -18,9 +18,9 @@ def hip():
 @pytest.fixture(params=[64, 128], autouse=True)
 def gemm_tile(request, hip):
     """every test in this file runs with both GEMM block tiles (64x64 and 128x128)"""
-    hip.vcad_debug_force_gemm_tile(request.param)
+    U.GEMM_FLAGS = L.GEMM_TILE64 if request.param == 64 else L.GEMM_TILE128
     yield request.param
-    hip.vcad_debug_force_gemm_tile(0)
+    U.GEMM_FLAGS = 0
 
 
 @pytest.mark.parametrize("tra,trb", [(0, 0), (0, 1), (1, 1), (1, 0)])
@@ -74,71 +74,52 @@ def test_gemm_dma_kernel(hip):
     """the persistent DMA-fed kernel (forced: the automatic choice keeps some of these shapes on the register-staged kernel) at
     sizes where every workgroup streams several tiles — ragged M tail, k-slices with a short last slice, fused bias / GELU /
     residual — three times each: a mis-counted vmcnt shows up as sporadic wrong tiles"""
-    n0 = hip.vcad_debug_gemm_dma_launches()
-    hip.vcad_debug_gemm_dma(1)
-    try:
-        for rep in range(3):
-            U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1, seed=rep)
-            U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True, seed=rep)
-            U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, trb=1, seed=rep)
-            U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep)
-            U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep)
-        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8)      # small problems, same kernel
-        U.check_gemm(hip, DEV, 264, 128, 64, BF16, to=F32, tra=1, trb=1, pad=8)
-    finally:
-        hip.vcad_debug_gemm_dma(-1)
-    assert hip.vcad_debug_gemm_dma_launches() == n0 + 17, "a GEMM did not take the DMA kernel"
-    U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True)              # automatic choice: DMA kernel
-    assert hip.vcad_debug_gemm_dma_launches() == n0 + 18
+    dma = dict(flags=L.GEMM_DMA_ALWAYS, kernel=L.KERNEL_GEMM_DMA)
+    for rep in range(3):
+        U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1, seed=rep, **dma)
+        U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True, seed=rep, **dma)
+        U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, trb=1, seed=rep, **dma)
+        U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep, **dma)
+        U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep, **dma)
+    U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8, **dma)      # small problems, same kernel
+    U.check_gemm(hip, DEV, 264, 128, 64, BF16, to=F32, tra=1, trb=1, pad=8, **dma)
+    U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True, kernel=L.KERNEL_GEMM_DMA)   # automatic choice: DMA kernel
 
 
 def test_gemm_mid_kernel(hip):
     """six-stage DMA-ring kernel (gemm_mid.h) at the decoder's shapes: forward (k-contiguous W) and dgrad (row-contiguous W) layouts, fused
     epilogues, ragged M (B=16, T=186 -> 2976 rows), three times each (a mis-counted vmcnt shows up as sporadic wrong tiles); and the
     automatic choice takes it for a 2048 x 1024 x 1024 Linear"""
-    n0 = hip.vcad_debug_gemm_mid_launches()
-    hip.vcad_debug_gemm_mid(1); hip.vcad_debug_gemm_dma(0)
-    try:
-        for rep in range(3):
-            U.check_gemm(hip, DEV, 2048, 1024, 1024, BF16, to=F32, bias=True, residual=True, seed=rep)
-            U.check_gemm(hip, DEV, 2976, 3072, 1024, BF16, to=BF16, bias=True, seed=rep)
-            U.check_gemm(hip, DEV, 2976, 1024, 1024, BF16, to=BF16, bias=True, act=2, seed=rep)
-            U.check_gemm(hip, DEV, 2048, 1024, 3072, BF16, to=F32, trb=1, residual=True, seed=rep)
-            U.check_gemm(hip, DEV, 2976, 1024, 2048, BF16, to=BF16, trb=1, seed=rep)
-        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8)
-        U.check_gemm(hip, DEV, 300, 256, 64, BF16, to=BF16, trb=1, pad=8)
-    finally:
-        hip.vcad_debug_gemm_mid(-1); hip.vcad_debug_gemm_dma(-1)
-    assert hip.vcad_debug_gemm_mid_launches() == n0 + 17, "a GEMM did not take the DMA-ring kernel"
-    U.check_gemm(hip, DEV, 2048, 1024, 1024, BF16, to=F32, bias=True, residual=True)
-    assert hip.vcad_debug_gemm_mid_launches() == n0 + 18
+    mid = dict(flags=L.GEMM_DMA_NEVER | L.GEMM_MID_ALWAYS, kernel=L.KERNEL_GEMM_MID)
+    for rep in range(3):
+        U.check_gemm(hip, DEV, 2048, 1024, 1024, BF16, to=F32, bias=True, residual=True, seed=rep, **mid)
+        U.check_gemm(hip, DEV, 2976, 3072, 1024, BF16, to=BF16, bias=True, seed=rep, **mid)
+        U.check_gemm(hip, DEV, 2976, 1024, 1024, BF16, to=BF16, bias=True, act=2, seed=rep, **mid)
+        U.check_gemm(hip, DEV, 2048, 1024, 3072, BF16, to=F32, trb=1, residual=True, seed=rep, **mid)
+        U.check_gemm(hip, DEV, 2976, 1024, 2048, BF16, to=BF16, trb=1, seed=rep, **mid)
+    U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, residual=True, pad=8, **mid)
+    U.check_gemm(hip, DEV, 300, 256, 64, BF16, to=BF16, trb=1, pad=8, **mid)
+    U.check_gemm(hip, DEV, 2048, 1024, 1024, BF16, to=F32, bias=True, residual=True, kernel=L.KERNEL_GEMM_MID)   # automatic choice
 
 
-@pytest.mark.parametrize("waves", [8, 4])
-def test_gemm_dma_kernel_wide_tile(hip, waves):
+
+def test_gemm_dma_kernel_wide_tile(hip):
     """256 x 256 tile (automatic for the plain big GEMMs): QKV-forward-, dgrad-through-W^T- and wgrad-like problems, three times each
     (a mis-counted vmcnt of the two-stage ring shows up as sporadic wrong tiles), ragged M tail, short last k-slice"""
-    n0 = hip.vcad_debug_gemm_dma_launches()
-    hip.vcad_debug_gemm_dma(1); hip.vcad_debug_gemm_wide(1); hip.vcad_debug_gemm_waves(waves)
-    try:
-        for rep in range(3):
-            U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=rep)
-            U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, seed=rep)
-            U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, seed=rep)
-            U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep)
-            U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep)
-        U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, pad=8)
-        U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1)      # fused bias + GELU on the 256-wide tile (MLP-1 forward)
-        for xn in (2, 4, 8):                                             # XCD column groups, both tile widths
-            hip.vcad_debug_gemm_xcd_cols(xn)
-            U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=xn)
-            hip.vcad_debug_gemm_wide(0)
-            U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=xn)
-            U.check_gemm(hip, DEV, 20040, 1024, 512, BF16, to=F32, bias=True, residual=True, seed=xn)
-            hip.vcad_debug_gemm_wide(1)
-    finally:
-        hip.vcad_debug_gemm_dma(-1); hip.vcad_debug_gemm_wide(-1); hip.vcad_debug_gemm_xcd_cols(-1); hip.vcad_debug_gemm_waves(8)
-    assert hip.vcad_debug_gemm_dma_launches() == n0 + 26, "a GEMM did not take the DMA kernel"
+    wide = dict(flags=L.GEMM_DMA_ALWAYS | L.GEMM_WIDE_ALWAYS, kernel=L.KERNEL_GEMM_DMA)
+    for rep in range(3):
+        U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=rep, **wide)
+        U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, seed=rep, **wide)
+        U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, seed=rep, **wide)
+        U.check_gemm(hip, DEV, 3072, 512, 20032, BF16, to=F32, tra=1, trb=1, seed=rep, **wide)
+        U.check_gemm(hip, DEV, 512, 512, 40000 - 64, BF16, to=F32, tra=1, trb=1, seed=rep, **wide)
+    U.check_gemm(hip, DEV, 300, 256, 192, BF16, to=F32, bias=True, pad=8, **wide)
+    U.check_gemm(hip, DEV, 20040, 512, 512, BF16, to=BF16, bias=True, act=1, **wide)      # fused bias + GELU on the 256-wide tile (MLP-1 forward)
+    for xn in (2, 4, 8):                                             # XCD column groups, both tile widths
+        narrow = L.GEMM_DMA_ALWAYS | L.GEMM_WIDE_NEVER | L.gemm_xcd_cols(xn)
+        U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=xn, flags=wide["flags"] | L.gemm_xcd_cols(xn), kernel=L.KERNEL_GEMM_DMA)
+        U.check_gemm(hip, DEV, 20040, 3072, 512, BF16, to=BF16, bias=True, seed=xn, flags=narrow, kernel=L.KERNEL_GEMM_DMA)
+        U.check_gemm(hip, DEV, 20040, 1024, 512, BF16, to=F32, bias=True, residual=True, seed=xn, flags=narrow, kernel=L.KERNEL_GEMM_DMA)
 
 
 @pytest.mark.parametrize("C_,dt", [(512, F32), (1024, F32), (512, BF16), (1024, BF16)])

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
 
-lib = L.load()
+lib = L.load_ab()
 dev = "cuda:0"
 B, H, T, D = 2048, 16, 50, 64
 if len(sys.argv) > 1:

@@ -3,12 +3,12 @@ by construction; timing only).  python tools/gemm_ablate.py"""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
-lib = L.load(); lib.vcad_debug_gemm_skip.argtypes = [C.c_int]
+lib = L.load_ab()
 dev = "cuda:0"; BF = torch.bfloat16
 def run(M, N, K, iters=10):
     A = torch.randn(M, K, device=dev).to(BF); B = torch.randn(N, K, device=dev).to(BF); Cm = torch.empty(M, N, dtype=BF, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr()); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    call = lambda: lib.vcad_op_gemm(1, 1, 1, 1, 0, 0, p(A), p(B), p(Cm), M, N, K, K, K, N, None, 0, None, N, 1.0, None, 0, st)
+    call = lambda: lib.vcad_op_gemm(1, 1, 1, 1, 0, 0, p(A), p(B), p(Cm), M, N, K, K, K, N, None, 0, None, N, 1.0, None, 0, 0, None, st)
     for _ in range(3): call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
-lib = L.load(); dev = "cuda:0"
+lib = L.load_ab(); dev = "cuda:0"
 BF, F32 = torch.bfloat16, torch.float32
 TD = {F32: 0, BF: 1}
 scratch = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
@@ -20,7 +20,7 @@ def run(name, M, N, K, to=BF, tra=0, trb=0, bias=False, iters=10, masks=(0, 32, 
     for mask in masks:
         lib.vcad_debug_gemm_skip(mask)
         def call():
-            rc = lib.vcad_op_gemm(1, 1, 1, TD[to], tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0, None, N, 1.0, p(scratch), scratch.numel(), st)
+            rc = lib.vcad_op_gemm(1, 1, 1, TD[to], tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0, None, N, 1.0, p(scratch), scratch.numel(), 0, None, st)
             assert rc == 0
         for _ in range(2): call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

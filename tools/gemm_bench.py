@@ -10,7 +10,7 @@ from videocad_amd import lib as L
 
 if os.environ.get("VCAD_ABL"):      # ablated build (tools/gemm_ablate.sh): timing only, results are garbage
     L._lib = L.declare(C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", f"libvcad_abl{os.environ['VCAD_ABL']}.so")))
-lib = L.load()
+lib = L.load_ab()
 dev = "cuda:0"
 BF, F32 = torch.bfloat16, torch.float32
 TD = {F32: 0, BF: 1}
@@ -28,7 +28,7 @@ def run(name, M, N, K, sa=BF, sb=BF, to=BF, tra=0, trb=0, bias=False, res=False,
 
     def call():
         rc = lib.vcad_op_gemm(1, TD[sa], TD[sb], TD[to], tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0,
-                              p(res_t), N, 1.0, p(scratch), scratch.numel(), st)
+                              p(res_t), N, 1.0, p(scratch), scratch.numel(), 0, None, st)
         assert rc == 0, lib.vcad_last_error()
     for _ in range(3):
         call()

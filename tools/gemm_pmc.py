@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
 
-lib = L.load()
+lib = L.load_ab()
 dev = "cuda:0"
 BF, F32 = torch.bfloat16, torch.float32
 TD = {F32: 0, BF: 1}
@@ -27,7 +27,7 @@ def run(M, N, K, to=BF, tra=0, trb=0, bias=False, iters=3):
         lib.vcad_debug_gemm_dma(mode)
         for _ in range(iters):
             rc = lib.vcad_op_gemm(1, 1, 1, TD[to], tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0,
-                                  None, N, 1.0, p(scratch), scratch.numel(), st)
+                                  None, N, 1.0, p(scratch), scratch.numel(), 0, None, st)
             assert rc == 0, lib.vcad_last_error()
         torch.cuda.synchronize()
 

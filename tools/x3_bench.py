@@ -39,7 +39,7 @@ def gemm(name, M, N, K, ct=2, tra=0, trb=0, bias=False, res=False):
 
     def call():
         rc = lib.vcad_op_gemm(ct, 0, 0, 0, tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0, p(res_t), N, 1.0,
-                              p(scratch), scratch.numel(), st)
+                              p(scratch), scratch.numel(), 0, None, st)
         assert rc == 0, lib.vcad_last_error()
     ms = timeit(call)
     print(f"{name:28s} ct={'x3' if ct == 2 else 'f32'} M={M:6d} N={N:5d} K={K:6d} tra={tra} trb={trb} {ms*1e3:8.1f} us  {2.0*M*N*K/(ms*1e-3)/1e12:7.1f} TF/s", flush=True)

@@ -12,7 +12,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def gemm(M, N, K, tra=0, trb=0, iters=2):
     A = torch.randn((K, M) if tra else (M, K), device=dev); B = torch.randn((K, N) if trb else (N, K), device=dev); Cm = torch.empty(M, N, device=dev)
     for _ in range(iters):
-        assert lib.vcad_op_gemm(2, 0, 0, 0, tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, None, 0, None, N, 1.0, p(scratch), scratch.numel(), st) == 0
+        assert lib.vcad_op_gemm(2, 0, 0, 0, tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, None, 0, None, N, 1.0, p(scratch), scratch.numel(), 0, None, st) == 0
     torch.cuda.synchronize()
 
 

@@ -225,13 +225,13 @@ def run(args):
     B, T = args.batch, args.seq
     model, tr = build_trainer(args.dtype, args.dropout, device, rank)
     eng = model._engine
-    eng.lib.vcad_debug_gemm_dma(getattr(args, "gemm_dma", -1))
-    eng.lib.vcad_debug_gemm_wide(getattr(args, "gemm_wide", -1))
-    eng.lib.vcad_debug_gemm_policy(getattr(args, "gemm_policy", 0))
-    eng.lib.vcad_debug_attn_variant(getattr(args, "attn_variant", 0))
-    eng.lib.vcad_debug_gemm_mid(getattr(args, "gemm_mid", -1))
-    eng.lib.vcad_debug_split_gelu(getattr(args, "split_gelu", 1))
-    eng.lib.vcad_debug_no_side_stream(getattr(args, "no_side", 0))
+    # A/B switches expressible as per-engine kernel-selection flags (the product default is 0 = automatic); the process-global
+    # selectors of the A/B build are set by tools/bench_ab.py before it calls launch()
+    sel = lambda v, never, always: never if v == 0 else (always if v == 1 else 0)
+    eng.set_gemm_flags(sel(getattr(args, "gemm_dma", -1), L.GEMM_DMA_NEVER, L.GEMM_DMA_ALWAYS) | sel(getattr(args, "gemm_wide", -1), L.GEMM_WIDE_NEVER, L.GEMM_WIDE_ALWAYS)
+                       | sel(getattr(args, "gemm_mid", -1), L.GEMM_MID_NEVER, L.GEMM_MID_ALWAYS))
+    if getattr(args, "no_side", 0):
+        eng.set_side_stream(False)
     if getattr(args, "fp8", False):
         eng.set_fp8(True)            # VCAD_FP8 forward mode: ViT Linears on the block-scaled fp8 matrix cores (BASELINE configs[4] variant)
     bd = synthetic_batch(B, T, 1000 * 2 + rank, device, uint8=args.uint8_frames)

@@ -9,8 +9,9 @@ extern "C" {
 
 int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A, const void* B, void* C,
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
-                 const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, void* stream) {
+                 const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, uint32_t flags, int* kernel_out, void* stream) {
     GemmCall c; memset(&c, 0, sizeof(c));
+    c.flags = flags; c.kernel_out = kernel_out;
     c.ct = ct; c.sa = sa; c.sb = sb; c.to = to; c.tra = tra; c.trb = trb;
     c.p.A = A; c.p.B = B; c.p.C = C; c.p.M = M; c.p.N = N; c.p.K = K; c.p.lda = lda; c.p.ldb = ldb; c.p.ldc = ldc;
     c.p.bias = bias; c.p.act = act; c.p.residual = residual; c.p.ldr = ldr; c.p.alpha = alpha; c.p.rowadd_div = 1;

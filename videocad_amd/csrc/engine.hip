@@ -86,6 +86,8 @@ struct vcad_engine {
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
     float drop_p = 0.f; uint64_t drop_seed = 0;
+    // kernel-selection flags of this engine's GEMMs (VC_GF_*; tests put small batches on the kernels the C2 shapes take) and launches per kernel family
+    unsigned gemm_flags = 0; long kernel_launches[VC_NTAG] = {0, 0, 0, 0, 0};
     // bf16 mode: transposed copies W^T[in][out] of the frame ViT's Linear weights, so every big dgrad is a k-contiguous
     // (ds_read_b128) GEMM instead of a ds_read_b64_tr_b16 one (measured: dqkv dgrad 569 -> 462 us); refreshed lazily after
     // every weight change (optimizer step / shadow sync / re-plan)
@@ -285,11 +287,9 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 // ---------------------------------------------------------------------------------------------------------------
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------
-// the ViT MLP's GELU / GELU' as their own passes behind plain GEMMs (bf16 mode): 1 = yes (default), 0 = fused into the GEMM epilogues (r01; A/B)
-static int g_split_gelu = 1;
-extern "C" void vcad_debug_split_gelu(int on) { g_split_gelu = on ? 1 : 0; }
-static int g_no_side = 0;           // A/B: 1 = the CAD ViT and the deferred weight gradients stay on the caller's stream
-extern "C" void vcad_debug_no_side_stream(int on) { g_no_side = on ? 1 : 0; }
+// the ViT MLP's GELU / GELU' as their own passes behind plain GEMMs (bf16 mode): 1 = yes, 0 = fused into the GEMM epilogues (r01; A/B build only)
+#define g_split_gelu VC_AB(split_gelu, 1)
+#define g_no_side VC_AB(no_side, 0)
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CK_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -336,7 +336,10 @@ struct Ctx {
         p.alpha = 1.0f; p.bias = ep.bias; p.act = ep.act; p.residual = ep.residual; p.ldr = ep.ldr;
         p.rowadd = ep.rowadd; p.rowadd_div = ep.rdiv; p.rowadd_mod = ep.rmod; p.ld_rowadd = ep.ldrow;
         p.aux = ep.aux; p.ldaux = ep.ldaux; p.dact_src = ep.dact; p.lddact = ep.lddact; p.dact_kind = ep.dkind; p.drop = ep.drop;
-        return vc_gemm(c, L().scr_splitk, L().scr_splitk_bytes, s);
+        int tag = VC_TAG_NONE; c.flags = e->gemm_flags; c.kernel_out = &tag;
+        const int rc = vc_gemm(c, L().scr_splitk, L().scr_splitk_bytes, s);
+        if (!rc) ++e->kernel_launches[tag];
+        return rc;
     }
     // Y[M,N] = X[M,K] W[N,K]^T (+ epilogue)
     int lin_fwd(Mat X, Mat Wm, Mat Y, int M, int N, int K, const Epi& ep) const { return gemm(X, 0, Wm, 0, Y, M, N, K, ep); }
@@ -876,13 +879,17 @@ int vcad_set_fp8(vcad_engine* e, int on) {
     e->fp8 = on != 0; e->planned_ws = nullptr; e->B = e->T = 0; e->fwd_valid = false; e->infer_T = 0;
     return 0;
 }
+// kernel-selection flags of this engine's Linear layers (VCAD_GEMM_* in vcad.h; 0 = automatic) and launch counts per kernel family
+int vcad_set_gemm_flags(vcad_engine* e, uint32_t flags) { e->gemm_flags = flags; return 0; }
+int64_t vcad_kernel_launches(const vcad_engine* e, int family) { return (family >= 0 && family < VC_NTAG) ? e->kernel_launches[family] : -1; }
+int vcad_set_side_stream(vcad_engine* e, int on) { e->no_side = !on; return 0; }
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed) {
     if (!(p >= 0.f && p < 1.f)) { vc_set_error("vcad_set_dropout: p must be in [0, 1)"); return VC_ERR_ARG; }
     e->drop_p = p; e->drop_seed = seed;
     return 0;
 }
 // debug / test hook: the keep-multipliers (0 or 1/(1-p)) a site applies to elements 0..n-1, written to a HOST buffer
-int vcad_debug_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out) {
+int vcad_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out) {
     Ctx cx{const_cast<vcad_engine*>(e), nullptr};
     const vc_drop d = cx.site(module, layer, kind);
     for (int64_t i = 0; i < n; ++i) host_out[i] = d.key ? vc_drop_mul(d, (uint32_t)i) : 1.0f;

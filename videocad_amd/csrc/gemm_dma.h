@@ -261,7 +261,6 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 
     vc_f32x16 acc[MI][NJ];
     int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
-    const int dbg = p.debug_skip;
 
     // One k-tile: retire stage `slot`, re-arm the slot freed by the previous k-tile, feed the matrix cores.
     // Every instruction here is paid 300+ times per launch by every wave (a wave issues one instruction per ~4 cycles, a
@@ -373,7 +372,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             }
             ktile_prefetch();
             ktile_mfma();
-            if (dbg & 64) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
+            if (VC_ABL(64)) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
             float bv[NJ];
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn) bv[jn] = 0.0f;
@@ -431,7 +430,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                         }
                     }
                 }
-            if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = NS_ITEM;
+            if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
             continue;
         }
         // ---------------------------------------------------------------- row-per-lane form (tr-read B layouts), as in r01
@@ -476,7 +475,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         ktile_mfma();
 
         // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3
-        if (dbg & 64) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
+        if (VC_ABL(64)) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = tm * GD_BM + wm * WR + i * 32 + (lane & 31);
@@ -501,7 +500,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                     }
             }
         }
-        if ((tm + 1) * GD_BM <= p.M && !(dbg & 32)) young_cur = NS_ITEM;
+        if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
     }
     vc_wait_vmcnt<0>();            // no DMA may still be writing this workgroup's LDS when it is handed to the next one
 }

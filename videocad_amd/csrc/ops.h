@@ -6,6 +6,7 @@
 #include "attn.h"
 #include "loss.h"
 #include "optim.h"
+#include "ab.h"
 
 enum { VC_F32 = 0, VC_BF16 = 1, VC_X3 = 2 /* GEMM compute type only: bf16x3 on fp32 tensors (gemm.h) */ };
 enum { VC_OK = 0, VC_ERR_ARG = 1, VC_ERR_UNSUPPORTED = 2, VC_ERR_LAUNCH = 3, VC_ERR_WORKSPACE = 4 };
@@ -26,11 +27,17 @@ struct ProfScope {
 };
 const char* vc_get_error();
 
+// per-call kernel-selection flags (0 = automatic): how the tests put small problems on the tile size / kernel family the big shapes take.
+// Plain arguments — the library has no process-global switches.
+enum { VC_GF_TILE64 = 1, VC_GF_TILE128 = 2, VC_GF_DMA_NEVER = 4, VC_GF_DMA_ALWAYS = 8, VC_GF_WIDE_NEVER = 16, VC_GF_WIDE_ALWAYS = 32,
+       VC_GF_MID_NEVER = 64, VC_GF_MID_ALWAYS = 128, VC_GF_XCD_COLS_SHIFT = 8 /* bits 8-11, XCD column groups of the persistent kernel: 0 automatic, 1 never, 2 / 4 / 8 forced */ };
 struct GemmCall {
     int ct, sa, sb, to;         // compute / A-source / B-source / output dtypes
     int tra, trb;
     int role;                   // profiler category: 0 = infer from the layout, else VC_CAT_GEMM_* + 1 (a dgrad through W^T has the forward's layout)
     GemmParams p;               // vecA/vecB/k_per_split/partial are filled by vc_gemm
+    unsigned flags;             // VC_GF_*
+    int* kernel_out;            // optional: receives the VC_TAG_* of the kernel family that ran
 };
 // scratch: fp32 workspace for split-K partial slabs (may be null -> no split)
 bool vc_profile_on();       // the HIP-event profiler is recording: per-kernel times must not overlap, so no side stream

@@ -94,8 +94,7 @@ static int check_rows_aligned(int t, const AttnParams& p, bool bwd) {
     }
     return VC_OK;
 }
-static int g_vit_bwd_variant = 0;
-extern "C" void vcad_debug_attn_variant(int v) { g_vit_bwd_variant = v; }
+#define g_vit_bwd_variant VC_AB(attn_variant, 0)          // 1 = r01 kernels (A/B build only)
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     p.window = clampw(p);
     if (int rc = check_rows_aligned(t, p, false)) return rc;
@@ -110,11 +109,13 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         else VC_LAUNCH((attn_vit_fwd2_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
     }
+#ifdef VCAD_AB
     if (mfma_ok(t, D, p, false)) {
         if (p.drop.key) VC_LAUNCH((attn_vit_fwd_mfma_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         else VC_LAUNCH((attn_vit_fwd_mfma_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(64), 0, s, p);
         return VC_OK;
     }
+#endif
     if (dec_mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {       // one wave per head-dim chunk
         const dim3 g((unsigned)((long)p.B * p.H));
         static unsigned attr = 0;
@@ -129,12 +130,14 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_cw_kernel<true, 2>), g, dim3(128), am_cw_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_fwd_cw_kernel<false, 2>), g, dim3(128), am_cw_lds_bytes(2), s, p); }
         return VC_OK;
     }
+#ifdef VCAD_AB
     if (dec_mfma_ok(t, D, p, false)) {
         const dim3 g((unsigned)((long)p.B * p.H));
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_mfma_kernel<true, 2>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_mfma_kernel<false, 2>), g, dim3(64), 0, s, p); }
         return VC_OK;
     }
+#endif
     if (dec_long_ok(t, D, p, false)) {
         const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
@@ -170,11 +173,13 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         else VC_LAUNCH(attn_vit_bwd4_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);
         return VC_OK;
     }
+#ifdef VCAD_AB
     if (mfma_ok(t, D, p, true)) {                                  // r01's two-wave kernel, kept for the A/B (vcad_debug_attn_variant(1))
         if (p.drop.key) VC_LAUNCH(attn_vit_bwd_mfma_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH(attn_vit_bwd_mfma_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
     }
+#endif
     if (dec_mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {        // one wave per (orientation, head-dim chunk)
         const dim3 g((unsigned)((long)p.B * p.H));
         static unsigned attr = 0;
@@ -189,12 +194,14 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_cw_kernel<true, 2>), g, dim3(256), am_cwb_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_bwd_cw_kernel<false, 2>), g, dim3(256), am_cwb_lds_bytes(2), s, p); }
         return VC_OK;
     }
+#ifdef VCAD_AB
     if (dec_mfma_ok(t, D, p, true)) {
         const dim3 g((unsigned)((long)p.B * p.H));
         if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 4>), g, dim3(128), 0, s, p); else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 4>), g, dim3(128), 0, s, p); }
         else               { if (p.drop.key) VC_LAUNCH((attn_dec_bwd_mfma_kernel<true, 2>), g, dim3(128), 0, s, p); else VC_LAUNCH((attn_dec_bwd_mfma_kernel<false, 2>), g, dim3(128), 0, s, p); }
         return VC_OK;
     }
+#endif
     if (dec_long_ok(t, D, p, true)) {
         static unsigned attr = 0;
         if (!(attr & vc_device_bit())) {

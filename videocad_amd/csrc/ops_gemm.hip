@@ -59,21 +59,6 @@ int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s);
 int vc_gemm_launch_bf16_wgrad(GemmCall c, int nsplit, vc_stream_t s);              // tra = trb = 1, fp32 output, either source fp32 or bf16
 int vc_gemm_launch_bf16(GemmCall c, int nsplit, int lay, vc_stream_t s);            // lay 0 / 1, B bf16
 
-static int g_dma_mode = -1;     // -1 = automatic, 0 = never, 1 = whenever legal (tests run small problems through it)
-extern "C" void vcad_debug_gemm_dma(int mode) { g_dma_mode = mode; }
-static int g_dma_wide = -1;     // 256 x 256 tile of the persistent kernel: -1 = automatic, 0 = never, 1 = whenever legal
-extern "C" void vcad_debug_gemm_wide(int mode) { g_dma_wide = mode; }
-static int g_mid_mode = -1;     // six-stage DMA-ring kernel for mid-size problems (gemm_mid.h): -1 = automatic, 0 = never, 1 = whenever legal
-extern "C" void vcad_debug_gemm_mid(int mode) { g_mid_mode = mode; }
-static int g_policy = 0;        // A/B bits for the dispatcher's measured rules: 1 = GELU / GELU' epilogues may use the persistent kernel, 2 = wgrads with < 16 tiles may
-extern "C" void vcad_debug_gemm_policy(int bits) { g_policy = bits; }
-static int g_stagger = -1;      // -1 = automatic
-extern "C" void vcad_debug_gemm_stagger(int n) { g_stagger = n; }
-static int g_debug_skip = 0;
-extern "C" void vcad_debug_gemm_skip(int mask) { g_debug_skip = mask; }
-static int g_force_tile = 0;     // 0 = automatic, 64 / 128 = forced (tests exercise both tile sizes on small problems)
-extern "C" void vcad_debug_force_gemm_tile(int tile) { g_force_tile = (tile == 64 || tile == 128) ? tile : 0; }
-
 static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
 
 // validation + the per-problem flags every kernel expects (activation remap, 16-byte legality of each operand)
@@ -81,12 +66,12 @@ int vc_gemm_prepare(GemmCall& c) {
     GemmParams& p = c.p;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
     if ((c.ct == VC_F32 || c.ct == VC_X3) && (c.sa != VC_F32 || c.sb != VC_F32 || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 / bf16x3 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
-    p.debug_skip = g_debug_skip;
+    p.debug_skip = VC_AB(skip, 0);
     if (c.ct == VC_BF16) {          // bf16 mode: cheap erf (gemm.h) in both GEMM kernels, so results do not depend on the kernel choice
         if (p.act == VC_ACT_GELU) p.act = VC_ACT_GELU_FAST;
         if (p.dact_kind == VC_ACT_GELU) p.dact_kind = VC_ACT_GELU_FAST;
     }
-    p.stagger = g_stagger >= 0 ? g_stagger : 0;
+    p.stagger = VC_AB(stagger, 0);
     p.vecA = (((uintptr_t)p.A) % 16 == 0) && ((p.lda * dsize(c.sa)) % 16 == 0);
     p.vecB = (((uintptr_t)p.B) % 16 == 0) && ((p.ldb * dsize(c.sb)) % 16 == 0);
     {   // row-wise vector epilogue: every tensor it touches must allow aligned 4-column accesses
@@ -96,13 +81,21 @@ int vc_gemm_prepare(GemmCall& c) {
                  ok(p.dact_src, p.lddact, eo) && ok(p.rowadd, p.ld_rowadd, 4) && ok(p.bias, 4, 4);
         if (eo == 2) p.vecC = p.vecC && ((uintptr_t)p.C % 8 == 0);
     }
-    if (g_debug_skip & 16) p.vecC = 0;          // ablation: register-direct epilogue
+    if (VC_AB(skip, 0) & 16) p.vecC = 0;          // ablation: register-direct epilogue
     return VC_OK;
 }
 
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     { int rc = vc_gemm_prepare(c); if (rc) return rc; }
     GemmParams& p = c.p;
+    const unsigned fl = c.flags | VC_AB(gemm_flags, 0u);
+    const int g_dma_mode = (fl & VC_GF_DMA_NEVER) ? 0 : ((fl & VC_GF_DMA_ALWAYS) ? 1 : -1);         // -1 = automatic, 0 = never, 1 = whenever legal
+    const int g_dma_wide = (fl & VC_GF_WIDE_NEVER) ? 0 : ((fl & VC_GF_WIDE_ALWAYS) ? 1 : -1);
+    const int g_mid_mode = (fl & VC_GF_MID_NEVER) ? 0 : ((fl & VC_GF_MID_ALWAYS) ? 1 : -1);
+    const int g_force_tile = (fl & VC_GF_TILE64) ? 64 : ((fl & VC_GF_TILE128) ? 128 : 0);
+    const int g_policy = VC_AB(policy, 0), g_debug_skip = VC_AB(skip, 0);
+    c.flags = fl;
+    int tag_dummy; int* const tag = c.kernel_out ? c.kernel_out : &tag_dummy;
     const int lay = c.tra * 2 + c.trb;
     // ---- persistent DMA-fed kernel for the big all-bf16 GEMMs (every large ViT Linear: forward, dgrad and wgrad): 256 x 256 tile where
     // the epilogue is plain (bias / k-slice slabs: QKV forward, dgrads through W^T, split-K wgrads), else 256 x 128
@@ -146,6 +139,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if ((g_dma_mode == 1 || wins) && wide_ok) {
             p.k_per_split = nt * GD_BK;
             p.partial = best > 1 ? scratch : nullptr;
+            *tag = VC_TAG_GEMM_DMA;
             return vc_gemm_dma_launch(c, best, BN, s);
         }
     }
@@ -156,8 +150,9 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         const long mt = (long)VC_CEIL_DIV(p.M, vc_gemm_mid_tile_m(c.trb)) * (p.N / vc_gemm_mid_tile_n(c.trb));
         // automatic for the k-contiguous-B (forward) layout only: in-model A/B at C2 (profiles/r02_gemm_mid_ab.txt) forward -0.35 ms per step,
         // but the row-contiguous-B variant (decoder dgrads through W, 64 x 128 tile) +0.26 ms against the register-staged kernel
-        if (g_mid_mode == 1 || (!c.trb && mt >= 96 && mt <= 1024 && p.K >= 256)) return vc_gemm_mid_launch(c, s);
+        if (g_mid_mode == 1 || (!c.trb && mt >= 96 && mt <= 1024 && p.K >= 256)) { *tag = VC_TAG_GEMM_MID; return vc_gemm_mid_launch(c, s); }
     }
+    *tag = VC_TAG_GEMM_REG;
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;
     // tile size: 128x128 by default; 64x64 when that grid would leave most of the 256 CUs idle (the decoder's
     // 2048-token GEMMs): 4x the blocks and no split-K pass.  Long token reductions still split K.

@@ -2,20 +2,11 @@
 // compiles in parallel with the register-staged kernels of ops_gemm.hip.
 #include "ops.h"
 #include "gemm_dma.h"
-#include "gemm_pp.h"
+#ifdef VCAD_AB
+#include "gemm_pp.h"       // ping-pong variant: A/B build only (measured 1.6-2x slower, profiles/r02_gemm_pingpong_ab.txt)
+#endif
 
-static long g_dma_launches = 0;
-static int g_xn = -1;            // XCD column groups of the forward-layout launches: -1 = automatic, 0 = never, 2 / 4 / 8 = forced (A/B)
-extern "C" void vcad_debug_gemm_xcd_cols(int xn) { g_xn = (xn == 2 || xn == 4 || xn == 8) ? xn : (xn == 0 ? 0 : -1); }
-static int g_variant = 0;        // 0 = the lockstep kernel (gemm_dma.h, default), 1 = ping-pong wave groups (gemm_pp.h): measured SLOWER, kept for the A/B
-                                 // (profiles/r02_gemm_pingpong_ab.txt: both are bound by the ~20 B/clk/CU L2->LDS DMA rate, not by MFMA issue)
-extern "C" void vcad_debug_gemm_variant(int v) { g_variant = v ? 1 : 0; }
-extern "C" long vcad_debug_gemm_dma_launches(void) { return g_dma_launches; }
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
-static int g_epi = -1;           // epilogue form of the k-contiguous-B launches: -1 = automatic, 0 = row-per-lane (r01), 1 = column-per-lane
-extern "C" void vcad_debug_gemm_epilogue(int m) { g_epi = m; }
-static int g_waves = 8;          // wave count of the 256-wide tile's launches: 8 (4 x 2 waves of 64 x 128) or 4 (2 x 2 waves of 128 x 128, one per SIMD)
-extern "C" void vcad_debug_gemm_waves(int n) { g_waves = n == 4 ? 4 : 8; }
 template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
 static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #ifndef VC_EMU
@@ -29,10 +20,10 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
                  (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_DMA);
     const int tiles_n = c.p.N / BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
-    ++g_dma_launches;
     const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
+#ifdef VCAD_AB
     // the ping-pong kernel carries the plain epilogue (bias, k-slice slabs); per-element side inputs stay on the lockstep kernel
-    if (NW == 8 && BN == GD_BN && g_variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
+    if (NW == 8 && BN == GD_BN && g_ab.variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
 #ifndef VC_EMU
         static unsigned attr_pp = 0;
         if (!(attr_pp & vc_device_bit())) {
@@ -42,9 +33,12 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
         }
 #endif
         VC_LAUNCH((gemm_pp_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GP_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
-    } else {
+    } else
+#endif
+    {
     // XCD column groups (see the kernel): only for k-contiguous forward-layout GEMMs whose weight matrix would not stay in one XCD's L2
     int xn = 1;
+    const int g_xn = (int)((c.flags >> VC_GF_XCD_COLS_SHIFT) & 15u) == 1 ? 0 : ((int)((c.flags >> VC_GF_XCD_COLS_SHIFT) & 15u) ? (int)((c.flags >> VC_GF_XCD_COLS_SHIFT) & 15u) : -1);
     if (!TRA && !TRB && g_xn != 0 && grid >= 8) {
         const double b_bytes = (double)c.p.N * c.p.K * 2, a_bytes = (double)c.p.M * c.p.K * 2, slice = (double)BN * c.p.K * 2;
         const int tiles_m = tiles_mn / tiles_n;
@@ -71,7 +65,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 // dgrad 87 -> 67 us); with the 128-wide tile it owns 2 (twice the store / side-load instructions of the row form's 16-byte quads) and the
 // fused residual epilogues LOSE 45-60 % (out-proj forward 196 -> 286 us) — those keep r01's row-per-lane form.
 static bool use_col(const GemmCall& c, int BN) {
-    if (g_epi >= 0) return g_epi != 0;
+    if (VC_AB(epilogue, -1) >= 0) return VC_AB(epilogue, -1) != 0;
     return BN == 256;
 }
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
@@ -82,10 +76,12 @@ int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
         if (lay != 0 || c.p.dact_src || c.p.residual) { vc_set_error("vc_gemm_dma_launch: 256-wide tile has no such fused epilogue"); return VC_ERR_UNSUPPORTED; }
         return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, true>(c, nsplit, s);
     }
-    if (BN == 256 && g_waves == 4) {       // four-wave form of the hot instantiations
+#ifdef VCAD_AB
+    if (BN == 256 && g_ab.waves == 4) {       // four-wave form of the hot instantiations
         if (lay == 3) return gemm_launch_dma<float, true, true, 256, false, 4>(c, nsplit, s);
         if (lay == 0 && use_col(c, BN)) return c.to == VC_F32 ? gemm_launch_dma<float, false, false, 256, true, 4>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, true, 4>(c, nsplit, s);
     }
+#endif
     if (BN == 256) {                       // plain epilogues only (checked by the dispatcher); no tr-read B instantiation
         if (lay == 3) return gemm_launch_dma<float, true, true, 256, false>(c, nsplit, s);
         if (lay == 0 && c.to == VC_F32) return use_col(c, BN) ? gemm_launch_dma<float, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<float, false, false, 256, false>(c, nsplit, s);

@@ -2,8 +2,6 @@
 #include "ops.h"
 #include "gemm_mid.h"
 
-static long g_mid_launches = 0;
-extern "C" long vcad_debug_gemm_mid_launches(void) { return g_mid_launches; }
 
 template <typename TO, bool TRB, int BM, int BN>
 static int gemm_launch_mid(GemmCall c, vc_stream_t s) {
@@ -18,7 +16,6 @@ static int gemm_launch_mid(GemmCall c, vc_stream_t s) {
 #endif
     ProfScope ps(c.role ? c.role - 1 : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD), 2.0 * c.p.M * c.p.N * c.p.K,
                  (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_MID);
-    ++g_mid_launches;
     const int tiles = VC_CEIL_DIV(c.p.M, BM) * (c.p.N / BN);
     VC_LAUNCH((gemm_mid_kernel<TO, TRB, BM, BN>), dim3(tiles), dim3(GM_THREADS), TL::LDS_BYTES, s, c.p);
     return VC_OK;

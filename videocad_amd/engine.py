@@ -104,8 +104,18 @@ class NativeEngine:
 
     def dropout_mask(self, module: int, layer: int, kind: int, n: int) -> torch.Tensor:
         out = torch.empty(n, dtype=torch.float32)
-        L.check(self.lib, self.lib.vcad_debug_dropout_mask(self.h, module, layer, kind, n, C.c_void_p(out.data_ptr())), "dropout_mask")
+        L.check(self.lib, self.lib.vcad_dropout_mask(self.h, module, layer, kind, n, C.c_void_p(out.data_ptr())), "dropout_mask")
         return out
+
+    # kernel-selection flags (tests: small batches on the kernels the C2 shapes take; lib.GEMM_*) / launches per kernel family / side stream
+    def set_gemm_flags(self, flags: int):
+        L.check(self.lib, self.lib.vcad_set_gemm_flags(self.h, int(flags)), "set_gemm_flags")
+
+    def kernel_launches(self, family: int) -> int:
+        return int(self.lib.vcad_kernel_launches(self.h, int(family)))
+
+    def set_side_stream(self, on: bool):
+        L.check(self.lib, self.lib.vcad_set_side_stream(self.h, int(bool(on))), "set_side_stream")
 
     # ------------------------------------------------------------------ hot path
     def forward(self, frames: torch.Tensor, actions_norm: torch.Tensor, cad: torch.Tensor):

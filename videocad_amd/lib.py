@@ -12,6 +12,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvcad_hip.so")
 
 VCAD_F32, VCAD_BF16, VCAD_BF16X3 = 0, 1, 2
+# kernel-selection flags (include/vcad.h VCAD_GEMM_*; tests only) and kernel families (vcad_kernel_launches / vcad_op_gemm kernel_out)
+GEMM_TILE64, GEMM_TILE128, GEMM_DMA_NEVER, GEMM_DMA_ALWAYS, GEMM_WIDE_NEVER, GEMM_WIDE_ALWAYS, GEMM_MID_NEVER, GEMM_MID_ALWAYS = 1, 2, 4, 8, 16, 32, 64, 128
+KERNEL_GEMM_DMA, KERNEL_GEMM_REG, KERNEL_GEMM_MID, KERNEL_GEMM_GROUPED = 1, 2, 3, 4
+
+
+def gemm_xcd_cols(n):
+    return int(n) << 8
+
 NMETRIC = 32
 
 # metric slots (csrc/loss.h)
@@ -45,7 +53,7 @@ PROTOTYPES = {
     "vcad_set_workspace": (_i, [_vp, _vp, _sz]),
     "vcad_set_dropout": (_i, [_vp, _f, C.c_uint64]),
     "vcad_set_fp8": (_i, [_vp, _i]),
-    "vcad_debug_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
+    "vcad_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_forward_u8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_forward_rgb8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -64,23 +72,10 @@ PROTOTYPES = {
     "vcad_profile_begin": (None, []),
     "vcad_profile_kernel": (_i, [_i, C.POINTER(C.c_double * 4)]),
     "vcad_profile_end": (_i, [C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_double * 8), C.POINTER(C.c_int * 8)]),
-    "vcad_debug_force_gemm_tile": (None, [_i]),
-    "vcad_debug_gemm_dma": (None, [_i]),
-    "vcad_debug_gemm_dma_launches": (C.c_long, []),
-    "vcad_debug_gemm_variant": (None, [_i]),
-    "vcad_debug_gemm_wide": (None, [_i]),
-    "vcad_debug_gemm_policy": (None, [_i]),
-    "vcad_debug_no_side_stream": (None, [_i]),
-    "vcad_debug_split_gelu": (None, [_i]),
-    "vcad_debug_gemm_waves": (None, [_i]),
-    "vcad_debug_gemm_mid": (None, [_i]),
-    "vcad_debug_gemm_mid_launches": (C.c_long, []),
-    "vcad_debug_attn_variant": (None, [_i]),
-    "vcad_debug_gemm_xcd_cols": (None, [_i]),
-    "vcad_debug_gemm_epilogue": (None, [_i]),
-    "vcad_debug_gemm_stagger": (None, [_i]),
-    "vcad_debug_gemm_skip": (None, [_i]),
-    "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, _vp]),
+    "vcad_set_gemm_flags": (_i, [_vp, C.c_uint32]),
+    "vcad_kernel_launches": (_i64, [_vp, _i]),
+    "vcad_set_side_stream": (_i, [_vp, _i]),
+    "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, C.c_uint32, C.POINTER(_i), _vp]),
     "vcad_op_quant_mx8": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _vp]),
     "vcad_op_gemm_mx8": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _i, _vp, _i64, _vp]),
     "vcad_op_layernorm_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
@@ -91,6 +86,14 @@ PROTOTYPES = {
     "vcad_op_attention_bwd_o": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                      _i, _i, _i, _i, _i, _i, _f, _vp]),
 }
+
+
+# A/B build only (csrc/ab.h; `make -C videocad_amd/csrc ab`): process-global selectors used by tools/, absent from libvcad_hip.so
+AB_PROTOTYPES = {name: (None, [_i]) for name in (
+    "vcad_debug_force_gemm_tile", "vcad_debug_gemm_dma", "vcad_debug_gemm_wide", "vcad_debug_gemm_mid", "vcad_debug_gemm_xcd_cols",
+    "vcad_debug_attn_variant", "vcad_debug_gemm_waves", "vcad_debug_split_gelu", "vcad_debug_no_side_stream", "vcad_debug_gemm_policy",
+    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip")}
+AB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_bin", "libvcad_ab.so")
 
 
 def declare(lib):
@@ -114,6 +117,26 @@ def load():
                                "(the VideoCAD MI355X path has no CPU fallback)")
         _lib = declare(C.CDLL(LIB_PATH))
     return _lib
+
+
+def load_ab():
+    """The A/B build, for the measurement scripts under tools/ only: becomes the library the package runs on in THIS process (call it
+    before anything else loads).  Never used by the product path or the tests."""
+    global _lib
+    if _lib is not None and getattr(_lib, "_vcad_ab", False):
+        return _lib
+    if _lib is not None:
+        raise RuntimeError("load_ab() must run before the product library is loaded")
+    if not os.path.exists(AB_LIB_PATH):
+        raise RuntimeError(f"{AB_LIB_PATH} not found: build it with `make -C videocad_amd/csrc ab`")
+    lib = declare(C.CDLL(AB_LIB_PATH))
+    for name, (res, args) in AB_PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._vcad_ab = True
+    _lib = lib
+    return lib
 
 
 def check(lib, rc, what=""):
