@@ -112,6 +112,7 @@ def load():
     """Load the HIP library; fail loudly (no CPU fallback)."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  (first: the library must bind to the HIP runtime torch ships, not load a second one from /opt/rocm)
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C videocad_amd/csrc` "
                                "(the VideoCAD MI355X path has no CPU fallback)")
@@ -127,6 +128,7 @@ def load_ab():
         return _lib
     if _lib is not None:
         raise RuntimeError("load_ab() must run before the product library is loaded")
+    import torch  # noqa: F401  (see load())
     if not os.path.exists(AB_LIB_PATH):
         raise RuntimeError(f"{AB_LIB_PATH} not found: build it with `make -C videocad_amd/csrc ab`")
     lib = declare(C.CDLL(AB_LIB_PATH))
