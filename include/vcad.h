@@ -13,8 +13,8 @@
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); nothing here synchronises the device
  *   - return value 0 = ok; non-zero = error, text via vcad_last_error() (thread-local)
  *   - dtype: VCAD_F32 = exact-fp32 parity mode (f32 MFMA), VCAD_BF16 = bf16 MFMA with fp32 accumulate,
- *     fp32 residual stream, fp32 master weights + bf16 weight shadow; VCAD_BF16X3 = fp32 tensors everywhere (like VCAD_F32, no
- *     shadow), every Linear on the bf16 matrix cores with hi/lo operand splits (three MFMAs per product, fp32 accumulate): the
+ *     fp32 residual stream, fp32 master weights + bf16 weight shadow; VCAD_BF16X3 = fp32 tensors everywhere (like VCAD_F32; the
+ *     shadow holds the weights pre-split into hi | lo bf16 words), every Linear on the bf16 matrix cores with hi/lo operand splits (three MFMAs per product, fp32 accumulate): the
  *     in-tolerance throughput mode (logits within 1e-3 of the fp32 reference, reference main.py:28 allows TF32 there)
  */
 #ifndef VCAD_H
@@ -58,9 +58,11 @@ int vcad_param_info(const vcad_engine* e, int index, char* name, size_t name_cap
 int vcad_bucket_count(const vcad_engine* e);
 int vcad_bucket_range(const vcad_engine* e, int bucket, int64_t* begin, int64_t* end);
 
-/* params/grads/m/v: fp32 [vcad_param_total]; shadow: bf16 [vcad_param_total] (VCAD_BF16 only, else NULL) */
-int vcad_bind(vcad_engine* e, float* params, float* grads, float* adam_m, float* adam_v, void* shadow_bf16);
-/* refresh the bf16 weight shadow from the fp32 master weights (after load_state_dict / external optimiser) */
+/* params/grads/m/v: fp32 [vcad_param_total]; shadow: VCAD_BF16 -> bf16 [vcad_param_total] (required); VCAD_BF16X3 -> uint32
+ * [vcad_param_total] of pre-split hi | lo words (optional: NULL = the GEMMs split the fp32 weights while staging, same results, slower);
+ * VCAD_F32 -> NULL.  The optimiser step keeps the shadow current. */
+int vcad_bind(vcad_engine* e, float* params, float* grads, float* adam_m, float* adam_v, void* shadow);
+/* refresh the weight shadow from the fp32 master weights (after load_state_dict / external optimiser) */
 int vcad_sync_shadow(vcad_engine* e, void* stream);
 
 size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T);
@@ -201,6 +203,9 @@ int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
                  const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, uint32_t flags /* VCAD_GEMM_* */,
                  int* kernel_out /* optional: kernel family that ran */, void* stream);
+/* y[i] = (RNE bf16(x[i]) << 16) | RNE bf16(x[i] - hi): the pre-split operand word of the bf16x3 GEMMs (storage type 3 as vcad_op_gemm's `sb`,
+ * forward / dgrad layouts; bit-identical results to splitting inside the kernel, which is what an fp32 `sb` does) */
+int vcad_op_pack_x3(const float* x, void* y, int64_t n, void* stream);
 /* MXFP8 (VCAD_FP8 mode): x [rows, cols] fp32 / bf16 (tx) -> q [rows, cols] OCP e4m3 bytes + scales [rows, cols/32] E8M0 bytes (one
  * power-of-two scale per 32 consecutive elements); C (type `to`) = act(A8 B8^T + bias) + residual on the block-scaled fp8 MFMA */
 int vcad_op_quant_mx8(int tx, const void* x, int64_t ldx, void* q, void* scales, int64_t rows, int cols, void* stream);

@@ -78,9 +78,10 @@ GEMM_FLAGS = 0        # OR-ed into every check_gemm call (the tile-size fixtures
 
 
 def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0, bias=False, act=0, residual=False, seed=0,
-               pad=0, tol=None, splitk=True, flags=0, kernel=None):
+               pad=0, tol=None, splitk=True, flags=0, kernel=None, pack_b=False):
     """C = act(opA @ opB^T + bias) + residual ; operands stored with `pad` extra leading-dimension elements.
-    flags: VCAD_GEMM_* kernel-selection flags of the call; kernel: the kernel family (lib.KERNEL_*) that must have run."""
+    flags: VCAD_GEMM_* kernel-selection flags of the call; kernel: the kernel family (lib.KERNEL_*) that must have run.
+    pack_b (bf16x3): B additionally handed over as pre-split hi | lo words (vcad_op_pack_x3) — the result must be bit-identical."""
     x3 = ct == X3
     st = torch.float32 if x3 else ct
     sa = st if sa is None else sa
@@ -107,6 +108,15 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
     rc = lib.vcad_op_gemm(TD[ct], TD[sa], TD[sb], TD[to], tra, trb, ptr(A), ptr(Bm), ptr(Cbuf), M, N, K, lda, ldb, N + pad,
                           ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, flags | GEMM_FLAGS, C.byref(tag), stream_of(device))
     L.check(lib, rc, "gemm")
+    if pack_b:
+        assert x3
+        Bp = torch.empty(Bm.shape, dtype=torch.int32, device=device)
+        L.check(lib, lib.vcad_op_pack_x3(ptr(Bm), ptr(Bp), Bm.numel(), stream_of(device)), "pack_x3")
+        C2 = torch.full((M, N + pad), 7.0, dtype=to, device=device)
+        rc = lib.vcad_op_gemm(TD[ct], TD[sa], 3, TD[to], tra, trb, ptr(A), ptr(Bp), ptr(C2), M, N, K, lda, ldb, N + pad,
+                              ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, flags | GEMM_FLAGS, None, stream_of(device))
+        L.check(lib, rc, "gemm (pre-split B)")
+        assert torch.equal(C2.cpu(), Cbuf.cpu()), "pre-split B operand: result differs from the in-kernel split"
     if kernel is not None:
         assert tag.value == kernel, f"gemm M{M} N{N} K{K} tra={tra} trb={trb} flags={flags}: ran on kernel family {tag.value}, expected {kernel}"
     ref = A_q.double() @ B_q.double().t()

@@ -83,7 +83,7 @@ def test_engine_step_bf16x3_in_tolerance(emu):
     inside north_star's 1e-3, arg-max exact, gradients / clip norm / post-Adam weights at the three-term split's accuracy"""
     cfg = small_cfg()
     eng, weights = build(cfg, L.VCAD_BF16X3, emu)
-    assert eng.shadow is None                                   # fp32 storage: no bf16 weight shadow
+    assert eng.shadow.dtype == torch.int32                      # fp32 tensors; the shadow holds the weights pre-split into hi | lo bf16 words
     B, T = 2, 3
     batch = synth.make_batch(B, T, seed=5, lengths=[4, 3])
     ot = O.OracleTrainer(weights, cfg)
@@ -107,6 +107,12 @@ def test_engine_step_bf16x3_in_tolerance(emu):
     assert worst[1] < 1e-3, worst
     norm = eng.optimizer_step(lr=1e-5)
     assert abs(float(norm[0]) - ototal) / ototal < 2e-4
+    # the optimiser step kept the pre-split shadow current: word = RNE bf16(w) << 16 | RNE bf16(w - hi)
+    w = eng.params
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    words = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xFFFF)
+    assert torch.equal(eng.shadow, words)
 
 
 def test_engine_forward_bf16_close(emu):

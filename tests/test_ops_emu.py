@@ -49,12 +49,12 @@ def test_gemm_bf16(emu, tra, trb, sa, to):
 def test_gemm_bf16x3_layouts(emu, tra, trb):
     """VCAD_BF16X3: fp32 operands split into hi / lo bf16 planes while staging, three MFMAs per product (gemm.h) — checked against the
     exact product of the UNROUNDED operands"""
-    U.check_gemm(emu, "cpu", 70, 40, 100, U.X3, tra=tra, trb=trb, pad=4, bias=True, residual=True, splitk=False)
-    U.check_gemm(emu, "cpu", 33, 7, 50, U.X3, tra=tra, trb=trb, pad=1, act=2, splitk=False)       # unaligned rows: element-wise staging path
+    U.check_gemm(emu, "cpu", 70, 40, 100, U.X3, tra=tra, trb=trb, pad=4, bias=True, residual=True, splitk=False, pack_b=not tra)
+    U.check_gemm(emu, "cpu", 33, 7, 50, U.X3, tra=tra, trb=trb, pad=1, act=2, splitk=False, pack_b=not tra)       # unaligned rows: element-wise staging path
 
 
 def test_gemm_bf16x3_multi_tile_splitk(emu):
-    U.check_gemm(emu, "cpu", 130, 136, 70, U.X3, act=1, bias=True, pad=4)
+    U.check_gemm(emu, "cpu", 130, 136, 70, U.X3, act=1, bias=True, pad=4, pack_b=True)
     U.check_gemm(emu, "cpu", 24, 20, 640, U.X3, tra=1, trb=1, bias=True, residual=True)
 
 

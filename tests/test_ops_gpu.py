@@ -48,14 +48,14 @@ def test_gemm_bf16(hip, tra, trb, sa, to):
 def test_gemm_bf16x3(hip, tra, trb):
     """VCAD_BF16X3 compute type: fp32 operands split into hi / lo bf16 planes while staging, three MFMAs per product; checked against
     the exact product of the unrounded fp32 operands (tolerance 1.5e-5 relative: ~2^-17 per operand + the dropped lo*lo term)"""
-    U.check_gemm(hip, DEV, 520, 264, 392, U.X3, tra=tra, trb=trb, pad=4, bias=True, act=2, residual=True, splitk=False)
-    U.check_gemm(hip, DEV, 33, 7, 100, U.X3, tra=tra, trb=trb, pad=1, splitk=False)
+    U.check_gemm(hip, DEV, 520, 264, 392, U.X3, tra=tra, trb=trb, pad=4, bias=True, act=2, residual=True, splitk=False, pack_b=not tra)
+    U.check_gemm(hip, DEV, 33, 7, 100, U.X3, tra=tra, trb=trb, pad=1, splitk=False, pack_b=not tra)
 
 
 def test_gemm_bf16x3_big(hip):
-    U.check_gemm(hip, DEV, 5000, 3072, 512, U.X3, bias=True)                # ViT QKV shape
+    U.check_gemm(hip, DEV, 5000, 3072, 512, U.X3, bias=True, pack_b=True)                # ViT QKV shape
     U.check_gemm(hip, DEV, 3072, 512, 20000, U.X3, tra=1, trb=1)            # ViT QKV wgrad, split-K
-    U.check_gemm(hip, DEV, 4096, 512, 1024, U.X3, trb=1, residual=True, act=1, bias=True)
+    U.check_gemm(hip, DEV, 4096, 512, 1024, U.X3, trb=1, residual=True, act=1, bias=True, pack_b=True)
 
 
 def test_gemm_bf16_wgrad_f32_sources(hip):

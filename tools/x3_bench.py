@@ -29,20 +29,25 @@ def timeit(call, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-def gemm(name, M, N, K, ct=2, tra=0, trb=0, bias=False, res=False):
+def gemm(name, M, N, K, ct=2, tra=0, trb=0, bias=False, res=False, pk=False):
     A = torch.randn((K, M) if tra else (M, K), device=dev)
     B = torch.randn((K, N) if trb else (N, K), device=dev)
     Cm = torch.empty(M, N, device=dev)
     bias_t = torch.randn(N, device=dev) if bias else None
     res_t = torch.randn(M, N, device=dev) if res else None
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sb = 0
+    if pk:        # B pre-split into hi | lo words (what the engine's weight shadow holds)
+        Bp = torch.empty(B.shape, dtype=torch.int32, device=dev)
+        assert lib.vcad_op_pack_x3(p(B), p(Bp), B.numel(), st) == 0
+        B, sb = Bp, 3
 
     def call():
-        rc = lib.vcad_op_gemm(ct, 0, 0, 0, tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0, p(res_t), N, 1.0,
+        rc = lib.vcad_op_gemm(ct, 0, sb, 0, tra, trb, p(A), p(B), p(Cm), M, N, K, A.shape[1], B.shape[1], N, p(bias_t), 0, p(res_t), N, 1.0,
                               p(scratch), scratch.numel(), 0, None, st)
         assert rc == 0, lib.vcad_last_error()
     ms = timeit(call)
-    print(f"{name:28s} ct={'x3' if ct == 2 else 'f32'} M={M:6d} N={N:5d} K={K:6d} tra={tra} trb={trb} {ms*1e3:8.1f} us  {2.0*M*N*K/(ms*1e-3)/1e12:7.1f} TF/s", flush=True)
+    print(f"{name:28s} ct={('x3pk' if pk else 'x3') if ct == 2 else 'f32'} M={M:6d} N={N:5d} K={K:6d} tra={tra} trb={trb} {ms*1e3:8.1f} us  {2.0*M*N*K/(ms*1e-3)/1e12:7.1f} TF/s", flush=True)
 
 
 def attn(name, B, H, T, D, window, causal):
@@ -65,6 +70,9 @@ def attn(name, B, H, T, D, window, causal):
 R = 2048 * 50
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 if what in ("gemm", "all"):
+    for nm, M, N, K, kw in (("QKV fwd", R, 3072, 512, {}), ("out-proj fwd (+res)", R, 512, 1024, dict(bias=True, res=True)), ("MLP fwd", R, 512, 512, dict(bias=True)),
+                            ("dqkv dgrad", R, 512, 3072, dict(trb=1)), ("dao dgrad", R, 1024, 512, dict(trb=1))):
+        gemm(nm, M, N, K, 2, pk=True, **kw)
     for ct in (2, 0):
         gemm("QKV fwd", R, 3072, 512, ct)
         gemm("out-proj fwd (+res)", R, 512, 1024, ct, bias=True, res=True)

@@ -20,6 +20,12 @@ int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A
     return rc;
 }
 
+// fp32 -> pre-split bf16x3 operand words (VCAD_PK storage: what bf16x3 engines keep as their weight shadow)
+int vcad_op_pack_x3(const float* x, void* y, int64_t n, void* stream) {
+    int rc = vc_pack_x3(x, (uint32_t*)y, n, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_pack_x3: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
 int vcad_op_quant_mx8(int tx, const void* x, int64_t ldx, void* q, void* scales, int64_t rows, int cols, void* stream) {
     int rc = vc_mx8_quant(tx, x, ldx, (uint8_t*)q, (uint8_t*)scales, rows, cols, (vc_stream_t)stream);
     if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_quant_mx8: launch failed"); return VC_ERR_LAUNCH; }

@@ -65,7 +65,7 @@ struct vcad_engine {
     std::vector<std::pair<long, long>> buckets;
     VitW wv[2]; std::vector<DecW> wd;      // [0] = state_embedding_model, [1] = cad_embedding_model
     long o_es_w, o_es_b, o_ei_w, o_ei_b, o_ip_w, o_ip_b, o_ea_w, o_ea_b, o_ts, o_h5_w, o_h5_b, o_h6_w, o_h6_b;
-    float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr; vc_bf16* S = nullptr;
+    float *P = nullptr, *G = nullptr, *Mm = nullptr, *Vv = nullptr; vc_bf16* S = nullptr; uint32_t* Spk = nullptr;
     char* ws = nullptr; size_t ws_bytes = 0; char* planned_ws = nullptr;
     // incremental inference (vcad_infer_begin / vcad_infer_step): per decoder layer the projected keys / values of every step so
     // far — self-attention over the tgt stream, cross-attention over the memory stream — laid out [B][Tmax][2H]
@@ -297,7 +297,10 @@ struct Ctx {
     vcad_engine* e; vc_stream_t s; int ln = 0;       // ln: which Lane's scratch / temporaries this context may touch
     const Lane& L() const { return e->lane[ln]; }
     int dt() const { return e->dt; }
-    Mat W(long off, long ld) const { return e->dt == VC_BF16 ? Mat{(const void*)(e->S + off), VC_BF16, ld} : Mat{(const void*)(e->P + off), VC_F32, ld}; }
+    Mat W(long off, long ld) const {
+        if (e->Spk) return Mat{(const void*)(e->Spk + off), VC_PK, ld};          // bf16x3: pre-split weights (gemm.h vc_pk)
+        return e->dt == VC_BF16 ? Mat{(const void*)(e->S + off), VC_BF16, ld} : Mat{(const void*)(e->P + off), VC_F32, ld};
+    }
     // transposed shadow (bf16 mode, frame ViT): offT < 0 -> not available
     bool hasT(long offT) const { return e->wT && offT >= 0; }
     Mat WT(long offT, long ld) const { return Mat{(const void*)(e->wT + offT), VC_BF16, ld}; }
@@ -856,10 +859,13 @@ int vcad_bucket_range(const vcad_engine* e, int b, int64_t* begin, int64_t* end)
 int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, void* shadow) {
     if (!params) { vc_set_error("vcad_bind: params is null"); return VC_ERR_ARG; }
     if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
-    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = (vc_bf16*)shadow; e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false;
+    e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = e->dt == VC_BF16 ? (vc_bf16*)shadow : nullptr;
+    e->Spk = e->ct == VC_X3 ? (uint32_t*)shadow : nullptr;      // optional: without it the bf16x3 GEMMs split the fp32 weights while staging
+    e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false;
     return 0;
 }
 int vcad_sync_shadow(vcad_engine* e, void* stream) {
+    if (e->Spk) return vc_pack_x3(e->P, e->Spk, e->ptotal, (vc_stream_t)stream);
     if (e->dt != VC_BF16) return 0;
     if (!e->P || !e->S) { vc_set_error("vcad_sync_shadow: not bound"); return VC_ERR_ARG; }
     e->wT_fresh = false; e->q8_fresh = false;
@@ -1183,7 +1189,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
         AdamParams a; memset(&a, 0, sizeof(a));
         a.p = e->P + lo; a.g = e->G + lo; a.m = e->Mm + lo; a.v = e->Vv + lo; a.n = hi - lo; a.lr = lr_bucket[b0]; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
         a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
-        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr;
+        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr; a.shadow_pk = e->Spk ? e->Spk + lo : nullptr;
         CK(vc_adam(a, s));
         b0 = b1i + 1;
     }

@@ -23,6 +23,7 @@
 // 16-byte slot (bf16) / one dword (f32) so the ds_read_b128 / ds_read_b32 fragment reads are conflict-free.
 #pragma once
 #include "vc_rt.h"
+#include <type_traits>
 
 enum { VC_ACT_NONE = 0, VC_ACT_GELU = 1, VC_ACT_RELU = 2, VC_ACT_TANH = 3, VC_ACT_GELU_FAST = 4 /* internal: bf16-mode GELU */ };
 
@@ -235,6 +236,18 @@ VC_DEV void gemm_split4(const vc_u32x4& a, vc_u32x2& hi, vc_u32x2& lo) {
     gemm_split2(vc_bits_f32(a.x), vc_bits_f32(a.y), hi.x, lo.x); gemm_split2(vc_bits_f32(a.z), vc_bits_f32(a.w), hi.y, lo.y);
 #endif
 }
+// Pre-split operand (bf16x3 engines keep their weights this way, engine.hip): one 32-bit word per element, hi bf16 in the upper half and lo
+// bf16 in the lower — the same two values gemm_split2 produces, so a GEMM gives bit-identical results either way; staging such a tile costs
+// four byte-permutes per quad instead of the ~10 VALU of the split (the bf16x3 kernel is VALU-bound: profiles/r03_x3_pmc.md).
+VC_DEV void gemm_unpack4(const vc_u32x4& a, vc_u32x2& hi, vc_u32x2& lo) {
+#ifndef VC_EMU
+    hi.x = __builtin_amdgcn_perm(a.y, a.x, 0x07060302u); hi.y = __builtin_amdgcn_perm(a.w, a.z, 0x07060302u);
+    lo.x = __builtin_amdgcn_perm(a.y, a.x, 0x05040100u); lo.y = __builtin_amdgcn_perm(a.w, a.z, 0x05040100u);
+#else
+    hi.x = (a.x >> 16) | (a.y & 0xFFFF0000u); hi.y = (a.z >> 16) | (a.w & 0xFFFF0000u);
+    lo.x = (a.x & 0xFFFFu) | (a.y << 16); lo.y = (a.z & 0xFFFFu) | (a.w << 16);
+#endif
+}
 struct gemm_true { static constexpr bool value = true; };
 struct gemm_false { static constexpr bool value = false; };
 // pipeline-stage ablation switches (tools/gemm_ablate*.py) exist only in the -DVCAD_AB build used by tools/; the shipped kernels carry no such branches
@@ -275,6 +288,9 @@ VC_DEV vc_u32x4 gemm_pack_chunk(const float (&f)[GemmCfg<CT>::CHUNK]) {
     return r;
 }
 
+template <typename T> VC_DEV float gemm_src_f32(T v) { return vc_cvt<T>::to_f32(v); }
+VC_DEV float gemm_src_f32(vc_pk) { return 0.0f; }       // never evaluated (the packed path returns before it); keeps the template well-formed
+
 // Stage one ROWS x BK operand tile.
 template <typename CT, typename ST, bool TR, int ROWS>
 struct GemmStager {
@@ -283,7 +299,9 @@ struct GemmStager {
     static constexpr int TS = gemm_tstride<CT, ROWS>();
     static constexpr bool X3 = gemm_is_x3<CT>::value;             // registers hold the RAW fp32 chunk (one quad = 4 elements); the hi / lo split happens in store()
     static constexpr int PLANE = gemm_plane_elems<CT, TR, ROWS>();
+    static constexpr bool PK = std::is_same<ST, vc_pk>::value;    // pre-split source words: unpacked, not split, in store()
     static_assert(!X3 || sizeof(ST) == 4, "bf16x3 splits fp32 sources");
+    static_assert(!PK || X3, "pre-split operands feed the bf16x3 kernel only");
     vc_u32x4 regs[NCH];
 
     // interior tile + 16-byte-aligned operand: straight-line vector loads (no per-chunk branch, so all loads of a
@@ -322,9 +340,14 @@ struct GemmStager {
                 nv = (k0 + k < Kend) ? (R - (r0 + rc)) : 0;
                 p = base + (long)(k0 + k) * ld + (r0 + rc);
             }
+            if constexpr (PK) {       // raw words, zero fill (hi = lo = 0)
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+                regs[i].x = 0 < nv ? w[0] : 0u; regs[i].y = 1 < nv ? w[1] : 0u; regs[i].z = 2 < nv ? w[2] : 0u; regs[i].w = 3 < nv ? w[3] : 0u;
+                continue;
+            }
             float f[CH];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) f[j] = (j < nv) ? vc_cvt<ST>::to_f32(p[j]) : 0.0f;
+            for (int j = 0; j < CH; ++j) f[j] = (j < nv) ? gemm_src_f32(p[j]) : 0.0f;
             if constexpr (X3) { regs[i].x = vc_f32_bits(f[0]); regs[i].y = vc_f32_bits(f[1]); regs[i].z = vc_f32_bits(f[2]); regs[i].w = vc_f32_bits(f[3]); }
             else regs[i] = gemm_pack_chunk<CT, ST>(f);
         }
@@ -344,7 +367,7 @@ struct GemmStager {
             if constexpr (X3) {       // split the fp32 quad into its hi and lo bf16 planes (same image in both): two 8-byte LDS stores
                 const vc_u32x4 a = regs[i];
                 vc_u32x2 hi, lo;
-                gemm_split4(a, hi, lo);
+                if constexpr (PK) gemm_unpack4(a, hi, lo); else gemm_split4(a, hi, lo);
                 int off;          // 16-byte slots are swizzled, the two 8-byte halves of a slot stay in order
                 if constexpr (!TR) { const int row = c / (BK / CH), q = c % (BK / CH); off = row * STRIDE + (((q >> 1) ^ ((row >> 2) & 3)) * 8) + (q & 1) * 4; }
                 else if constexpr (gemm_tswz<CT, ROWS>()) { const int k = c / (ROWS / CH); off = k * TS + (((c % (ROWS / CH)) * CH) ^ ((k & 3) << 5)); }

@@ -8,7 +8,8 @@
 #include "optim.h"
 #include "ab.h"
 
-enum { VC_F32 = 0, VC_BF16 = 1, VC_X3 = 2 /* GEMM compute type only: bf16x3 on fp32 tensors (gemm.h) */ };
+enum { VC_F32 = 0, VC_BF16 = 1, VC_X3 = 2 /* GEMM compute type only: bf16x3 on fp32 tensors (gemm.h) */,
+       VC_PK = 3 /* storage type of a bf16x3 GEMM's B operand only: pre-split hi | lo words (gemm.h vc_pk) */ };
 enum { VC_OK = 0, VC_ERR_ARG = 1, VC_ERR_UNSUPPORTED = 2, VC_ERR_LAUNCH = 3, VC_ERR_WORKSPACE = 4 };
 
 void vc_set_error(const char* fmt, ...);
@@ -67,6 +68,7 @@ int vc_embed_action(int ty, const float* a, const float* W, const float* b, cons
 int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s);
 int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s);
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
+int vc_pack_x3(const float* x, uint32_t* y, long n, vc_stream_t s);       // y[i] = hi bf16(x[i]) << 16 | lo bf16(x[i] - hi)
 // g = dropout(act(z)) / dz = (dz * dropmask) * act'(z): compact bf16 [rows, cols], masks indexed like the fused GEMM epilogue
 int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_drop d, vc_stream_t s);
 int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s);

@@ -2,6 +2,11 @@
 #include "gemm_launch.h"
 
 int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s) {
+    if (c.sb == VC_PK) {          // pre-split weights (forward / dgrad layouts)
+        if (lay == 0) return gemm_launch<vc_x3, float, vc_pk, float, false, false>(c, nsplit, s);
+        if (lay == 1) return gemm_launch<vc_x3, float, vc_pk, float, false, true>(c, nsplit, s);
+        vc_set_error("vc_gemm: pre-split B operand in layout %d", lay); return VC_ERR_UNSUPPORTED;
+    }
     switch (lay) {
         case 0: return gemm_launch<vc_x3, float, float, float, false, false>(c, nsplit, s);
         case 1: return gemm_launch<vc_x3, float, float, float, false, true>(c, nsplit, s);

@@ -121,6 +121,14 @@ int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s) {
     VC_LAUNCH(add_inplace_kernel, dim3((unsigned)VC_CEIL_DIV(n, 256)), dim3(256), 0, s, a, b, n);
     return VC_OK;
 }
+VC_KERNEL __launch_bounds__(256) void pack_x3_kernel(const float* x, uint32_t* y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = vc_pk_pack(x[i]);
+}
+int vc_pack_x3(const float* x, uint32_t* y, long n, vc_stream_t s) {
+    long nb = VC_CEIL_DIV(n, 256); if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
+    VC_LAUNCH(pack_x3_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, y, n);
+    return VC_OK;
+}
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s) {
     dim3 g((unsigned)VC_CEIL_DIV(n, 1024));
     if (ty == VC_BF16) VC_LAUNCH((cast_kernel<vc_bf16>), g, dim3(256), 0, s, x, (vc_bf16*)y, n);
@@ -185,7 +193,7 @@ int vc_grad_norm(const float* g, long n, float max_norm, float gscale, float* pa
     return VC_OK;
 }
 int vc_adam(AdamParams a, vc_stream_t s) {
-    ProfScope ps(VC_CAT_OPTIM, 0, (double)a.n * (28 + (a.shadow ? 2 : 0)), s);
+    ProfScope ps(VC_CAT_OPTIM, 0, (double)a.n * (28 + (a.shadow ? 2 : 0) + (a.shadow_pk ? 4 : 0)), s);
     long nb = VC_CEIL_DIV(a.n, 256); if (nb > 8192) nb = 8192; if (nb < 1) nb = 1;
     VC_LAUNCH(adam_kernel, dim3((unsigned)nb), dim3(256), 0, s, a);
     return VC_OK;

@@ -41,6 +41,7 @@ struct AdamParams {
     const float* clip;                          // device scalar (norm_out + 1) or null
     float gscale;                               // extra gradient scale (1/world for DDP sum -> mean)
     vc_bf16* shadow;                            // optional bf16 copy of p (same flat offsets)
+    uint32_t* shadow_pk;                        // optional pre-split (hi | lo bf16) copy of p for the bf16x3 GEMMs (gemm.h vc_pk)
 };
 VC_KERNEL __launch_bounds__(256) void adam_kernel(AdamParams a) {
     const float c = (a.clip ? a.clip[0] : 1.0f) * a.gscale;
@@ -52,5 +53,6 @@ VC_KERNEL __launch_bounds__(256) void adam_kernel(AdamParams a) {
         const float p = a.p[i] - step * (m / (sqrtf(v) * rs2 + a.eps));
         a.m[i] = m; a.v[i] = v; a.p[i] = p;
         if (a.shadow) a.shadow[i] = vc_f32_to_bf16(p);
+        if (a.shadow_pk) a.shadow_pk[i] = vc_pk_pack(p);
     }
 }

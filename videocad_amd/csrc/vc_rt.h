@@ -263,6 +263,13 @@ template <> struct vc_cvt<vc_bf16> {
     VC_HD static float to_f32(vc_bf16 v) { return vc_bf16_to_f32(v); }
     VC_HD static vc_bf16 from_f32(float v) { return vc_f32_to_bf16(v); }
 };
+// pre-split bf16x3 operand word (gemm.h): hi bf16 in the upper half, lo = bf16(x - hi) in the lower
+struct vc_pk { uint32_t w; };
+VC_HD uint32_t vc_pk_pack(float x) {
+    const vc_bf16 h = vc_f32_to_bf16(x);
+    const vc_bf16 l = vc_f32_to_bf16(x - vc_bf16_to_f32(h));
+    return ((uint32_t)h.bits << 16) | (uint32_t)l.bits;
+}
 template <typename T> VC_HD float vc_ld(const T* p) { return vc_cvt<T>::to_f32(*p); }
 template <typename T> VC_HD void vc_st(T* p, float v) { *p = vc_cvt<T>::from_f32(v); }
 

@@ -66,7 +66,8 @@ class NativeEngine:
         z = lambda dt=torch.float32: torch.zeros(self.total, dtype=dt, device=self.device)
         self.params = params.to(self.device) if params is not None else z()
         self.grads, self.m, self.v = z(), z(), z()
-        self.shadow = z(torch.bfloat16) if self.cfg.dtype == L.VCAD_BF16 else None
+        # bf16: bf16 copy of the weights; bf16x3: the weights pre-split into hi | lo bf16 words (same 4 bytes per element); f32: none
+        self.shadow = z(torch.bfloat16) if self.cfg.dtype == L.VCAD_BF16 else (z(torch.int32) if self.cfg.dtype == L.VCAD_BF16X3 else None)
         self.ws = None
         self._bind()
 

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "vcad_kernel_launches": (_i64, [_vp, _i]),
     "vcad_set_side_stream": (_i, [_vp, _i]),
     "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, C.c_uint32, C.POINTER(_i), _vp]),
+    "vcad_op_pack_x3": (_i, [_vp, _vp, _i64, _vp]),
     "vcad_op_quant_mx8": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _vp]),
     "vcad_op_gemm_mx8": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _i, _vp, _i64, _vp]),
     "vcad_op_layernorm_fwd": (_i, [_i, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _f, _vp]),
