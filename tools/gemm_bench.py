@@ -164,6 +164,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "abl":
                 run(f"{name} [{'no epilogue' if sk else 'full'} #{rnd}]", *dims, **kw)
     lib.vcad_debug_gemm_skip(0)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "wr":
+    # is the epilogue's cost the HBM write stream?  full / no epilogue (64) / the same stores aimed at 256 rows of C that stay in L2 (128)
+    lib.vcad_debug_gemm_dma(1)
+    for name, dims, kw in [("qkv fwd", (R, 3072, 512), {}), ("dao dgrad W^T", (R, 1024, 512), {}), ("dh dgrad W^T", (R, 512, 512), {}), ("dqkv dgrad W^T", (R, 512, 3072), {})]:
+        for rnd in range(2):
+            for sk, tag in ((0, "full"), (64, "no epilogue"), (128, "stores stay in L2")):
+                lib.vcad_debug_gemm_skip(sk)
+                run(f"{name} [{tag} #{rnd}]", *dims, **kw)
+    lib.vcad_debug_gemm_skip(0)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "epi2":
     # interleaved A/B (rule: perf deltas come from within-process interleaved rounds): per shape, 3 rounds of row / col
     lib.vcad_debug_gemm_dma(1)

@@ -120,6 +120,20 @@ template <int NJ> VC_DEV void gd_vec_ld_f32(const float* q, float (&v)[NJ]) {
     else { const vc_u32x2 t = *reinterpret_cast<const vc_u32x2*>(q); v[0] = vc_bits_f32(t.x); v[1] = vc_bits_f32(t.y); }
 }
 
+template <int I, int N, typename F> VC_DEV void gd_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); gd_static_for<I + 1, N>(f); }
+}
+// scheduling directive for the region it ends: NM MFMAs, each followed by its share of ND LDS reads
+template <int NM, int ND> VC_DEV void gd_interleave() {
+#ifndef VC_EMU
+    gd_static_for<0, NM>([](auto m) {
+        constexpr int M = decltype(m)::value, n = (ND * (M + 1)) / NM - (ND * M) / NM;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x100, n, 0);
+    });
+#endif
+}
+
 struct GdCursor { int item, kt, ntc, seq, z, tm, tn; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile row, tile column)
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
@@ -292,30 +306,44 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         }
         turn ^= 1;
     };
+    // Fragments are software-pipelined inside the k-tile: the 6 / 4 ds_reads of k-step ks + 1 are issued BEFORE the 8 / 4 MFMAs of k-step ks
+    // (r02's order — reads, wait, MFMAs, per k-step — left the matrix pipe idle for one LDS round trip per k-step: the ISA had
+    // `s_waitcnt lgkmcnt(0)` in front of every MFMA group; profiles/r03_gemm_fragpipe_ab.txt).
+    auto load_frags = [&](const vc_bf16* a_tile, const vc_bf16* b_tile, int ks, vc_s16x8 (&af)[MI], vc_s16x8 (&bf)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) af[i][e] = (short)(lane + i); asm volatile("" : "+v"(af[i])); }
+            else af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * WR + i * 32, ks, lane);
+        }
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) bf[jn][e] = (short)(lane + jn); asm volatile("" : "+v"(bf[jn])); }
+            else bf[jn] = gd_frag<TRB, BN>(b_tile, wn * HALF_N + jn * 32, ks, lane);
+        }
+    };
+    auto mfma_step = [&](const vc_s16x8 (&af)[MI], const vc_s16x8 (&bf)[NJ]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) {
+                if constexpr (GD_ABLATE & 1) { asm volatile("" :: "v"(af[i]), "v"(bf[jn])); continue; }
+                if constexpr (COL) acc[i][jn] = vc_mfma_32x32x16_bf16(af[i], bf[jn], acc[i][jn]);      // D[m][n]: lane = column
+                else acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);                    // swapped, D[n][m]: lane = row
+            }
+    };
     auto ktile_mfma = [&]() {
         const vc_bf16* a_tile = lds + slot * STAGE_ELEMS;
         const vc_bf16* b_tile = a_tile + GD_A_ELEMS;
+        vc_s16x8 af[2][MI], bf[2][NJ];
+        load_frags(a_tile, b_tile, 0, af[0], bf[0]);
 #pragma unroll
         for (int ks = 0; ks < GD_BK / 16; ++ks) {
-            vc_s16x8 af[MI], bf[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) af[i][e] = (short)(lane + i); asm volatile("" : "+v"(af[i])); }
-                else af[i] = gd_frag<TRA, GD_BM>(a_tile, wm * WR + i * 32, ks, lane);
-            }
-#pragma unroll
-            for (int jn = 0; jn < NJ; ++jn) {
-                if constexpr (GD_ABLATE & 2) { for (int e = 0; e < 8; ++e) bf[jn][e] = (short)(lane + jn); asm volatile("" : "+v"(bf[jn])); }
-                else bf[jn] = gd_frag<TRB, BN>(b_tile, wn * HALF_N + jn * 32, ks, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    if constexpr (GD_ABLATE & 1) { asm volatile("" :: "v"(af[i]), "v"(bf[jn])); continue; }
-                    if constexpr (COL) acc[i][jn] = vc_mfma_32x32x16_bf16(af[i], bf[jn], acc[i][jn]);      // D[m][n]: lane = column
-                    else acc[i][jn] = vc_mfma_32x32x16_bf16(bf[jn], af[i], acc[i][jn]);                    // swapped, D[n][m]: lane = row
-                }
+            if (ks + 1 < GD_BK / 16) load_frags(a_tile, b_tile, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+            mfma_step(af[ks & 1], bf[ks & 1]);
+            // issue order of this region: one MFMA, then its share of the next k-step's LDS reads — a burst of reads from all eight waves
+            // fills the LDS queue and the waves then sit in ds_read issue while the matrix pipe drains (r02 ablation: MFMA + reads = sum of both)
+            if (ks + 1 < GD_BK / 16) gd_interleave<MI * NJ, MI * (TRA ? 2 : 1) + NJ * (TRB ? 2 : 1)>();
+            vc_sched_fence();
         }
         slot = slot == STAGES - 1 ? 0 : slot + 1;
     };
@@ -323,20 +351,62 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 
     // plain epilogue = scale-free, bias at most: the QKV / dgrad / split-K launches (most of the FLOPs) skip the generic code
     const bool plain = !p.partial && !p.aux && !p.act && !p.drop.key && !p.dact_src && !p.residual && p.alpha == 1.0f;
+    // accumulators start at the tile's bias (acc_init) — on the 256-wide tile only: the 128-wide tile keeps r02's loop
+    // (its launches are the fused residual epilogues, bound by their side-input / output streams; a straight-line "dropout + residual" epilogue
+    // was tried there and gained nothing, profiles/r03_gemm_epilogue_fastpath_ab.txt) and its fast paths add the bias instead
+    constexpr bool FOLD = BN == 256;
+    const bool fold_bias = FOLD && use_bias && plain;
 
     for (; cp.item < last; cp.item += nbx, ++cp.seq) {
         if (cp.seq) locate(cp);
         const int z = cp.z, tm = cp.tm, tn = cp.tn;
+        // accumulators start at the tile's bias when the epilogue is plain (then the epilogue is convert + store: no per-element add); the bias row
+        // was DMA'd ahead of the item's first stage, so it is readable once that stage's wait + barrier (ktile_begin) are through
+        auto acc_init = [&]() {
+            if (fold_bias) {
+                if constexpr (COL) {
+                    float b[NJ]; gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % 3) * BN + wn * HALF_N + NJ * (lane & 31), b);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int jn = 0; jn < NJ; ++jn)
+                        for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-        for (int kt = 0; kt < cp.ntc - 1; ++kt) { ktile_begin(); ktile_prefetch(); ktile_mfma(); }
+                            for (int r = 0; r < 16; ++r) acc[i][jn][r] = b[jn];
+                } else {
+                    const float* br = bias_lds + (cp.seq % 3) * BN + wn * HALF_N + 4 * (lane >> 5);
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float b4[4]; quad_ld_f32(br + jn * 32 + 8 * q, b4);
+#pragma unroll
+                            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) acc[i][jn][4 * q + k] = b4[k];
+                        }
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+        };
+        if constexpr (FOLD) {
+            if (cp.ntc > 1) {
+                ktile_begin(); acc_init(); ktile_prefetch(); ktile_mfma();
+                for (int kt = 1; kt < cp.ntc - 1; ++kt) { ktile_begin(); ktile_prefetch(); ktile_mfma(); }
+            }
+        } else {
+            acc_init();
+            for (int kt = 0; kt < cp.ntc - 1; ++kt) { ktile_begin(); ktile_prefetch(); ktile_mfma(); }
+        }
 
         // ---- last k-tile of the item: the epilogue's side input is requested before the MFMA phase that hides its latency
         ktile_begin();
+        if constexpr (FOLD) if (cp.ntc == 1) acc_init();
         // ---------------------------------------------------------------- column-per-lane form (k-contiguous B)
         if constexpr (COL) {
             const int cl = lane & 31;
@@ -377,6 +447,34 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn) bv[jn] = 0.0f;
             if (use_bias) gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % 3) * BN + wn * HALF_N + NJ * cl, bv);
+            // ---- plain / k-slice-slab epilogues (most of the FLOPs): straight-line code.  The generic loop below decides partial / plain /
+            // fused, the row bound and a 64-bit row address PER ROW — ~35 instructions and 4 branches per store, ~1 100 per wave and item,
+            // a quarter of the QKV forward's time (profiles/r03_gemm_epilogue_fastpath_ab.txt).  Here: the mode and "interior tile" are
+            // decided once (wave-uniform), row offsets are compile-time multiples of the (scalar) leading dimension.
+            if (p.partial || plain) {
+                const bool interior = (tm + 1) * GD_BM <= p.M;
+                auto rows = [&](auto INTERIOR, auto PART) {
+                    using T = typename std::conditional<decltype(PART)::value, float, TO>::type;
+                    const long ld = decltype(PART)::value ? (long)p.N : p.ldc;
+                    T* q0 = (decltype(PART)::value ? (T*)(p.partial + (long)z * p.M * p.N) : (T*)p.C) + (long)mb * ld + nb;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (decltype(INTERIOR)::value || mb + ro < p.M) {
+                                float v[NJ];
+#pragma unroll
+                                for (int jn = 0; jn < NJ; ++jn) v[jn] = FOLD ? acc[i][jn][r] : acc[i][jn][r] + bv[jn];      // (256-wide: the bias is already in, acc_init; slabs: bv = 0)
+                                gd_vec_st<T, NJ>(q0 + (long)ro * ld, v);
+                            }
+                        }
+                };
+                if (p.partial) { if (interior) rows(gemm_true{}, gemm_true{}); else rows(gemm_false{}, gemm_true{}); }
+                else { if (interior) rows(gemm_true{}, gemm_false{}); else rows(gemm_false{}, gemm_false{}); }
+                if (interior && !VC_ABL(32)) young_cur = NS_ITEM;
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -386,13 +484,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                         float v[NJ];
 #pragma unroll
                         for (int jn = 0; jn < NJ; ++jn) v[jn] = acc[i][jn][r];
-                        if (p.partial) {
-                            gd_vec_st<float, NJ>(p.partial + ((long)z * p.M + m) * p.N + nb, v);
-                        } else if (plain) {
-#pragma unroll
-                            for (int jn = 0; jn < NJ; ++jn) v[jn] += bv[jn];
-                            gd_vec_st<TO, NJ>(((TO*)p.C) + (long)m * p.ldc + nb, v);
-                        } else if constexpr (NJ == 4) {
+                        if constexpr (NJ == 4) {          // (fused epilogues only from here on: the plain / slab stores returned above)
                             // 256-wide tile: the fused epilogues that need NO per-element side input (the MLP's first Linear: bias,
                             // pre-activation output, GELU, dropout) on the lane's four adjacent columns — 8 / 16-byte row pieces
                             float b4[4] = {bv[0], bv[1], bv[2], bv[3]};
@@ -476,6 +568,34 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 
         // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3
         if (VC_ABL(64)) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7]; continue; }
+        if (p.partial || plain) {      // straight-line plain / slab stores (see the column-per-lane form above)
+            auto quads = [&](auto PART) {
+                using T = typename std::conditional<decltype(PART)::value, float, TO>::type;
+                const long ld = decltype(PART)::value ? (long)p.N : p.ldc;
+                const int m0 = tm * GD_BM + wm * WR + (lane & 31), n0 = tn * BN + wn * HALF_N + 4 * (lane >> 5);
+                T* q0 = (decltype(PART)::value ? (T*)(p.partial + (long)z * p.M * p.N) : (T*)p.C) + (long)m0 * ld + n0;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    if (m0 + i * 32 < p.M) {
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float v[4] = {acc[i][jn][4 * q], acc[i][jn][4 * q + 1], acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]};
+                                if constexpr (!FOLD && !decltype(PART)::value) if (use_bias) {
+                                    float b4[4]; quad_ld_f32(brow + jn * 32 + 8 * q, b4);
+#pragma unroll
+                                    for (int k = 0; k < 4; ++k) v[k] += b4[k];
+                                }
+                                quad_st<T>(q0 + (long)(i * 32) * ld + jn * 32 + 8 * q, v);
+                            }
+                    }
+                }
+            };
+            if (p.partial) quads(gemm_true{}); else quads(gemm_false{});
+            if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = tm * GD_BM + wm * WR + i * 32 + (lane & 31);
@@ -486,17 +606,9 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                     for (int q = 0; q < 4; ++q) {
                         const int n = tn * BN + wn * HALF_N + jn * 32 + 8 * q + 4 * (lane >> 5);
                         float v[4] = {acc[i][jn][4 * q], acc[i][jn][4 * q + 1], acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]};
-                        if (p.partial) {
-                            quad_st<float>(p.partial + ((long)z * p.M + m) * p.N + n, v);
-                        } else {
-                            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (use_bias) quad_ld_f32(brow + jn * 32 + 8 * q, b4);
-                            if (plain) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) v[k] += b4[k];
-                                quad_st<TO>(((TO*)p.C) + (long)m * p.ldc + n, v);
-                            } else if constexpr (NJ == 2) gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
-                        }
+                        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (use_bias) quad_ld_f32(brow + jn * 32 + 8 * q, b4);
+                        if constexpr (NJ == 2) gd_epilogue_quad<TO>(p, m, n, v, b4, side[i][jn][q]);
                     }
             }
         }

@@ -130,10 +130,13 @@ def load_ab():
     if _lib is not None:
         raise RuntimeError("load_ab() must run before the product library is loaded")
     import torch  # noqa: F401  (see load())
-    if not os.path.exists(AB_LIB_PATH):
-        raise RuntimeError(f"{AB_LIB_PATH} not found: build it with `make -C videocad_amd/csrc ab`")
-    lib = declare(C.CDLL(AB_LIB_PATH))
-    for name, (res, args) in AB_PROTOTYPES.items():
+    path = os.environ.get("VCAD_AB_LIB", AB_LIB_PATH)          # (an older A/B build kept beside the current one, for before / after timings)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build it with `make -C videocad_amd/csrc ab`")
+    lib = C.CDLL(path)
+    for name, (res, args) in list(PROTOTYPES.items()) + list(AB_PROTOTYPES.items()):
+        if not hasattr(lib, name) and "VCAD_AB_LIB" in os.environ:
+            continue                                           # an older build may lack newer entry points
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
