@@ -191,7 +191,7 @@ void vcad_debug_attn_variant(int v);         /* 0 = current attention kernels, 1
 void vcad_debug_gemm_waves(int n);           /* 256-wide tile of the persistent kernel: 8 waves (64 x 128 each) or 4 waves (128 x 128 each) */
 void vcad_debug_split_gelu(int on);          /* ViT MLP activation as its own pass behind a plain GEMM (1, default) or fused into the GEMM epilogue (0) */
 void vcad_debug_no_side_stream(int on);
-void vcad_debug_gemm_policy(int bits);       /* dispatcher rules: 1 = activation epilogues on the persistent kernel, 2 = small-tile-count wgrads too */
+void vcad_debug_gemm_policy(int bits);       /* dispatcher rules of r02: 1 = activation epilogues stay off the persistent kernel, 2 = small-tile-count wgrads too */
 void vcad_debug_gemm_epilogue(int mode);     /* persistent kernel, k-contiguous B: -1 automatic, 0 row-per-lane (r01), 1 column-per-lane */
 void vcad_debug_gemm_variant(int v);         /* 0 = lockstep persistent kernel, 1 = ping-pong wave groups (slower) */
 void vcad_debug_gemm_stagger(int n);         /* ablation (tools/gemm_ablate*.py) */

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from videocad_amd import lib as L  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--gemm-policy", type=int, default=0, help="dispatcher rules: 1 = activation epilogues on the persistent kernel, 2 = small-tile-count wgrads too")
+ap.add_argument("--gemm-policy", type=int, default=0, help="r02 dispatcher rules: 1 = activation epilogues stay off the persistent kernel, 2 = small-tile-count wgrads too")
 ap.add_argument("--attn-variant", type=int, default=0, help="1 = r01 attention kernels")
 ap.add_argument("--split-gelu", type=int, default=1, help="0 = GELU / GELU' fused into the MLP GEMM epilogues (r01)")
 ap.add_argument("--gemm-waves", type=int, default=8, help="4 = four-wave form of the 256-wide tile")

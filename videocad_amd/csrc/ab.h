@@ -8,7 +8,7 @@
 #pragma once
 #ifdef VCAD_AB
 struct VcAb {
-    int policy;        // dispatcher rules: 1 = activation epilogues on the persistent kernel, 2 = small-tile-count wgrads too, 8 = fused wide epilogue
+    int policy;        // dispatcher rules: 1 = activation epilogues stay off the persistent kernel (r02), 2 = small-tile-count wgrads too (r02), 8 = fused wide epilogue
     int stagger;       // first-wave start offset of the register-staged kernel (units of s_sleep(127))
     int skip;          // pipeline-stage ablation mask (tools/gemm_ablate*.py)
     int epilogue;      // persistent kernel, k-contiguous B: -1 automatic, 0 row-per-lane (r01), 1 column-per-lane

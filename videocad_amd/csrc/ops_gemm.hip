@@ -131,8 +131,11 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         // Where the persistent kernel wins was measured in-model at the C2 shapes (A/B of one train step, profiles/r01_gemm_ab.md):
         // it loses where its one-workgroup-per-CU design has nothing to overlap a VALU-heavy epilogue with (GELU / GELU' — the
         // register-staged kernel's second co-resident workgroup hides that), on the long-K dgrad through ds_read_b64_tr_b16
-        // (K >= 2048), and on wgrads with fewer than 16 output tiles (the k-slice slabs dominate).
-        const bool wins = tiles * best >= 200 && ((g_policy & 1) || (BN == 256 && wide_fused && !p.dact_src) || (!p.act && !p.dact_src)) && !(lay == 1 && p.K >= 2048) && ((g_policy & 2) || !(lay == 3 && tiles < 16));
+        // (K >= 2048), and (r01 / r02 only, see below) on wgrads with fewer than 16 output tiles (the k-slice slabs dominated).
+        // r03: with the straight-line slab / plain epilogues the persistent kernel also wins the wgrads with fewer than 16 output tiles (the
+        // MLP's 512 x 512 ones) and is level on the activation epilogues: 26.20 -> 25.90 ms per step (profiles/r03_gemm_policy_ab.txt).  A/B
+        // build: policy bit 1 / 2 restore r02's two exclusions.
+        const bool wins = tiles * best >= 200 && (!(g_policy & 1) || (BN == 256 && wide_fused && !p.dact_src) || (!p.act && !p.dact_src)) && !(lay == 1 && p.K >= 2048) && (!(g_policy & 2) || !(lay == 3 && tiles < 16));
         // the wide tile halves the item count: with few, short items (N = 512, K = 512: 814 items of 8 k-tiles = 3.2 rounds) the last,
         // partly filled round costs more than the tile saves (measured: profiles/r02_gemm_wide_ab.txt) — long items amortise it
         const double fill = (double)(tiles * best) / (256.0 * VC_CEIL_DIV(tiles * best, 256));
