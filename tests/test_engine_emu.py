@@ -223,6 +223,34 @@ def test_engine_train_mode_dropout_matches_oracle_with_same_masks(emu):
     assert U.relerr(p2, pars) > 1e-3
 
 
+def test_engine_bf16_backward_fused_bias_gradients(emu):
+    """bf16 engine, three ViT layers, dropout on: the bias gradients that r03 reduces inside other kernels — b1 in the activation-derivative
+    pass (dact_bwd_bf16_rows_kernel), b4 / out-projection bias in the LayerNorm backward that emits the masked gradient (LnBwdParams::dsum) —
+    and every other gradient against the oracle fed the same masks, at bf16 tolerances."""
+    cfg = small_cfg(vit_depth=3, num_decoder_layers=1)
+    eng, weights = build(cfg, L.VCAD_BF16, emu)
+    B, T = 1, 2
+    eng.set_dropout(0.1, seed=77)
+    batch = synth.make_batch(B, T, seed=8)
+    ot = O.OracleTrainer(weights, cfg)
+    ot.masks = engine_masks(eng, cfg, B, T)
+    oloss, _, ocmds, opars = ot.loss_and_grads(batch)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    assert U.relerr(pars, opars) < 3e-2
+    eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    eng.backward()
+    errs = {}
+    for k in weights:
+        g = eng.view(k, eng.grads); og = ot.P[k].grad
+        if og is not None and float(og.norm()) > 0:
+            errs[k] = float((g - og).norm()) / float(og.norm())
+    fused = [k for k in errs if "state_embedding_model.transformer.layers" in k and k.endswith("bias") and (".net.1." in k or ".net.4." in k or "to_out" in k)]
+    assert len(fused) >= 3 * 3 - 0, sorted(errs)
+    assert max(errs[k] for k in fused) < 6e-2, {k: errs[k] for k in fused}
+    assert sorted(errs.values())[len(errs) // 2] < 3e-2 and max(errs.values()) < 0.25, max(errs.items(), key=lambda kv: kv[1])
+
+
 @pytest.mark.parametrize("pa,ps,tse", [(False, True, True), (True, False, False), (False, False, True)])
 def test_engine_other_wirings_match_oracle(emu, pa, ps, tse):
     """The other branches of AutoRegressiveTransformer.forward (reference :198-213): tgt = UI embeddings / memory, band-limited

@@ -394,7 +394,7 @@ struct Ctx {
     // `du` (optional): also emit the masked copy du = T(dx * mask(site d)) that masked() would produce from dx32 in a second pass
     int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
                const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C,
-               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr) const {
+               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr) const {
         LnBwdParams p; memset(&p, 0, sizeof(p));
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
@@ -402,7 +402,8 @@ struct Ctx {
             if (d.key) { void* dst = du_dst ? du_dst : L().t_dum; p.dxt = dst; p.lddxt = C; p.drop = d; *du = AT(dst, C); }
             else *du = A32(dx32, lddx);
         }
-        return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s);
+        // du_colsum: the bias gradient of the Linear that consumes du, reduced by this kernel instead of a column-sum pass over du
+        return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s, du ? du_colsum : nullptr);
     }
 };
 
@@ -514,20 +515,24 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         const long ldx = cls_only ? TD : D, ldao = cls_only ? TI : inner;
         // MLP (x' = xm + drop(W4 drop(gelu(z)) + b4)): the gradient entering W4 is dx * mask_out
         if (!have_du) CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));     // else: emitted by the layer above's LayerNorm backward
+        const bool have_db4 = have_du;
         have_du = false;
-        CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));
+        CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, have_db4 ? nullptr : cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));   // (b4's gradient: from the LayerNorm backward that emitted du)
+        bool have_db1 = false;
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
           const bool split = e->dt == VC_BF16 && g_split_gelu && !cls_only;      // bf16: plain dgrad, then the activation-derivative pass
           const Epi epg = split ? Epi() : ep;
           if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
           else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
-          if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s)); }
-        CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
+          // (the activation-derivative pass also reduces its output over rows: b1's gradient without a column-sum pass over dz)
+          if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), cx.L().scr_lnpart, cx.L().scr_lnpart_bytes, cx.L().scr_colsum));
+          have_db1 = split; }
+        CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, have_db1 ? nullptr : cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
         if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         else CK(cx.lin_dgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         // attention block (xm = x + drop(Wo ao + bo)): the LayerNorm backward also emits du = dx * mask_out
-        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du));
-        CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, cx.Gf(wl.ob), (int)Rm, D, inner));
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, nullptr, cx.Gf(wl.ob)));
+        CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
         if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         {
@@ -548,7 +553,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.lin_wgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
         if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
         else CK(cx.lin_dgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
-        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du)); have_du = true; }
+        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4))); have_du = true; }
         else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
     }
     if (part != 1) {

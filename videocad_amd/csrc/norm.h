@@ -160,16 +160,18 @@ struct LnBwdParams {
     float* partial;                   // [gridDim.x][2][C] dgamma / dbeta partial sums (fixed order => deterministic)
     long rows;
     int img, patch; int P; int u8;    // PATCH / EMBED mapping (EMBED: dy row = n*(P+1)+p+1 for x row n*P+p); u8 as in LnFwdParams
+    int dsum;                         // also reduce the emitted gradient (dxt if written, else dx32) over rows: third partial row = the bias
+                                      // gradient of the Linear that consumes it (saves that Linear's own column-sum pass over the tensor)
 };
 
 template <typename TD, typename TX, typename TY, int VPL, int MODE>
 VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     constexpr int C = 64 * VPL;
-    VC_SHARED float red[4][2][C];
+    VC_SHARED float red[4][3][C];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float dg[VPL], db[VPL], g[VPL];
+    float dg[VPL], db[VPL], ds[VPL], g[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < VPL; ++i) { dg[i] = 0.f; db[i] = 0.f; ds[i] = 0.f; }
     row_load<float, VPL>(p.gamma, g, lane);
     for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
         float x[VPL], dy[VPL];
@@ -206,15 +208,21 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
                 }
                 row_store<TY, VPL>((TY*)p.dxt + row * p.lddxt, dx, lane);
             }
+            if (p.dsum) {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) ds[i] += dx[i];                      // (fp32 values, before the store's rounding)
+            }
         }
     }
     if (p.partial) {
+        const int NR = p.dsum ? 3 : 2;
         row_store<float, VPL>(&red[wave][0][0], dg, lane);
         row_store<float, VPL>(&red[wave][1][0], db, lane);
+        row_store<float, VPL>(&red[wave][2][0], ds, lane);
         vc_sync();
-        const float* r0 = &red[0][0][0];                                          // [wave][2*C]
-        for (int i = threadIdx.x; i < 2 * C; i += 256)
-            p.partial[(long)blockIdx.x * 2 * C + i] = r0[i] + r0[2 * C + i] + r0[4 * C + i] + r0[6 * C + i];
+        const float* r0 = &red[0][0][0];                                          // [wave][3*C]
+        for (int i = threadIdx.x; i < NR * C; i += 256)
+            p.partial[(long)blockIdx.x * NR * C + i] = r0[i] + r0[3 * C + i] + r0[6 * C + i] + r0[9 * C + i];
     }
 }
 
@@ -359,6 +367,40 @@ VC_KERNEL __launch_bounds__(256) void dact_bwd_bf16_kernel(vc_bf16* dz, const vc
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = vc_apply_dact(v[k], s[k], kind);
     *reinterpret_cast<vc_u32x4*>(dz + i * 8) = vc_pack8(v);
+}
+
+// The same pass over whole rows, also reducing its output over rows (the bias gradient of the Linear whose pre-activation this is): thread =
+// one 8-column chunk, 256 / (cols / 8) rows per block step, grid-stride over rows; partial[block][cols] is summed by a column-sum pass over
+// <= 2048 rows instead of one over the whole tensor.  Needs 256 % (cols / 8) == 0.
+VC_KERNEL __launch_bounds__(256) void dact_bwd_bf16_rows_kernel(vc_bf16* dz, const vc_bf16* z, long rows, int cols, int kind, vc_drop d, float* partial) {
+    VC_SHARED float red[256 * 8];
+    const int c8n = cols / 8, rpb = 256 / c8n, r_in = threadIdx.x / c8n, c8 = threadIdx.x % c8n;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+    for (long row = (long)blockIdx.x * rpb + r_in; row < rows; row += (long)gridDim.x * rpb) {
+        const long i = row * c8n + c8;
+        float v[8], s[8];
+        vc_unpack8(*reinterpret_cast<const vc_u32x4*>(dz + i * 8), v);
+        vc_unpack8(*reinterpret_cast<const vc_u32x4*>(z + i * 8), s);
+        if (d.key) {
+            float m0[4], m1[4];
+            vc_drop_mul4(d, (uint32_t)(i * 8), m0); vc_drop_mul4(d, (uint32_t)(i * 8 + 4), m1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] *= m0[k]; v[4 + k] *= m1[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = vc_apply_dact(v[k], s[k], kind); acc[k] += v[k]; }
+        *reinterpret_cast<vc_u32x4*>(dz + i * 8) = vc_pack8(v);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[r_in * cols + c8 * 8 + k] = acc[k];
+    vc_sync();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float t = 0.0f;
+        for (int r = 0; r < rpb; ++r) t += red[r * cols + c];
+        partial[(long)blockIdx.x * cols + c] = t;
+    }
 }
 
 // ---- dst[c][r] = src[r][c] (bf16): the transposed weight shadows of the frame ViT (engine.hip: wT); 32x32 tiles through LDS

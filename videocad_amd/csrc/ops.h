@@ -55,7 +55,7 @@ int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s);
 // partial_ws: >= ln_bwd_blocks(rows) * 2 * C floats; dgamma/dbeta written (not accumulated)
 long vc_ln_bwd_blocks(long rows);
 int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* partial_ws, float* dgamma, float* dbeta,
-              float* colsum_ws, vc_stream_t s);
+              float* colsum_ws, vc_stream_t s, float* dsum_out = nullptr);   // dsum_out: column sums of the emitted gradient (norm.h LnBwdParams::dsum)
 // out[b][c] (=|+=) sum_r x[b][r][c];  ws >= batch * nchunk(rows) * cols floats
 long vc_colsum_chunks(long rows);
 int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
@@ -71,7 +71,9 @@ int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
 int vc_pack_x3(const float* x, uint32_t* y, long n, vc_stream_t s);       // y[i] = hi bf16(x[i]) << 16 | lo bf16(x[i] - hi)
 // g = dropout(act(z)) / dz = (dz * dropmask) * act'(z): compact bf16 [rows, cols], masks indexed like the fused GEMM epilogue
 int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_drop d, vc_stream_t s);
-int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s);
+int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out = nullptr, float* partial_ws = nullptr,
+                     size_t partial_bytes = 0, float* colsum_ws = nullptr);
+long vc_dact_bwd_blocks(long rows, int cols);
 // grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]

@@ -42,10 +42,12 @@ static int ln_bwd_m(int C, int mode, LnBwdParams p, unsigned nblk, vc_stream_t s
     vc_set_error("ln_bwd: bad mode %d", mode); return VC_ERR_ARG;
 }
 int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* partial_ws, float* dgamma, float* dbeta,
-              float* colsum_ws, vc_stream_t s) {
+              float* colsum_ws, vc_stream_t s, float* dsum_out) {
     if (p.rows <= 0) return VC_OK;
     const unsigned nblk = (unsigned)vc_ln_bwd_blocks(p.rows);
     p.partial = partial_ws;
+    p.dsum = dsum_out && partial_ws && (p.dx32 || p.dxt);
+    const long PS = (p.dsum ? 3L : 2L) * C;          // partial row stride
     ProfScope ps(VC_CAT_NORM, 0, (double)p.rows * C * ((td == VC_BF16 ? 2 : 4) + 4 + (p.add_in ? 4 : 0) + (p.dx32 ? 4 : 0)), s);
     int rc;
     if (td == VC_F32 && tx == VC_F32 && ty == VC_F32) rc = ln_bwd_m<float, float, float>(C, mode, p, nblk, s);
@@ -55,11 +57,12 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     if (rc) return rc;
     if (partial_ws) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C)
         if (dbeta == dgamma + C) {       // weight and bias adjacent in the flat gradient buffer: one reduction over 2C columns
-            rc = vc_colsum(VC_F32, partial_ws, 2L * C, nblk, 2 * C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+            rc = vc_colsum(VC_F32, partial_ws, PS, nblk, 2 * C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
         } else {
-            rc = vc_colsum(VC_F32, partial_ws, 2L * C, nblk, C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
-            rc = vc_colsum(VC_F32, partial_ws + C, 2L * C, nblk, C, dbeta, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+            rc = vc_colsum(VC_F32, partial_ws, PS, nblk, C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
+            rc = vc_colsum(VC_F32, partial_ws + C, PS, nblk, C, dbeta, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
         }
+        if (p.dsum) { rc = vc_colsum(VC_F32, partial_ws + 2 * C, PS, nblk, C, dsum_out, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc; }
     }
     return VC_OK;
 }
@@ -150,14 +153,27 @@ int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_dro
     VC_LAUNCH(act_fwd_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(n8, 256)), dim3(256), 0, s, (const vc_bf16*)z, (vc_bf16*)g, n8, act, d);
     return VC_OK;
 }
-int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s) {
+// colsum_out (optional): column sums of the result, i.e. the bias gradient of the Linear whose pre-activation z is; partial_ws holds
+// vc_dact_bwd_blocks(rows, cols) x cols floats, colsum_ws as for vc_colsum
+long vc_dact_bwd_blocks(long rows, int cols) { const long b = VC_CEIL_DIV(rows, (long)(256 / (cols / 8 > 0 ? cols / 8 : 1))); return b > 2048 ? 2048 : (b < 1 ? 1 : b); }
+int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out, float* partial_ws, size_t partial_bytes, float* colsum_ws) {
     if (rows <= 0) return VC_OK;
     if (int rc = act_check(dz, z, rows, cols, "dact_bwd")) return rc;
     if (kind == VC_ACT_GELU) kind = VC_ACT_GELU_FAST;
-    ProfScope ps(VC_CAT_OTHER, 0, (double)rows * cols * 6, s);
-    const long n8 = rows * cols / 8;
-    VC_LAUNCH(dact_bwd_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(n8, 256)), dim3(256), 0, s, (vc_bf16*)dz, (const vc_bf16*)z, n8, kind, d);
-    return VC_OK;
+    const int c8n = cols / 8;
+    const bool fused = colsum_out && c8n <= 256 && 256 % c8n == 0 && partial_ws && (size_t)vc_dact_bwd_blocks(rows, cols) * cols * 4 <= partial_bytes;
+    {
+        ProfScope ps(VC_CAT_OTHER, 0, (double)rows * cols * 6, s);
+        if (fused) {
+            VC_LAUNCH(dact_bwd_bf16_rows_kernel, dim3((unsigned)vc_dact_bwd_blocks(rows, cols)), dim3(256), 0, s, (vc_bf16*)dz, (const vc_bf16*)z, rows, cols, kind, d, partial_ws);
+        } else {
+            const long n8 = rows * cols / 8;
+            VC_LAUNCH(dact_bwd_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(n8, 256)), dim3(256), 0, s, (vc_bf16*)dz, (const vc_bf16*)z, n8, kind, d);
+        }
+    }
+    if (!colsum_out) return VC_OK;
+    if (fused) return vc_colsum(VC_F32, partial_ws, cols, vc_dact_bwd_blocks(rows, cols), cols, colsum_out, 0, 1, 0, 0, colsum_ws, s);
+    return vc_colsum(VC_BF16, dz, cols, rows, cols, colsum_out, 0, 1, 0, 0, colsum_ws, s);
 }
 
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s) {
