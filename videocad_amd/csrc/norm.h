@@ -167,7 +167,7 @@ struct LnBwdParams {
 template <typename TD, typename TX, typename TY, int VPL, int MODE>
 VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     constexpr int C = 64 * VPL;
-    VC_SHARED float red[4][3][C];
+    VC_SHARED float red[4][C];             // one partial row at a time (three rows at once cost the kernel a quarter of its occupancy)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float dg[VPL], db[VPL], ds[VPL], g[VPL];
 #pragma unroll
@@ -216,13 +216,15 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
     }
     if (p.partial) {
         const int NR = p.dsum ? 3 : 2;
-        row_store<float, VPL>(&red[wave][0][0], dg, lane);
-        row_store<float, VPL>(&red[wave][1][0], db, lane);
-        row_store<float, VPL>(&red[wave][2][0], ds, lane);
-        vc_sync();
-        const float* r0 = &red[0][0][0];                                          // [wave][3*C]
-        for (int i = threadIdx.x; i < NR * C; i += 256)
-            p.partial[(long)blockIdx.x * NR * C + i] = r0[i] + r0[3 * C + i] + r0[6 * C + i] + r0[9 * C + i];
+        auto flush = [&](const float (&v)[VPL], int part) {
+            row_store<float, VPL>(&red[wave][0], v, lane);
+            vc_sync();
+            for (int i = threadIdx.x; i < C; i += 256)
+                p.partial[((long)blockIdx.x * NR + part) * C + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+            vc_sync();
+        };
+        flush(dg, 0); flush(db, 1);
+        if (p.dsum) flush(ds, 2);
     }
 }
 
