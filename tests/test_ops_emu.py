@@ -28,6 +28,16 @@ def test_gemm_f32_layouts(emu, tra, trb):
     U.check_gemm(emu, "cpu", 70, 40, 50, F32, tra=tra, trb=trb, pad=3, bias=True, residual=True, splitk=False)
 
 
+@pytest.mark.parametrize("ct", [F32, U.X3, BF16])
+def test_gemm_column_group_sweep(emu, gemm_tile, ct):
+    """register-staged kernel, tile order in column groups (gemm.h n_group; automatic only when B overflows an L2): forced group widths that do and do
+    not divide the tile-column count, ragged edges — every tile must still be computed exactly once"""
+    if gemm_tile != 64:
+        pytest.skip("one tile size is enough (5 x 3 tiles of 64)")
+    for g in (1, 2, 3, 4):
+        U.check_gemm(emu, "cpu", 170, 300, 40, ct, trb=(g & 1), pad=4, bias=True, splitk=False, flags=L.gemm_ngroup(g), kernel=L.KERNEL_GEMM_REG)
+
+
 def test_gemm_f32_multi_tile_and_act(emu):
     U.check_gemm(emu, "cpu", 130, 136, 37, F32, act=1, bias=True, pad=4)
     U.check_gemm(emu, "cpu", 16, 5, 64, F32, act=3, bias=True, pad=0)

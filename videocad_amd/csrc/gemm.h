@@ -45,6 +45,7 @@ struct GemmParams {
     const float* residual; long ldr;                                      // fp32, may alias C
     vc_drop drop;                                                         // applied after act, before dact / residual (key 0 = off)
     int stagger;                                                          // first-wave start offset in units of s_sleep(127) (~3.4 us); 0 = off
+    int n_group;                                                          // register-staged kernel: tile columns per sweep (0 = all: n fastest over the whole width); see gemm_tile_program
     int debug_skip;                                                       // ablation only (tools/gemm_ablate.py): 1 = no global loads in the loop, 2 = no LDS stores, 4 = no MFMA
 };
 
@@ -441,7 +442,16 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
         const int total = nx * ny;
         const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;     // bijective for any total
-        tile_m = t / nx; tile_n = t - tile_m * nx;
+        if (p.n_group > 0 && p.n_group < nx) {
+            // column groups (r03): when the whole B operand does not fit an XCD's 4 MiB L2 (fp32 / bf16x3 QKV weights: 6.3 MB), a row-major
+            // sweep re-fetches B for every tile row (bf16x3 QKV forward: 4.4 GB fetched for 0.22 GB of operands, profiles/r03_x3_pmc.md).
+            // Sweep n_group tile columns at a time over ALL tile rows instead: that slice of B stays resident, A is read nx / n_group times.
+            const int gsz = p.n_group * ny, g = t / gsz, rem = t - g * gsz;
+            const int w = (g + 1) * p.n_group <= nx ? p.n_group : nx - g * p.n_group;
+            tile_m = rem / w; tile_n = g * p.n_group + rem - tile_m * w;
+        } else {
+            tile_m = t / nx; tile_n = t - tile_m * nx;
+        }
     }
     const int m0 = tile_m * GEMM_BM, n0 = tile_n * GEMM_BN;
 #ifndef VC_EMU

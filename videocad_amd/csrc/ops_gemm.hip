@@ -180,6 +180,19 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     p.partial = nsplit > 1 ? scratch : nullptr;
     c.p.k_per_split = small ? -kps : kps;          // sign carries the tile-size choice to gemm_launch (restored there)
 
+    // column groups of the register-staged kernel (gemm.h n_group): only where B overflows an XCD's L2 and re-reading A per group is the
+    // smaller evil (the fp32 / bf16x3 QKV forward: A 0.21 GB x 3 groups against B 6.3 MB x 800 tile rows)
+    c.p.n_group = 0;
+    if (lay <= 1 && nsplit == 1) {
+        const double esb = (double)dsize(c.sb), esa = (double)dsize(c.sa);
+        const double b_bytes = (double)p.N * p.K * esb, a_bytes = (double)p.M * p.K * esa;
+        const int bt = small ? 64 : 128, nx = VC_CEIL_DIV(p.N, bt), ny = VC_CEIL_DIV(p.M, bt);
+        if (b_bytes > 3.0e6 && ny >= 16) {
+            int gn = (int)(2.0e6 / ((double)bt * p.K * esb)); if (gn < 1) gn = 1;
+            if (gn < nx && a_bytes * VC_CEIL_DIV(nx, gn) < 0.5 * b_bytes * ny) c.p.n_group = gn;
+        }
+    }
+    if ((fl >> VC_GF_NGROUP_SHIFT) & 15u) c.p.n_group = (int)((fl >> VC_GF_NGROUP_SHIFT) & 15u);        // (tests)
     if (c.ct == VC_F32) return vc_gemm_launch_f32(c, nsplit, lay, s);
     if (c.ct == VC_X3) return vc_gemm_launch_x3(c, nsplit, lay, s);
     if (lay == 3) {            // wgrad: fp32 output always; either operand may be an fp32 tensor (converted while staging)

@@ -20,6 +20,10 @@ KERNEL_GEMM_DMA, KERNEL_GEMM_REG, KERNEL_GEMM_MID, KERNEL_GEMM_GROUPED = 1, 2, 3
 def gemm_xcd_cols(n):
     return int(n) << 8
 
+
+def gemm_ngroup(n):
+    return int(n) << 12
+
 NMETRIC = 32
 
 # metric slots (csrc/loss.h)
