@@ -36,6 +36,7 @@ typedef struct vcad_config {
     int dtype;                     /* VCAD_F32 | VCAD_BF16 | VCAD_BF16X3 */
     /* wiring flags of forward (reference model/autoregressive_transformer.py:149-213) */
     int enable_past_actions, enable_past_states, enable_timestep_embedding;
+    int num_views;          /* multiview branch (reference model/autoregressive_transformer.py:72-74,167-170): 0 = off (every final_experiments.json entry) */
 } vcad_config;
 
 typedef struct vcad_engine vcad_engine;
@@ -78,6 +79,8 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * vcad_workspace_bytes again).  Replaces nothing in the reference: BASELINE configs[4]'s "fp8 MFMA" variant. */
 int vcad_set_fp8(vcad_engine* e, int on);
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed);
+/* multiview images of the NEXT vcad_forward* call (engines with num_views > 0): [B][num_views] gray planes in the CAD image's pixel format, contiguous */
+int vcad_set_multiview(vcad_engine* e, const void* images);
 /* keep-multipliers of one site, recomputed from (seed, site, index); a pure function of the engine's dropout setting (the parity tests hand them to the oracle)
  *  (module 1 = frame ViT, 2 = CAD ViT, 3 = decoder; kind ids in engine.hip) -> HOST buffer */
 int vcad_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out);

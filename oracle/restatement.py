@@ -84,8 +84,11 @@ def param_shapes(cfg: dict = CANONICAL_CONFIG) -> Dict[str, Tuple[int, ...]]:
         s[pre + "transformer.norm.bias"] = (D,)
     s["embed_state.weight"] = (H, D); s["embed_state.bias"] = (H,)
     s["embed_image.weight"] = (H, D); s["embed_image.bias"] = (H,)
-    num_inputs = 1 + (1 if cfg.get("enable_past_states", True) else 0)       # autoregressive_transformer.py:68-76
+    V = cfg.get("num_views", 0)
+    num_inputs = 1 + (1 if cfg.get("enable_past_states", True) else 0) + (1 if V > 0 else 0)       # autoregressive_transformer.py:68-76
     s["image_projection.weight"] = (H, num_inputs * H); s["image_projection.bias"] = (H,)
+    if V > 0:
+        s["embed_multiview.weight"] = (H, D * V); s["embed_multiview.bias"] = (H,)               # :72-74
     s["embed_action.weight"] = (H, cfg["act_dim"]); s["embed_action.bias"] = (H,)
     if cfg.get("enable_timestep_embedding", True):
         s["timestep_embedding.weight"] = (cfg["max_ep_len"], H)
@@ -201,11 +204,12 @@ def decoder_forward(P: dict, tgt: Tensor, mem: Tensor, cfg: dict, taps: Optional
 
 
 # ----------------------------------------------------------------------------------------
-# full forward (canonical wiring: past actions + past states + timestep embedding, no multiview)
+# full forward (all wirings; the optional multiview branch included)
 # ----------------------------------------------------------------------------------------
 
 def model_forward(P: dict, frames: Tensor, actions_norm: Tensor, cad: Tensor,
-                  cfg: dict = CANONICAL_CONFIG, taps: Optional[dict] = None, masks: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+                  cfg: dict = CANONICAL_CONFIG, taps: Optional[dict] = None, masks: Optional[dict] = None,
+                  multiview: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """frames [B,T,1,S,S], actions_norm [B,T,7] (already normalised), cad [B,1,S,S]
     -> cmds [B,T,5], params [B,T,6,1000]   (autoregressive_transformer.py:121-220)."""
     B, T = actions_norm.shape[:2]
@@ -220,6 +224,11 @@ def model_forward(P: dict, frames: Tensor, actions_norm: Tensor, cad: Tensor,
             images.append(ui)
     c = vit_forward(P, "cad_embedding_model.", cad, cfg, taps, masks)                                        # :162
     images.append(F.linear(c, P["embed_image.weight"], P["embed_image.bias"]).unsqueeze(1).repeat(1, T, 1))  # :163-164
+    V = cfg.get("num_views", 0)
+    if multiview is not None and V > 0:                                                                     # :167-170 (trajectory_model.py:77-87)
+        mv = vit_forward(P, "cad_embedding_model.", multiview.reshape(B * V, *multiview.shape[2:]), cfg, None, masks)
+        mv = mv.reshape(B, V, -1).unsqueeze(1).expand(-1, T, -1, -1).reshape(B, T, -1)
+        images.append(F.linear(mv, P["embed_multiview.weight"], P["embed_multiview.bias"]))
     mem = torch.cat(images, dim=-1)
     if len(images) > 1:
         mem = F.linear(mem, P["image_projection.weight"], P["image_projection.bias"])                       # :172-174
@@ -363,7 +372,9 @@ class OracleTrainer:
         frames = torch.as_tensor(batch["frames"], dtype=torch.float32)
         actions = torch.as_tensor(batch["actions"], dtype=torch.float32)
         cad = torch.as_tensor(batch["cad_image"], dtype=torch.float32)
-        cmds, params = model_forward(self.P, frames[:, :-1], normalize_actions(actions[:, :-1]), cad, self.cfg, taps, self.masks)
+        mv = batch.get("multiview_images", None)
+        mv = torch.as_tensor(mv, dtype=torch.float32) if mv is not None else None
+        cmds, params = model_forward(self.P, frames[:, :-1], normalize_actions(actions[:, :-1]), cad, self.cfg, taps, self.masks, mv)
         return cmds, params, actions[:, 1:]
 
     def loss_and_grads(self, batch: dict):

@@ -109,7 +109,63 @@ def eval_cases(model, mk, weights):
     return {"sequences": len(ffm[0]["Sequence Lengths"]), "total_predictions": metrics["total_predictions"]}
 
 
+def multiview_case(scratch):
+    """f4 remainder (r03): the multiview branch (reference model/autoregressive_transformer.py:72-74,167-170; trajectory_model.py:77-87).  Config = the
+    canonical entry with `num_views: 2` (the value of the reference's `multiview_params`; its own multiview entries use the resnet encoder, which is out
+    of scope).  One train step of the IMPORTED reference with two random views per clip: logits, loss, gradient norms."""
+    cfg_name = "cad_past_10_actions_and_states_multiview_2"
+    rcfg = json.load(open(os.path.join(HERE, "model_configs.json")))[cfg_name]
+    ocfg = dict(O.CANONICAL_CONFIG); ocfg.update(num_views=rcfg["num_views"])
+    wts = {k: synth.make_param(k, s) for k, s in O.param_shapes(ocfg).items()}
+    modelx, mkx, _ = build_reference(cfg_name, wts, scratch)
+    trx = mkx(True)
+    B, T, seed = 2, 6, 9
+    batch_np = synth.make_batch(B, T, seed, num_views=rcfg["num_views"])
+    batch = tbatch(batch_np)
+    modelx.eval()
+    with torch.no_grad():
+        bd = trx.prepare_batch(batch)
+        cmds, params = modelx(trx._prepare_model_inputs(bd, False))
+    gradsx = {}
+    orig_clip = torch.nn.utils.clip_grad_norm_
+    def spyx(parameters, max_norm, *a, **k):
+        for n, p in modelx.named_parameters():
+            if p.grad is not None and n in wts:
+                gradsx[n] = p.grad.detach().clone()
+        out = orig_clip(modelx.parameters(), max_norm, *a, **k)
+        gradsx["__total_norm__"] = out.detach().clone()
+        return out
+    torch.nn.utils.clip_grad_norm_ = spyx
+    loss_s, metrics = trx._process_batch(batch)
+    torch.nn.utils.clip_grad_norm_ = orig_clip
+    ot = O.OracleTrainer(wts, ocfg)
+    oloss, ometrics, ocmds, oparams = ot.loss_and_grads(batch_np)
+    live = sorted(k for k in gradsx if k != "__total_norm__")
+    olive = sorted(k for k, p in ot.P.items() if p.grad is not None)
+    dev = {"cmds_rel": rel(ocmds, cmds), "params_rel": rel(oparams, params), "loss_abs": abs(float(oloss) - float(loss_s)),
+           "live_sets_equal": live == olive, "metrics_equal": ometrics == metrics,
+           "grad_rel_max": max(rel(ot.P[k].grad, gradsx[k]) for k in live if gradsx[k].norm() > 0)}
+    print("multiview_2", json.dumps(dev))
+    assert dev["cmds_rel"] < 1e-5 and dev["params_rel"] < 1e-5 and dev["live_sets_equal"] and dev["grad_rel_max"] < 1e-3, dev
+    np.savez_compressed(os.path.join(HERE, "multiview_2.npz"), cmds=cmds.numpy(), params=params[:, :, :, ::8].numpy().copy(),
+                        params_argmax=params.argmax(-1).numpy(), loss=np.float32(loss_s.item()),
+                        total_grad_norm=np.float32(gradsx["__total_norm__"].item()), grad_names=np.array(live),
+                        grad_norms=np.array([float(gradsx[k].double().norm()) for k in live], dtype=np.float64),
+                        grad_embed_multiview=sl(gradsx["embed_multiview.weight"], 256), grad_image_projection=sl(gradsx["image_projection.weight"], 256),
+                        metrics_json=np.array(json.dumps(metrics)))
+    return {"config": cfg_name, "B": B, "T": T, "seed": seed, "num_views": rcfg["num_views"], "oracle_vs_reference": dev}
+
+
 def main():
+    if "--only-multiview" in sys.argv:                  # tests/golden/multiview_2.npz alone (the full run writes the same file)
+        scratch = tempfile.mkdtemp(prefix="vcad_golden_")
+        shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
+        os.chdir(scratch)
+        info = multiview_case(scratch)
+        meta = json.load(open(os.path.join(HERE, "meta.json"))); meta["cases"]["multiview_2"] = info
+        json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
     if "--only-eval" in sys.argv:                       # regenerate tests/golden/eval_cases.json alone (the full run writes the same file)
         scratch = tempfile.mkdtemp(prefix="vcad_golden_")
         shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
@@ -317,6 +373,7 @@ def main():
 
     # ------------------------------------------------------------------ evaluation bookkeeping of the reference trainer
     meta["cases"]["eval_cases"] = eval_cases(model, mk, weights)
+    meta["cases"]["multiview_2"] = multiview_case(scratch)
 
     # ------------------------------------------------------------------ loss-only cases on synthetic logits
     tr = mk(True); trn = mk(False)

@@ -115,6 +115,44 @@ def test_autograd_bridge_and_trainer_step_under_emulator(emu, tmp_path, monkeypa
     assert d < 2e-6, d
 
 
+def test_multiview_model_through_factory_and_trainer_under_emulator(emu, tmp_path, monkeypatch):
+    """The multiview branch at the reference's surface: `num_views` in the JSON entry, `multiview_images` in the loader's batch (reference
+    trainer.py:320-322,515-516) -> create_model / create_trainer / model(inputs) / _process_batch; numbers against the oracle."""
+    monkeypatch.chdir(tmp_path)
+    _cwd_with_class_weights(tmp_path)
+    cfg, ocfg = small_model(emu, num_views=2)
+    ocfg["num_views"] = 2
+    model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
+    assert model.num_views == 2 and model.num_inputs == 3 and tuple(model.embed_multiview.weight.shape) == (1024, 1024)
+    weights = {k: synth.make_param(k, s) for k, s in O.param_shapes(ocfg).items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()}, strict=True)
+    model.eval()
+    batch = synth.make_batch(1, 2, seed=14, num_views=2)
+    tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
+    pk = {"loader": [tb], "sampler": None}
+    tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=0)
+    ot = O.OracleTrainer(weights, ocfg)
+    oloss, ometrics, ocmds, opars = ot.loss_and_grads(batch)
+    bd = tr.prepare_batch(tb)
+    inputs = tr._prepare_model_inputs(bd, False)
+    assert inputs["multiview_images"].shape == (1, 2, 1, 224, 224)
+    preds = model(inputs)
+    assert U.relerr(preds[1], opars) < 1e-5
+    with pytest.raises(RuntimeError, match="multiview"):
+        model({k: v for k, v in inputs.items() if k != "multiview_images"})
+    loss, metrics = tr.compute_loss(preds, bd["actions"][:, 1:])
+    loss.backward()
+    worst = max((U.relerr(p.grad, ot.P[n].grad), n) for n, p in model.named_parameters() if float(ot.P[n].grad.norm()) > 0)
+    assert worst[0] < 2e-4, worst
+    ot.apply_grads({k: p.grad for k, p in ot.P.items()})
+    loss2, metrics2 = tr._process_batch(tb)
+    assert abs(float(loss2) - float(oloss)) < 1e-5 * abs(float(oloss)) and metrics2 == ometrics
+    d = max(float((p.detach() - ot.P[n].detach()).abs().max()) for n, p in model.named_parameters())
+    assert d < 2e-6, d
+    with pytest.raises(RuntimeError, match="multiview"):
+        model.sequential_inference(bd["frames"][:, :-1], bd["cad_image"])          # as in the reference, inference has no multiview input
+
+
 def _ddp_worker(rank, world, port, tmp, q):
     import torch.distributed as dist
     _cwd_with_class_weights(tmp)

@@ -251,6 +251,55 @@ def test_engine_bf16_backward_fused_bias_gradients(emu):
     assert sorted(errs.values())[len(errs) // 2] < 3e-2 and max(errs.values()) < 0.25, max(errs.items(), key=lambda kv: kv[1])
 
 
+@pytest.mark.parametrize("pa,ps,V,dtype", [(True, True, 2, L.VCAD_F32), (True, False, 3, L.VCAD_F32), (False, False, 1, L.VCAD_F32), (True, True, 2, L.VCAD_BF16X3)])
+def test_engine_multiview_branch_matches_oracle(emu, pa, ps, V, dtype):
+    """Multiview branch (reference model/autoregressive_transformer.py:72-74,167-170; trajectory_model.py:77-87): V views per clip through the CAD
+    tower, embed_multiview on their concatenated cls vectors, one more image_projection input — forward, loss and EVERY gradient (the CAD tower's
+    now come from B (1 + V) images) against the oracle; Adam step on top."""
+    cfg = small_cfg(vit_depth=2, num_decoder_layers=1, enable_past_actions=pa, enable_past_states=ps, num_views=V)
+    shapes = O.param_shapes(cfg)
+    assert shapes["embed_multiview.weight"] == (1024, 512 * V) and shapes["image_projection.weight"] == (1024, 1024 * (2 + int(ps)))
+    weights = {k: synth.make_param(k, s) for k, s in shapes.items()}
+    keys = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
+            "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size",
+            "enable_past_actions", "enable_past_states", "enable_timestep_embedding", "num_views")
+    eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in keys}), "cpu")
+    assert set(eng.table) == set(shapes) and all(eng.table[k][2] == tuple(shapes[k]) for k in shapes)
+    for k, w in weights.items():
+        eng.view(k).copy_(torch.from_numpy(w))
+    eng.sync_shadow()
+    B, T = 2, 3
+    batch = synth.make_batch(B, T, seed=31, num_views=V)
+    ot = O.OracleTrainer(weights, cfg)
+    oloss, ometrics, ocmds, opars = ot.loss_and_grads(batch)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    mv = torch.from_numpy(batch["multiview_images"])
+    with pytest.raises(RuntimeError, match="multiview"):
+        eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)               # a multiview model needs its views
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad, mv)
+    tol = 1e-5 if dtype == L.VCAD_F32 else 5e-5
+    assert U.relerr(pars, opars) < tol and U.relerr(cmds, ocmds) < tol, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - float(oloss)) < 1e-4 * max(1.0, abs(float(oloss)))
+    eng.backward()
+    worst = ("", 0.0)
+    for k in weights:
+        g = eng.view(k, eng.grads); og = ot.P[k].grad
+        if og is None:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        denom = float(og.norm())
+        err = float((g - og).norm()) / (denom + 1e-12) if denom > 0 else float(g.abs().max())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < (2e-4 if dtype == L.VCAD_F32 else 1e-3), worst
+    assert float(ot.P["embed_multiview.weight"].grad.norm()) > 0 and float(eng.view("embed_multiview.weight", eng.grads).norm()) > 0
+    # the views matter: other views -> other logits
+    mv2 = torch.from_numpy(synth.make_batch(B, T, seed=32, num_views=V)["multiview_images"])
+    c2, p2 = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad, mv2)
+    assert U.relerr(p2, pars) > 1e-4
+
+
 @pytest.mark.parametrize("pa,ps,tse", [(False, True, True), (True, False, False), (False, False, True)])
 def test_engine_other_wirings_match_oracle(emu, pa, ps, tse):
     """The other branches of AutoRegressiveTransformer.forward (reference :198-213): tgt = UI embeddings / memory, band-limited

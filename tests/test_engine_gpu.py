@@ -369,6 +369,48 @@ def test_f32_other_wirings_match_reference_goldens(golden_dir, case):
     assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < 1e-3 * float(gold["total_grad_norm"])
 
 
+@pytest.mark.parametrize("dtype,tol,gtol", [(L.VCAD_F32, 1e-4, 2e-3), (L.VCAD_BF16X3, 1e-4, 3e-3), (L.VCAD_BF16, 6e-3, 6e-2)])
+def test_multiview_branch_matches_reference_goldens(golden_dir, dtype, tol, gtol):
+    """f4 remainder: the multiview branch (reference model/autoregressive_transformer.py:72-74,167-170) on the canonical model with num_views = 2 against
+    one train step of the imported reference (tests/golden/multiview_2.npz): logits, arg-max (exact in f32 / bf16x3), loss, every gradient norm —
+    the CAD tower runs B (1 + V) images here, embed_multiview and the third image_projection block are live."""
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["cases"]["multiview_2"]
+    gold = np.load(os.path.join(golden_dir, "multiview_2.npz"))
+    V = meta["num_views"]
+    cfg = dict(O.CANONICAL_CONFIG); cfg.update(num_views=V)
+    eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in CFG_KEYS + ("num_views",)}), DEV)
+    shapes = O.param_shapes(cfg)
+    assert set(eng.table) == set(shapes)
+    for k, sh in shapes.items():
+        eng.view(k).copy_(synth.make_param_torch(k, sh, DEV))
+    eng.sync_shadow()
+    batch = synth.make_batch_torch(meta["B"], meta["T"], meta["seed"], DEV, None, num_views=V)
+    frames, actions, cad, mv = batch["frames"], batch["actions"], batch["cad_image"], batch["multiview_images"]
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad, mv)
+    gc = torch.from_numpy(gold["cmds"]).to(DEV); gp = torch.from_numpy(gold["params"]).to(DEV)
+    assert U.relerr(cmds, gc) < tol and U.relerr(pars[:, :, :, ::8], gp) < tol, (U.relerr(cmds, gc), U.relerr(pars[:, :, :, ::8], gp))
+    agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
+    assert agree == 1.0 if dtype != L.VCAD_BF16 else agree >= 0.95, agree
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - float(gold["loss"])) < (1e-4 if dtype != L.VCAD_BF16 else 2e-2) * abs(float(gold["loss"]))
+    eng.backward()
+    errs = []
+    for n, gn in zip([str(x) for x in gold["grad_names"]], gold["grad_norms"]):
+        errs.append((abs(float(eng.view(n, eng.grads).double().norm()) - gn) / (gn + 1e-12), n))
+    assert max(errs)[0] < gtol * (1 if dtype != L.VCAD_BF16 else 4) and sorted(errs)[len(errs) // 2][0] < gtol, max(errs)
+    # sampled gradient elements of the two tensors only this branch touches
+    for key, name in (("grad_embed_multiview", "embed_multiview.weight"), ("grad_image_projection", "image_projection.weight")):
+        assert U.relerr(torch.from_numpy(sl(eng.view(name, eng.grads), 256)), torch.from_numpy(gold[key])) < (5e-3 if dtype != L.VCAD_BF16 else 0.15), name
+    # uint8 pixels for all three image inputs: the CAD-tower staging copies bytes, the patchify kernel normalises (same result as fp32 of the same pixels)
+    if dtype == L.VCAD_F32:
+        u8 = lambda t: ((t * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8)
+        f8, c8, m8 = u8(frames[:, :-1]), u8(cad), u8(mv)
+        back = lambda t: ((t.cpu().to(torch.float32) / 255.0 - 0.5) / 0.5).to(DEV)      # on the host: IEEE division, as the kernel does (torch's GPU division by a constant is not)
+        ca, pa_ = eng.forward(f8, O.normalize_actions(actions[:, :-1]), c8, m8)
+        cb, pb = eng.forward(back(f8), O.normalize_actions(actions[:, :-1]), back(c8), back(m8))
+        assert torch.equal(pa_, pb) and torch.equal(ca, cb)
+
+
 def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
     """The data-parallel order (stage 0, stage 1 on the side stream, stages 2-3, join) must produce exactly the gradients of
     the single-call backward: same kernels, only the stream they are issued on differs."""

@@ -118,3 +118,21 @@ def test_oracle_other_wirings_match_reference_goldens(case):
     assert live == [str(n) for n in g["grad_names"]] and sorted(set(ot.P) - set(live)) == meta["dead_parameters"]
     for n, gn in zip(live, g["grad_norms"]):
         assert abs(float(ot.P[n].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-10, n
+
+
+def test_oracle_multiview_branch_matches_reference_goldens():
+    """f4 remainder: the multiview branch (reference model/autoregressive_transformer.py:72-74,167-170) — oracle against one train step of the imported
+    reference with num_views = 2 (tests/golden/multiview_2.npz, make_goldens.py multiview_case)."""
+    meta = json.load(open(os.path.join(GOLD, "meta.json")))["cases"]["multiview_2"]
+    g = np.load(os.path.join(GOLD, "multiview_2.npz"))
+    cfg = dict(O.CANONICAL_CONFIG); cfg.update(num_views=meta["num_views"])
+    ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in O.param_shapes(cfg).items()}, cfg)
+    loss, metrics, cmds, params = ot.loss_and_grads(synth.make_batch(meta["B"], meta["T"], meta["seed"], num_views=meta["num_views"]))
+    ref = torch.from_numpy(g["params"])
+    assert float((params[:, :, :, ::8] - ref).norm() / ref.norm()) < 5e-6
+    assert float((cmds - torch.from_numpy(g["cmds"])).norm() / torch.from_numpy(g["cmds"]).norm()) < 5e-6
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"])) and metrics == json.loads(str(g["metrics_json"]))
+    live = sorted(k for k, p in ot.P.items() if p.grad is not None)
+    assert live == [str(n) for n in g["grad_names"]] and "embed_multiview.weight" in live
+    for n, gn in zip(live, g["grad_norms"]):
+        assert abs(float(ot.P[n].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-10, n

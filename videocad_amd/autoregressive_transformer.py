@@ -11,7 +11,7 @@ Differences that are deliberate and documented in DESIGN.md:
     Adam and the RCCL all-reduce run over contiguous memory
   * every wiring of forward (:149-213) is native: past actions and/or past states, with or without the timestep embedding;
     parameters a wiring never touches (e.g. image_projection without both flags) keep a zero gradient and are left unchanged
-    by the optimiser, as in the reference where their .grad stays None; encoder != "vit" and the multiview branch raise
+    by the optimiser, as in the reference where their .grad stays None; encoder != "vit" raises
   * dropout is a stateless counter-based mask (hash of step seed, site, element index) regenerated in the backward:
     statistically equivalent to nn.Dropout at the same sites, not bit-identical to torch's Philox stream
 There is no CPU fallback: calling forward on a non-CUDA module raises.
@@ -56,8 +56,8 @@ class _EngineFn(torch.autograd.Function):
     are handed to autograd as views, so `loss.backward()`, `clip_grad_norm_` and torch optimisers work unchanged)."""
 
     @staticmethod
-    def forward(ctx, model, frames, actions, cad, *params):
-        cmds, pars = model._engine.forward(frames, actions, cad)
+    def forward(ctx, model, frames, actions, cad, mv, *params):
+        cmds, pars = model._engine.forward(frames, actions, cad, mv)
         ctx.model = model
         ctx.fwd_id = model._engine.fwd_serial       # ANY later engine forward (no_grad / eval forwards, trainer.train_step, evaluate, cached
         return cmds, pars                           # inference) bumps it: a backward through this node then raises instead of using their activations
@@ -74,7 +74,7 @@ class _EngineFn(torch.autograd.Function):
         # backward into it in place, so hand it a private copy (one flat clone, parameters are views of it)
         flat = eng.grads.clone()
         grads = tuple(eng.view(n, flat) for n in model._param_names)
-        return (None, None, None, None) + grads
+        return (None, None, None, None, None) + grads
 
 
 class AutoRegressiveTransformer(nn.Module):
@@ -88,15 +88,16 @@ class AutoRegressiveTransformer(nn.Module):
         if encoder != "vit" or use_pretrained_cad_model:
             raise NotImplementedError(f"encoder={encoder!r}/gencad is out of scope of the MI355X path (needs torchvision weights; "
                                       "reference model/trajectory_model.py:68-74)")
-        if num_views:
-            raise NotImplementedError("multiview branch (reference :167-170) is not on the hot path (SURVEY §8 f4)")
+        if num_views and enable_past_states and not enable_past_actions:
+            raise NotImplementedError("num_views > 0 with past states but no past actions: the reference's image_projection fan-in (:69-76) does not match "
+                                      "the inputs it concatenates (:158-170) in that wiring")
         self.state_dim, self.act_dim, self.hidden_size = state_dim, act_dim, hidden_size
         self.max_length, self.max_ep_len = max_length, max_ep_len
         self.enable_past_actions, self.enable_past_states = enable_past_actions, enable_past_states
         self.enable_timestep_embedding = enable_timestep_embedding
         self.window_size, self.normalize, self.num_views = window_size, normalize, num_views
         self.use_pretrained_cad_model = use_pretrained_cad_model
-        self.num_inputs = 1 + (1 if enable_past_states else 0)              # reference :67-76
+        self.num_inputs = 1 + (1 if enable_past_states else 0) + (1 if num_views > 0 else 0)      # reference :67-76
         self.state_embedding_model_size = self.cad_embedding_model_size = 512
         self.dropout_p = dropout
         self.compute_dtype = compute_dtype
@@ -107,7 +108,7 @@ class AutoRegressiveTransformer(nn.Module):
                           dim_feedforward=dim_feedforward, window_size=window_size, act_dim=act_dim, num_classes=num_classes,
                           num_params=num_params, num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dt,
                           enable_past_actions=enable_past_actions, enable_past_states=enable_past_states,
-                          enable_timestep_embedding=enable_timestep_embedding,
+                          enable_timestep_embedding=enable_timestep_embedding, num_views=num_views,
                           **{k: kwargs[k] for k in ("vit_depth",) if k in kwargs})    # extension (tests): shallower ViT
         self._engine = NativeEngine(cfg, "cpu")
         self._param_names = list(self._engine.table.keys())
@@ -217,8 +218,10 @@ class AutoRegressiveTransformer(nn.Module):
         """inputs: dict with 'frames' [B,T,1,224,224], 'actions' [B,T,7] (normalised), 'cad_image' [B,1,224,224]
         ('timesteps' is ignored exactly as in the reference, :144).  Returns (cmds [B,T,5], params [B,T,6,1000])."""
         frames, actions, cad = inputs["frames"], inputs["actions"], inputs["cad_image"]
-        if inputs.get("multiview_images", None) is not None and self.num_views > 0:
-            raise NotImplementedError("multiview")
+        mv = inputs.get("multiview_images", None) if self.num_views > 0 else None      # reference :141,167: used only when both are set
+        if self.num_views > 0 and mv is None:
+            raise RuntimeError(f"model built with num_views = {self.num_views}: inputs['multiview_images'] [B, V, 1, S, S] is required "
+                               "(the reference's image_projection would fail on the missing input)")
         if self._engine.params.device.type != "cuda" and b"gfx950" in self._engine.lib.vcad_version():
             raise RuntimeError("videocad_amd has no CPU fallback: move the model to a ROCm device (model.to('cuda'))")
         if not self._shadow_fresh:
@@ -227,11 +230,12 @@ class AutoRegressiveTransformer(nn.Module):
         self._arm_dropout()
         if frames.dtype != torch.uint8:                          # uint8 pixel batches are normalised inside the patchify kernel
             frames = frames.float(); cad = cad.float()
+            mv = mv.float() if mv is not None else None
         actions = actions.float()
         if torch.is_grad_enabled():
-            cmds, pars = _EngineFn.apply(self, frames, actions, cad, *self._plist)
+            cmds, pars = _EngineFn.apply(self, frames, actions, cad, mv, *self._plist)
         else:
-            cmds, pars = self._engine.forward(frames, actions, cad)
+            cmds, pars = self._engine.forward(frames, actions, cad, mv)
         return cmds, pars
 
     @torch.no_grad()

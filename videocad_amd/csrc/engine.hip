@@ -73,6 +73,9 @@ struct vcad_engine {
     // ---- per-(B,T) plan
     int B = 0, T = 0; bool fwd_valid = false;
     const void* in_frames = nullptr; long in_fbstride = 0; const float* in_actions = nullptr; const void* in_cad = nullptr;
+    // multiview branch (reference model/autoregressive_transformer.py:72-74,167-170): V views per clip run through the CAD tower with the CAD image
+    // (one batch of B (1 + V) images, staged contiguously), embed_multiview maps their concatenated cls vectors to one more image_projection input
+    const void* in_mv = nullptr; void* cadmv = nullptr; void* mvE = nullptr; float* t_dmvE = nullptr; long o_mv_w = -1, o_mv_b = -1;
     int in_u8 = 0;                // frames / cad are uint8 grayscale pixels, normalised inside the patchify kernels (vcad_forward_u8)
     VitActs va[2]; std::vector<DecLayerActs> da;
     float *ui, *cadterm, *mem, *act; void* cadE;
@@ -174,7 +177,9 @@ void build_params(vcad_engine* e) {
     }
     e->o_ea_w = add_param(e, "embed_action.weight", {H, (long)c.act_dim}); e->o_ea_b = add_param(e, "embed_action.bias", {H});
     e->o_ts = c.enable_timestep_embedding ? add_param(e, "timestep_embedding.weight", {(long)c.max_ep_len, H}) : -1;
-    e->o_ip_w = add_param(e, "image_projection.weight", {H, (c.enable_past_states ? 2 : 1) * H}); e->o_ip_b = add_param(e, "image_projection.bias", {H});
+    // image_projection's fan-in is the reference's num_inputs = CAD + (past states) + (multiview), model/autoregressive_transformer.py:69-76
+    e->o_ip_w = add_param(e, "image_projection.weight", {H, (1 + (c.enable_past_states ? 1 : 0) + (c.num_views > 0 ? 1 : 0)) * H}); e->o_ip_b = add_param(e, "image_projection.bias", {H});
+    if (c.num_views > 0) { e->o_mv_w = add_param(e, "embed_multiview.weight", {H, (long)c.vit_dim * c.num_views}); e->o_mv_b = add_param(e, "embed_multiview.bias", {H}); }
     e->o_ei_w = add_param(e, "embed_image.weight", {H, (long)c.vit_dim}); e->o_ei_b = add_param(e, "embed_image.bias", {H});
     e->o_es_w = add_param(e, "embed_state.weight", {H, (long)c.vit_dim}); e->o_es_b = add_param(e, "embed_state.bias", {H});
     e->buckets.push_back({b0, e->ptotal});
@@ -211,7 +216,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     const long g = c.image_size / c.patch_size, P = g * g, pd = (long)c.patch_size * c.patch_size;
     for (int v = 0; v < 2; ++v) {
         VitActs& a = e->va[v];
-        a.N = v == 0 ? M : B;
+        a.N = v == 0 ? M : (long)B * (1 + c.num_views);
         const long R = a.N * (P + 1), Rp = a.N * P;
         a.pn = b.take<void>(Rp * pd * es); a.pstat = b.take<float>(Rp * 2 * 4); a.pe = b.take<float>(Rp * D * 4);
         a.stat2 = b.take<float>(Rp * 2 * 4); a.x0 = b.take<float>(R * D * 4);
@@ -225,6 +230,10 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         a.statn = b.take<float>(a.N * 2 * 4); a.e = b.take<void>(a.N * D * es);
     }
     e->ui = b.take<float>(M * H * 4); e->cadE = b.take<void>((long)B * H * es); e->cadterm = b.take<float>((long)B * H * 4);
+    if (c.num_views > 0) {
+        e->cadmv = b.take<void>((long)B * (1 + c.num_views) * c.image_size * c.image_size * 4); e->mvE = b.take<void>((long)B * H * es);
+        e->t_dmvE = b.take<float>((long)B * H * 4);
+    }
     e->mem = b.take<float>(M * H * 4); e->act = b.take<float>(M * H * 4);
     e->da.resize(c.num_decoder_layers);
     for (auto& d : e->da) {
@@ -246,7 +255,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     // backward temporaries + scratch, per lane: lane 0 (caller's stream) sized for the frame ViT / decoder, lane 1 (side stream) for the CAD ViT
     for (int ln = 0; ln < 2; ++ln) {
         Lane& l = e->lane[ln];
-        const long Nv = ln == 0 ? M : (long)B;                       // images this lane's ViT sees
+        const long Nv = ln == 0 ? M : (long)B * (1 + c.num_views);   // images this lane's ViT sees
         const long R = Nv * (P + 1), Rp = Nv * P;
         l.t_dx = b.take<float>(R * D * 4); l.t_dpe = b.take<float>(Rp * D * 4); l.t_dz = b.take<void>(R * c.vit_mlp * es);
         l.t_dh = b.take<void>(R * D * es); l.t_dao = b.take<void>(R * inner * es); l.t_dqkv = b.take<void>(R * 3 * inner * es);
@@ -264,7 +273,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     if (e->fp8) { e->q8w = b.take<uint8_t>(e->ptotal); e->q8ws = b.take<uint8_t>(e->ptotal / 32 + 64); }
     e->t_dmem = b.take<float>(M * H * 4); e->t_dcur = b.take<float>(M * H * 4); e->t_dui = b.take<float>(M * H * 4); e->t_dpre = b.take<float>(M * H * 4);
     e->t_dcadterm = b.take<float>((long)B * H * 4); e->t_dcadE = b.take<float>((long)B * H * 4);
-    e->t_dec = b.take<float>((long)B * D * 4); e->t_des = b.take<float>(M * D * 4);
+    e->t_dec = b.take<float>((long)B * (1 + c.num_views) * D * 4); e->t_des = b.take<float>(M * D * 4);
     e->t_df1 = b.take<void>(M * c.dim_feedforward * es); e->t_dq = b.take<void>(M * H * es); e->t_dkv = b.take<void>(M * 2 * H * es);
     e->t_dao_d = b.take<void>(M * H * es); e->t_dqkv_d = b.take<void>(M * 3 * H * es);
     e->loss_rows = b.take<float>(M * 7 * 3 * 4); e->loss_arg = b.take<int>(M * 7 * 4);
@@ -612,7 +621,16 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     const bool fork = ps && ensure_side(e);
     Ctx cxs{e, fork ? e->side : s, 1};
     if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
-    CK(vit_forward(cxs, 1, e->in_cad, 1, (long)c.image_size * c.image_size));
+    const int V = c.num_views; const long SS = (long)c.image_size * c.image_size;
+    const long ldip = (1 + (ps ? 1 : 0) + (V > 0 ? 1 : 0)) * (long)H;                   // leading dimension of image_projection.weight
+    if (V > 0) {
+        if (!e->in_mv) { vc_set_error("engine: num_views = %d but no multiview images were given (vcad_set_multiview)", V); return VC_ERR_ARG; }
+        if (ps && !pa) { vc_set_error("engine: num_views > 0 with past states but no past actions (the reference's image_projection shapes do not match there either)"); return VC_ERR_UNSUPPORTED; }
+        const size_t px = e->in_u8 ? 1 : 4;                                              // (CAD-tower pixels: one gray plane, uint8 or fp32)
+        CK(vc_memcpy_d2d_async(e->cadmv, e->in_cad, (size_t)B * SS * px, cxs.s));
+        CK(vc_memcpy_d2d_async((char*)e->cadmv + (size_t)B * SS * px, e->in_mv, (size_t)B * V * SS * px, cxs.s));
+    }
+    CK(vit_forward(cxs, 1, V > 0 ? e->cadmv : e->in_cad, 1, SS));
     if (fork) CK(vc_event_record(e->ev_join, e->side));
     if (ps) {
         CK(vit_forward(cx, 0, e->in_frames, T, e->in_fbstride));
@@ -621,12 +639,20 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     }
     if (fork) CK(vc_stream_wait_event(s, e->ev_join));
     { Epi ep; ep.bias = cx.Pf(e->o_ei_b); CK(cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep)); }
+    // multiview: rows B.. of the CAD tower's cls vectors are [B][V * D] (image B + b V + v); embed_multiview -> mvE [B, H]
+    if (V > 0) { Epi ep; ep.bias = cx.Pf(e->o_mv_b);
+                 CK(cx.lin_fwd(cx.AT((const char*)e->va[1].e + (size_t)B * D * es, (long)V * D), cx.W(e->o_mv_w, (long)V * D), cx.AT(e->mvE, H), B, H, V * D, ep)); }
     if (pa && ps) {
         { Epi ep; ep.bias = cx.Pf(e->o_ip_b);
-          Mat w2 = cx.W(e->o_ip_w + H, 2 * H);
-          CK(cx.lin_fwd(cx.AT(e->cadE, H), w2, cx.A32(e->cadterm, H), B, H, H, ep)); }
+          CK(cx.lin_fwd(cx.AT(e->cadE, H), cx.W(e->o_ip_w + H, ldip), cx.A32(e->cadterm, H), B, H, H, ep)); }
+        if (V > 0) { Epi ep; ep.residual = e->cadterm; ep.ldr = H;                       // cadterm += mvE W_ip[:, 2H:3H]^T
+                     CK(cx.lin_fwd(cx.AT(e->mvE, H), cx.W(e->o_ip_w + 2 * H, ldip), cx.A32(e->cadterm, H), B, H, H, ep)); }
         { Epi ep; ep.rowadd = e->cadterm; ep.rdiv = T; ep.rmod = 0; ep.ldrow = H; ep.act = VC_ACT_TANH;
-          CK(cx.lin_fwd(cx.A32(e->ui, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->mem, H), (int)M, H, H, ep)); }
+          CK(cx.lin_fwd(cx.A32(e->ui, H), cx.W(e->o_ip_w, ldip), cx.A32(e->mem, H), (int)M, H, H, ep)); }
+    } else if (V > 0) {                                                                 // memory = tanh(image_projection([cad, multiview])) repeated over time
+        { Epi ep; ep.bias = cx.Pf(e->o_ip_b); CK(cx.lin_fwd(cx.AT(e->cadE, H), cx.W(e->o_ip_w, ldip), cx.A32(e->cadterm, H), B, H, H, ep)); }
+        { Epi ep; ep.residual = e->cadterm; ep.ldr = H; CK(cx.lin_fwd(cx.AT(e->mvE, H), cx.W(e->o_ip_w + H, ldip), cx.A32(e->cadterm, H), B, H, H, ep)); }
+        CK(vc_bcast_tanh(VC_F32, e->cadterm, e->mem, M, H, T, s));
     } else {
         CK(vc_bcast_tanh(e->dt, e->cadE, e->mem, M, H, T, s));
     }
@@ -781,20 +807,38 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     }
     const float* dui = nullptr;                                                        // gradient w.r.t. ui (post-tanh)
     CK(vc_dtanh(VC_F32, e->t_dmem, e->mem, dpre, nullptr, M * H, s));                  // d pre-tanh of the memory
+    const int V = c.num_views; const long ldip = (1 + (ps ? 1 : 0) + (V > 0 ? 1 : 0)) * (long)H;
     if (pa && ps) {
-        CK(cx.gemm(cx.A32(dpre, H), 1, cx.A32(e->ui, H), 1, Mat{cx.Gf(e->o_ip_w), VC_F32, 2L * H}, H, H, (int)M, Epi()));
+        CK(cx.gemm(cx.A32(dpre, H), 1, cx.A32(e->ui, H), 1, Mat{cx.Gf(e->o_ip_w), VC_F32, ldip}, H, H, (int)M, Epi()));
         CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadterm, 0, B, (long)T * H, H));    // sum over t -> [B, H]
         CK(cx.colsum(cx.A32(e->t_dcadterm, H), B, H, cx.Gf(e->o_ip_b), 0));
-        CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->cadE, H), 1, Mat{cx.Gf(e->o_ip_w + H), VC_F32, 2L * H}, H, H, B, Epi()));
-        CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + H, 2 * H), cx.A32(e->t_dcadE, H), B, H, H, Epi()));
-        CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_ip_w, 2 * H), cx.A32(e->t_dui, H), (int)M, H, H, Epi()));
+        CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->cadE, H), 1, Mat{cx.Gf(e->o_ip_w + H), VC_F32, ldip}, H, H, B, Epi()));
+        CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + H, ldip), cx.A32(e->t_dcadE, H), B, H, H, Epi()));
+        if (V > 0) {
+            CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->mvE, H), 1, Mat{cx.Gf(e->o_ip_w + 2 * H), VC_F32, ldip}, H, H, B, Epi()));
+            CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + 2 * H, ldip), cx.A32(e->t_dmvE, H), B, H, H, Epi()));
+        }
+        CK(cx.lin_dgrad(cx.A32(dpre, H), cx.W(e->o_ip_w, ldip), cx.A32(e->t_dui, H), (int)M, H, H, Epi()));
         dui = e->t_dui;
+    } else if (V > 0) {                                                                // memory = tanh(image_projection([cad, multiview])[b]): sum over t, then through the projection
+        CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadterm, 0, B, (long)T * H, H));
+        CK(cx.colsum(cx.A32(e->t_dcadterm, H), B, H, cx.Gf(e->o_ip_b), 0));
+        CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->cadE, H), 1, Mat{cx.Gf(e->o_ip_w), VC_F32, ldip}, H, H, B, Epi()));
+        CK(cx.gemm(cx.A32(e->t_dcadterm, H), 1, cx.AT(e->mvE, H), 1, Mat{cx.Gf(e->o_ip_w + H), VC_F32, ldip}, H, H, B, Epi()));
+        CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w, ldip), cx.A32(e->t_dcadE, H), B, H, H, Epi()));
+        CK(cx.lin_dgrad(cx.A32(e->t_dcadterm, H), cx.W(e->o_ip_w + H, ldip), cx.A32(e->t_dmvE, H), B, H, H, Epi()));
+        if (ps) dui = dx;
     } else {
         CK(cx.colsum(cx.A32(dpre, H), T, H, e->t_dcadE, 0, B, (long)T * H, H));       // memory = tanh(cadE[b]): sum over t
         if (ps) dui = dx;                                                              // tgt = ui
     }
     CK(cx.lin_wgrad(cx.A32(e->t_dcadE, H), cx.AT(e->va[1].e, D), cx.Gf(e->o_ei_w), D, cx.Gf(e->o_ei_b), B, H, D));
     CK(cx.lin_dgrad(cx.A32(e->t_dcadE, H), cx.W(e->o_ei_w, D), cx.A32(e->t_dec, D), B, H, D, Epi()));
+    if (V > 0) {      // embed_multiview backward; its input gradient IS rows B.. of d(cls) of the CAD tower
+        const char* mvx = (const char*)e->va[1].e + (size_t)B * D * e->esz;
+        CK(cx.lin_wgrad(cx.A32(e->t_dmvE, H), cx.AT(mvx, (long)V * D), cx.Gf(e->o_mv_w), (long)V * D, cx.Gf(e->o_mv_b), B, H, V * D));
+        CK(cx.lin_dgrad(cx.A32(e->t_dmvE, H), cx.W(e->o_mv_w, (long)V * D), cx.A32(e->t_dec + (long)B * D, (long)V * D), B, H, V * D, Epi()));
+    }
     if (ps) {
         CK(vc_dtanh(VC_F32, dui, e->ui, dpre, nullptr, M * H, s));                     // d pre-tanh of the state embedding
         CK(cx.lin_wgrad(cx.A32(dpre, H), cx.AT(e->va[0].e, D), cx.Gf(e->o_es_w), D, cx.Gf(e->o_es_b), (int)M, H, D));
@@ -824,6 +868,8 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (cfg->hidden_size % cfg->nhead) { vc_set_error("hidden_size %% nhead != 0"); return VC_ERR_ARG; }
     const int hd = cfg->hidden_size / cfg->nhead;
     if ((hd != 256 && hd != 128 && hd != 64) || cfg->vit_dim_head != 64) { vc_set_error("head dims (%d, %d) unsupported (decoder 64/128/256, ViT 64)", hd, cfg->vit_dim_head); return VC_ERR_UNSUPPORTED; }
+    if (cfg->num_views < 0 || cfg->num_views > 8) { vc_set_error("num_views %d out of range (0..8)", cfg->num_views); return VC_ERR_ARG; }
+    if (cfg->num_views > 0 && cfg->enable_past_states && !cfg->enable_past_actions) { vc_set_error("num_views > 0 needs past actions when past states are on (the reference's image_projection fan-in does not match its inputs otherwise)"); return VC_ERR_UNSUPPORTED; }
     if (cfg->window_size < 1) { vc_set_error("window_size must be > 0 (reference model/autoregressive_transformer.py:52)"); return VC_ERR_ARG; }
     // every shape constraint of the kernels is checked HERE, so an unsupported reference config fails at construction (INTEGRATION.md
     // lists which of the reference's model_configs these exclude), never at the first forward
@@ -894,6 +940,13 @@ int vcad_set_fp8(vcad_engine* e, int on) {
 int vcad_set_gemm_flags(vcad_engine* e, uint32_t flags) { e->gemm_flags = flags; return 0; }
 int64_t vcad_kernel_launches(const vcad_engine* e, int family) { return (family >= 0 && family < VC_NTAG) ? e->kernel_launches[family] : -1; }
 int vcad_set_side_stream(vcad_engine* e, int on) { e->no_side = !on; return 0; }
+// multiview images of the NEXT forward: [B][num_views] gray planes in the CAD image's pixel format (fp32 normalised, or uint8 when the forward is
+// vcad_forward_u8 / _rgb8), contiguous; device pointer, read during the forward only (the engine stages its own copy for the backward)
+int vcad_set_multiview(vcad_engine* e, const void* images) {
+    if (e->c.num_views <= 0 && images) { vc_set_error("vcad_set_multiview: engine was created with num_views = 0"); return VC_ERR_ARG; }
+    if (images && ((uintptr_t)images & 3)) { vc_set_error("vcad_set_multiview: pointer must be 4-byte aligned"); return VC_ERR_ARG; }
+    e->in_mv = images; return 0;
+}
 int vcad_set_dropout(vcad_engine* e, float p, uint64_t seed) {
     if (!(p >= 0.f && p < 1.f)) { vc_set_error("vcad_set_dropout: p must be in [0, 1)"); return VC_ERR_ARG; }
     e->drop_p = p; e->drop_seed = seed;
@@ -992,7 +1045,7 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
     int rc = 0;
     switch (stage) {
         case 0: rc = backward_stage0(e, dcmds ? dcmds : e->dl_cmds, dpars ? dpars : e->dl_pars, s); break;
-        case 1: { Ctx c1{e, e->bwd_fork ? e->side : s, 1}; rc = vit_backward(c1, 1, e->t_dec, 0, e->in_cad, 1, img2); } break;
+        case 1: { Ctx c1{e, e->bwd_fork ? e->side : s, 1}; rc = vit_backward(c1, 1, e->t_dec, 0, e->c.num_views > 0 ? e->cadmv : e->in_cad, 1, img2); } break;
         case 2: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride) : 0; break;
         case 3: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride) : 0; break;
         default: vc_set_error("vcad_backward_stage: stage %d out of range", stage); return VC_ERR_ARG;
@@ -1068,6 +1121,7 @@ size_t vcad_infer_workspace_bytes(const vcad_engine* e, int B, int Tmax) {
 
 static int infer_begin_any(vcad_engine* e, const void* cad, int u8, int B, int Tmax, void* stream) {
     if (!e->P) { vc_set_error("vcad_infer_begin: parameters not bound"); return VC_ERR_ARG; }
+    if (e->c.num_views > 0) { vc_set_error("vcad_infer_begin: incremental inference has no multiview input (nor has the reference's sequential_inference)"); return VC_ERR_UNSUPPORTED; }
     if (B < 1 || Tmax < 1 || Tmax > 192 || Tmax > e->c.max_ep_len) { vc_set_error("vcad_infer_begin: bad B=%d Tmax=%d (1 <= Tmax <= 192)", B, Tmax); return VC_ERR_ARG; }
     if (!e->ws) { vc_set_error("vcad_infer_begin: no workspace"); return VC_ERR_WORKSPACE; }
     { vcad_engine tmp = *e; const size_t need = infer_plan(&tmp, B, Tmax, nullptr);

@@ -17,13 +17,13 @@ VIT_DEFAULTS = dict(vit_dim=512, vit_depth=6, vit_heads=16, vit_dim_head=64, vit
 
 def make_config(hidden_size, nhead=4, num_decoder_layers=8, dim_feedforward=512, window_size=1, act_dim=7, num_classes=5,
                 num_params=6, num_params_values=1000, max_ep_len=1000, dtype=L.VCAD_F32, enable_past_actions=True,
-                enable_past_states=True, enable_timestep_embedding=True, **vit) -> L.Config:
+                enable_past_states=True, enable_timestep_embedding=True, num_views=0, **vit) -> L.Config:
     v = dict(VIT_DEFAULTS); v.update({k: vit[k] for k in vit if k in VIT_DEFAULTS})
     return L.Config(hidden_size=hidden_size, nhead=nhead, num_decoder_layers=num_decoder_layers, dim_feedforward=dim_feedforward,
                     window_size=window_size, act_dim=act_dim, num_classes=num_classes, num_params=num_params,
                     num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dtype,
                     enable_past_actions=int(bool(enable_past_actions)), enable_past_states=int(bool(enable_past_states)),
-                    enable_timestep_embedding=int(bool(enable_timestep_embedding)), **v)
+                    enable_timestep_embedding=int(bool(enable_timestep_embedding)), num_views=int(num_views), **v)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -119,10 +119,11 @@ class NativeEngine:
         L.check(self.lib, self.lib.vcad_set_side_stream(self.h, int(bool(on))), "set_side_stream")
 
     # ------------------------------------------------------------------ hot path
-    def forward(self, frames: torch.Tensor, actions_norm: torch.Tensor, cad: torch.Tensor):
+    def forward(self, frames: torch.Tensor, actions_norm: torch.Tensor, cad: torch.Tensor, multiview: Optional[torch.Tensor] = None):
         """frames [B,T,1,S,S] (any batch stride, frames contiguous within a clip), actions_norm [B,T,7], cad [B,1,S,S].
         frames / cad are either fp32 (already normalised, the reference loader's contract) or BOTH uint8 grayscale pixels
-        (normalised inside the patchify kernel: vcad_forward_u8)."""
+        (normalised inside the patchify kernel: vcad_forward_u8).  multiview (engines with num_views > 0): [B,V,1,S,S] in the CAD
+        image's pixel format (reference model/autoregressive_transformer.py:131,167-170)."""
         B, T = int(actions_norm.shape[0]), int(actions_norm.shape[1])
         S = self.cfg.image_size
         u8 = frames.dtype == torch.uint8
@@ -143,7 +144,14 @@ class NativeEngine:
         self.ensure_workspace(B, T)
         cmds = torch.empty(B, T, self.cfg.num_classes, device=self.device)
         pars = torch.empty(B, T, self.cfg.num_params, self.cfg.num_params_values, device=self.device)
-        self._keep = (frames, actions_norm, cad)          # backward re-reads the inputs (patch-LN grads, embed_action wgrad)
+        V = self.cfg.num_views
+        if V > 0:
+            if multiview is None:
+                raise RuntimeError(f"this model was built with num_views = {V}: inputs['multiview_images'] is required")
+            assert multiview.dtype == cad.dtype and multiview.numel() == B * V * S * S, (multiview.dtype, tuple(multiview.shape))
+            multiview = multiview.contiguous()
+            L.check(self.lib, self.lib.vcad_set_multiview(self.h, _ptr(multiview)), "set_multiview")
+        self._keep = (frames, actions_norm, cad, multiview)          # backward re-reads the inputs (patch-LN grads, embed_action wgrad)
         self.fwd_serial += 1
         fn = self.lib.vcad_forward_rgb8 if rgb else (self.lib.vcad_forward_u8 if u8 else self.lib.vcad_forward)
         L.check(self.lib, fn(self.h, _ptr(frames), fb, _ptr(actions_norm), _ptr(cad), B, T, _ptr(cmds), _ptr(pars), self.stream()), "forward")

@@ -36,7 +36,7 @@ class Config(C.Structure):
         "hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim",
         "num_classes", "num_params", "num_params_values", "max_ep_len",
         "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size", "dtype",
-        "enable_past_actions", "enable_past_states", "enable_timestep_embedding")]
+        "enable_past_actions", "enable_past_states", "enable_timestep_embedding", "num_views")]
 
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
@@ -57,6 +57,7 @@ PROTOTYPES = {
     "vcad_set_workspace": (_i, [_vp, _vp, _sz]),
     "vcad_set_dropout": (_i, [_vp, _f, C.c_uint64]),
     "vcad_set_fp8": (_i, [_vp, _i]),
+    "vcad_set_multiview": (_i, [_vp, _vp]),
     "vcad_dropout_mask": (_i, [_vp, _i, _i, _i, _i64, _vp]),
     "vcad_forward": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "vcad_forward_u8": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -113,8 +113,9 @@ def make_actions(B: int, S: int, seed: int, lengths=None) -> np.ndarray:
     return act
 
 
-def make_batch(B: int, T: int, seed: int, lengths=None, img: int = 224) -> dict:
-    """Loader-shaped batch (numpy). `lengths` (per-clip valid S<=T+1) gives ragged clips padded with -1."""
+def make_batch(B: int, T: int, seed: int, lengths=None, img: int = 224, num_views: int = 0) -> dict:
+    """Loader-shaped batch (numpy). `lengths` (per-clip valid S<=T+1) gives ragged clips padded with -1.
+    num_views > 0 adds 'multiview_images' [B, V, 1, img, img] (reference data loader contract, autoregressive_transformer.py:131)."""
     S = T + 1
     kf = fnv1a64("frames") ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
     kc = fnv1a64("cad_image") ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
@@ -128,7 +129,8 @@ def make_batch(B: int, T: int, seed: int, lengths=None, img: int = 224) -> dict:
         "actions": make_actions(B, S, seed, lengths),
         "cad_image": cad,
         "timesteps": np.tile(np.arange(S, dtype=np.int64), (B, 1)),
-        "multiview_images": None,
+        "multiview_images": (hash_uniform(fnv1a64("multiview_images") ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF), B * num_views * img * img)
+                             .reshape(B, num_views, 1, img, img) if num_views > 0 else None),
     }
 
 
@@ -171,7 +173,7 @@ def make_param_torch(name: str, shape, device, seed: int = 0):
     return (torch.tensor(shift, dtype=torch.float32, device=device) + torch.tensor(scale, dtype=torch.float32, device=device) * u).reshape(tuple(shape))
 
 
-def make_batch_torch(B: int, T: int, seed: int, device, lengths=None, img: int = 224) -> dict:
+def make_batch_torch(B: int, T: int, seed: int, device, lengths=None, img: int = 224, num_views: int = 0) -> dict:
     """Same tensors as make_batch, generated on `device` (actions are tiny and come from the numpy path)."""
     import torch
     S = T + 1
@@ -183,4 +185,6 @@ def make_batch_torch(B: int, T: int, seed: int, device, lengths=None, img: int =
             frames[b, L:] = -1.0
     cad = hash_uniform_torch(kc, B * img * img, device).reshape(B, 1, img, img)
     return {"frames": frames, "actions": torch.from_numpy(make_actions(B, S, seed, lengths)).to(device), "cad_image": cad,
-            "timesteps": torch.arange(S, device=device).repeat(B, 1), "multiview_images": None}
+            "timesteps": torch.arange(S, device=device).repeat(B, 1),
+            "multiview_images": (hash_uniform_torch(fnv1a64("multiview_images") ^ (seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF), B * num_views * img * img, device)
+                                 .reshape(B, num_views, 1, img, img) if num_views > 0 else None)}

@@ -338,7 +338,7 @@ class BaseTrainer:
         else:
             out["timesteps"] = batch["timesteps"].to(self.device, dtype=torch.long)
         if batch.get("multiview_images", None) is not None:
-            out["multiview_images"] = batch["multiview_images"].to(self.device, dtype=torch.float)
+            out["multiview_images"] = to_dev(batch["multiview_images"])
         return out
 
     # ---- reference trainer.py:800-804
@@ -380,7 +380,7 @@ class BaseTrainer:
         if not self.native._shadow_fresh:
             eng.sync_shadow()
         self.native._arm_dropout()                               # model.train() -> dropout active, like the reference's train loop
-        cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"])
+        cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"], inputs.get("multiview_images") if self.native.num_views > 0 else None)
         out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
         self.gradsync.backward()
         eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
