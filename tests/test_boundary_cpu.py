@@ -57,7 +57,7 @@ def test_state_dict_matches_appendix_b_and_factory_surface():
     # no CPU fallback: the product path fails loudly without a ROCm device
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model({"frames": torch.zeros(1, 1, 1, 224, 224), "actions": torch.zeros(1, 1, 7), "cad_image": torch.zeros(1, 1, 224, 224)})
-    for bad in (dict(CANON, encoder="resnet"), dict(CANON, num_views=2), dict(CANON, window_size=0)):
+    for bad in (dict(CANON, encoder="resnet"), dict(CANON, num_views=2, enable_past_actions=False), dict(CANON, window_size=0)):   # (views + states without actions: the reference's own shapes do not match)
         with pytest.raises((NotImplementedError, AssertionError)):
             ModelFactory().create_model("x", bad, "cpu")
 
