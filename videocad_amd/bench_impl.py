@@ -349,7 +349,7 @@ def run(args):
                "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms, 3), "ms_per_step_median": round(float(np.median(per_step_ms)), 3) if per_step_ms else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype + ("+fp8 forward GEMMs (ViT)" if getattr(args, "fp8", False) else ""), "data": "synthetic (" + ("uint8 pixels" if args.uint8_frames else "U[-1,1) fp32 frames") + " in HBM, hash-init weights)",
-               "config": {"workload": f"autoregressive_transformer bf16 seq_len={T} batch={B} per GPU, {world}xMI355X (BASELINE configs[1])"
+               "config": {"workload": f"autoregressive_transformer {args.dtype} seq_len={T} batch={B} per GPU, {world}xMI355X (BASELINE configs[1])"
                           if (T, B) == (64, 32) else f"canonical model seq_len={T} batch={B} per GPU",
                           "dropout": args.dropout, "clips_per_gpu": B, "seq_len": T, "global_batch": B * world, "parallelism": f"dp{world}",
                           "step": "videocad_amd.trainer.BaseTrainer.train_step", "loss": float(loss.item())},
