@@ -175,6 +175,9 @@ int vcad_profile_kernel(int family, double out[4]);
 #define VCAD_GEMM_WIDE_ALWAYS 32u
 #define VCAD_GEMM_MID_NEVER 64u    /* six-stage DMA-ring kernel for mid-size problems: never / whenever legal */
 #define VCAD_GEMM_MID_ALWAYS 128u
+#define VCAD_GEMM_DYNAMIC (1u << 16)   /* the persistent kernel claims its items with tickets instead of static per-workgroup lists: robust when other kernels (RCCL) hold CUs.
+                                         * The one flag the product sets: the data-parallel trainer turns it on for world > 1 (vcad_set_gemm_flags); vcad_op_gemm carves the
+                                         * counters from its scratch buffer */
 #define VCAD_GEMM_NGROUP(n) ((uint32_t)(n) << 12)    /* register-staged kernel: tile columns per sweep over all tile rows (0 automatic: only when B overflows an XCD's L2) */
 #define VCAD_GEMM_XCD_COLS(n) ((uint32_t)(n) << 8)   /* XCD column groups of the persistent kernel's forward launches: 0 automatic, 1 never, 2 / 4 / 8 forced */
 int vcad_set_gemm_flags(vcad_engine* e, uint32_t flags);

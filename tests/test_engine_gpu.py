@@ -175,7 +175,7 @@ def gemm_dma_mode(request):
     """bf16 tests run twice: automatic kernel choice (these small batches stay on the register-staged GEMM) and with every
     legal bf16 GEMM forced through the persistent DMA-fed kernel (the one the C2 bench shapes take)."""
     global ENGINE_GEMM_FLAGS
-    ENGINE_GEMM_FLAGS = L.GEMM_DMA_ALWAYS if request.param == 1 else 0
+    ENGINE_GEMM_FLAGS = (L.GEMM_DMA_ALWAYS | L.GEMM_DYNAMIC) if request.param == 1 else 0      # (forced mode also draws the items with tickets, as the data-parallel trainer does)
     del ENGINES[:]
     used = lambda: sum(e.kernel_launches(L.KERNEL_GEMM_DMA) for e in ENGINES)
     yield request.param, used

@@ -110,6 +110,24 @@ def test_gemm_dma_kernel_wide_tile(emu, gemm_tile, tra, trb, to):
                          flags=wide["flags"] | L.gemm_xcd_cols(xn), kernel=L.KERNEL_GEMM_DMA)
 
 
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("tra,trb,to", [(0, 0, BF16), (0, 0, F32), (0, 1, BF16), (1, 1, F32)])
+def test_gemm_dma_kernel_dynamic_item_claiming(emu, gemm_tile, tra, trb, to, wide):
+    """persistent kernel with ticket-drawn items (gemm_dma.h `claim`; what the engine always uses): under the emulator workgroups run one after the
+    other, so the first one draws every item of its XCD's range and then steals the other XCDs' — the multi-item stream, the lazy claim in front
+    of the prefetch cursor's last k-tile (1, 2, 3 and 10 k-tiles per item), the exhausted-counter path and the counter reset (two launches on the
+    same scratch) in one go"""
+    if gemm_tile != 128 or (wide and trb and not tra):
+        pytest.skip("tile-size fixture does not apply / no wide tile for the tr-read B forward layout")
+    fl = L.GEMM_DMA_ALWAYS | L.GEMM_DYNAMIC | (L.GEMM_WIDE_ALWAYS if wide else L.GEMM_WIDE_NEVER)
+    for K in (64, 128, 192, 640):
+        M = 776 if tra else 790                        # 4 tile rows (ragged last one) x 2-4 tile columns
+        U.check_gemm(emu, "cpu", M, 512, K, BF16, sa=BF16, sb=BF16, to=to, tra=tra, trb=trb, pad=8, bias=not tra, residual=(to == F32 and not wide and not tra),
+                     splitk=True, flags=fl, kernel=L.KERNEL_GEMM_DMA)
+    if not tra and not trb:                            # XCD column groups keep their own counters (no stealing)
+        U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, splitk=True, flags=fl | L.gemm_xcd_cols(2), kernel=L.KERNEL_GEMM_DMA)
+
+
 @pytest.mark.parametrize("trb,to", [(0, BF16), (0, F32), (1, BF16), (1, F32)])
 def test_gemm_mid_kernel(emu, gemm_tile, trb, to):
     """the six-stage DMA-ring kernel for mid-size problems (gemm_mid.h): ragged M tail, fewer k-tiles than stages / exactly / more,

@@ -17,6 +17,22 @@ void vcad_debug_force_gemm_tile(int tile) { setf(VC_GF_TILE64 | VC_GF_TILE128, t
 void vcad_debug_gemm_dma(int mode) { setf(VC_GF_DMA_NEVER | VC_GF_DMA_ALWAYS, mode == 0 ? VC_GF_DMA_NEVER : (mode == 1 ? VC_GF_DMA_ALWAYS : 0u)); }
 void vcad_debug_gemm_wide(int mode) { setf(VC_GF_WIDE_NEVER | VC_GF_WIDE_ALWAYS, mode == 0 ? VC_GF_WIDE_NEVER : (mode == 1 ? VC_GF_WIDE_ALWAYS : 0u)); }
 void vcad_debug_gemm_mid(int mode) { setf(VC_GF_MID_NEVER | VC_GF_MID_ALWAYS, mode == 0 ? VC_GF_MID_NEVER : (mode == 1 ? VC_GF_MID_ALWAYS : 0u)); }
+// CU hog for the occupied-CU A/B of the dynamic item claiming (tools/gemm_hog_ab.py): n workgroups of 1024 threads with 160 KiB of LDS each — one per
+// CU, nothing else fits beside it — spinning for `us` microseconds on `stream` (the caller launches GEMMs on another stream meanwhile)
+__global__ __launch_bounds__(1024) void hog_kernel(long long ticks, int* sink) {
+    extern __shared__ int hog_lds[];
+    hog_lds[threadIdx.x] = threadIdx.x;
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();          // 100 MHz
+    long long t = t0;
+    while (t - t0 < ticks) { for (int i = 0; i < 16; ++i) __builtin_amdgcn_s_sleep(32); t = (long long)__builtin_amdgcn_s_memrealtime(); }
+    if (hog_lds[(threadIdx.x + 1) & 1023] == -1) sink[0] = 1;
+}
+int vcad_debug_hog(int n_wg, int us, int* sink, void* stream) {
+    static bool attr = false;
+    if (!attr) { if (hipFuncSetAttribute((const void*)hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return 1; attr = true; }
+    hipLaunchKernelGGL(hog_kernel, dim3(n_wg), dim3(1024), 160 * 1024, (hipStream_t)stream, (long long)us * 100, sink);     // s_memrealtime / cycle counter: 100 MHz
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 void vcad_debug_gemm_xcd_cols(int xn) { setf(15u << VC_GF_XCD_COLS_SHIFT, (unsigned)(xn == 0 ? 1 : ((xn == 2 || xn == 4 || xn == 8) ? xn : 0)) << VC_GF_XCD_COLS_SHIFT); }
 }
 #endif

@@ -12,6 +12,10 @@ int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A
                  const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, uint32_t flags, int* kernel_out, void* stream) {
     GemmCall c; memset(&c, 0, sizeof(c));
     c.flags = flags; c.kernel_out = kernel_out;
+    if ((flags & VC_GF_DYNAMIC) && scratch && scratch_bytes >= 256) {       // dynamic item claiming: 64 zeroed bytes at the head of the scratch buffer
+        if (int rc = vc_memset_async(scratch, 0, 64, (vc_stream_t)stream)) return rc;
+        c.claim = (int*)scratch; scratch += 64; scratch_bytes -= 256;
+    }
     c.ct = ct; c.sa = sa; c.sb = sb; c.to = to; c.tra = tra; c.trb = trb;
     c.p.A = A; c.p.B = B; c.p.C = C; c.p.M = M; c.p.N = N; c.p.K = K; c.p.lda = lda; c.p.ldb = ldb; c.p.ldc = ldc;
     c.p.bias = bias; c.p.act = act; c.p.residual = residual; c.p.ldr = ldr; c.p.alpha = alpha; c.p.rowadd_div = 1;

@@ -45,6 +45,7 @@ struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w
 // Scratch and ViT-backward temporaries exist twice: lane 0 = the caller's stream (frame ViT, decoder), lane 1 = the side stream the
 // CAD ViT (32 images: ~230 launch-bound kernels, 6 % of a step when serialised) runs on concurrently with the frame ViT.
 struct Lane { float* scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
+              int* claim;          // 16 ints: ticket counters of the persistent GEMM's dynamic item claiming (gemm_dma.h), zero between launches
               float *t_dx, *t_dpe; void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_dum; float* t_delta; uint8_t *q8a, *q8as; };
 
 struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo; };
@@ -266,6 +267,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         l.scr_splitk_bytes = 64ul << 20; l.scr_splitk = b.take<float>(l.scr_splitk_bytes);
         l.scr_colsum_bytes = (ln == 0 ? 64ul : 16ul) << 20; l.scr_colsum = b.take<float>(l.scr_colsum_bytes);
         l.scr_lnpart_bytes = 1024ul * 2 * 1024 * 4; l.scr_lnpart = b.take<float>(l.scr_lnpart_bytes);
+        l.claim = b.take<int>(64);
         l.q8a = nullptr; l.q8as = nullptr;
         if (e->fp8) { const long kmax = inner > D ? inner : D; l.q8a = b.take<uint8_t>(R * kmax); l.q8as = b.take<uint8_t>(R * kmax / 32); }
     }
@@ -349,6 +351,9 @@ struct Ctx {
         p.rowadd = ep.rowadd; p.rowadd_div = ep.rdiv; p.rowadd_mod = ep.rmod; p.ld_rowadd = ep.ldrow;
         p.aux = ep.aux; p.ldaux = ep.ldaux; p.dact_src = ep.dact; p.lddact = ep.lddact; p.dact_kind = ep.dkind; p.drop = ep.drop;
         int tag = VC_TAG_NONE; c.flags = e->gemm_flags; c.kernel_out = &tag;
+        // ticket-drawn items for the persistent kernel (gemm_dma.h): on when the engine shares the GPU with communication kernels (the data-parallel
+        // trainer sets the flag; profiles/r03_gemm_hog_ab.txt: 32 occupied CUs cost 13-16 % instead of 39-56 %), off otherwise (1-3 % ticket latency)
+        c.claim = (e->gemm_flags & VC_GF_DYNAMIC) ? L().claim : nullptr;
         const int rc = vc_gemm(c, L().scr_splitk, L().scr_splitk_bytes, s);
         if (!rc) ++e->kernel_launches[tag];
         return rc;
@@ -617,6 +622,8 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     const bool pa = c.enable_past_actions, ps = c.enable_past_states;
     const float* ts = c.enable_timestep_embedding ? cx.Pf(e->o_ts) : nullptr;
     CK(cx.refresh_q8());
+    // the persistent GEMM's ticket counters are left at zero by every launch; re-zeroed here so that an aborted launch cannot poison the next step
+    for (int ln = 0; ln < 2; ++ln) CK(vc_memset_async(e->lane[ln].claim, 0, 64, s));
     // CAD ViT (B images) on the side stream, issued first so that its ~100 small kernels slot in beside the frame ViT's big ones
     const bool fork = ps && ensure_side(e);
     Ctx cxs{e, fork ? e->side : s, 1};

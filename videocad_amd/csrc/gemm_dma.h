@@ -51,7 +51,7 @@ template <int BN> struct GdTile {
     static constexpr int NJ = BN / 64;                                          // 32-column accumulator tiles per wave (2 or 4)
     static constexpr int B_ELEMS = BN * GD_BK, STAGE_ELEMS = GD_A_ELEMS + B_ELEMS;
     static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_ELEMS * 2;
-    static constexpr size_t LDS_BYTES = RING_BYTES + 3 * BN * sizeof(float);
+    static constexpr size_t LDS_BYTES = RING_BYTES + 3 * BN * sizeof(float) + 8 * sizeof(int);     // + three bias rows + the ticket ring of the dynamic claiming
     static constexpr int PIECES_B = B_ELEMS * 2 / 1024;
     static constexpr int PW = (GD_PIECES_A + PIECES_B) / 4;                     // 12 / 16
     static constexpr int NS = 2 * NJ * 4;                                       // 16 / 32
@@ -186,7 +186,7 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
 // per 8 (128 KiB of reads per k-tile), and a wave hides its own fragment latency behind 16 back-to-back MFMAs.  All four waves issue
 // their quarter of every stage (no second wave on the SIMD to take turns with).
 template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
-VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn) {
+VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn, int* claim) {
     using TL = GdTile<BN>;
     static_assert(NW == 8 || (NW == 4 && BN == 256), "four-wave form: 256-wide tile only");
     constexpr int NJ = TL::NJ, STAGES = TL::STAGES, STAGE_ELEMS = TL::STAGE_ELEMS, PIECES_B = TL::PIECES_B, HALF_N = BN / 2;
@@ -200,6 +200,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     constexpr int NS_ITEM = (COL ? 32 : TL::NS) * (MI / 2);                      // epilogue stores per wave per interior item
     VC_DYN_SHARED(vc_bf16, lds);
     float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + TL::RING_BYTES);
+    int* const tk = reinterpret_cast<int*>(bias_lds + 3 * BN);            // dynamic claiming: item of sequence number s at tk[s & 7]
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned char* Ag = (const unsigned char*)p.A;
@@ -228,6 +229,39 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         const int cn = xcd < r8 ? q8 + 1 : q8;
         first = cs + j; last = cs + cn;                          // items first, first + nbx, ... < last
     }
+    // Dynamic item claiming (r03; `claim` = 9 zeroed ints: one ticket counter per XCD + a finish counter): the static lists above assume all
+    // gridDim.x workgroups run at once — one per CU.  When other kernels hold CUs (RCCL's all-reduce under the backward), the workgroups that
+    // could not start run as a second round after the others and the launch takes up to 2x.  With tickets, workgroup order does not matter:
+    // whoever runs takes the XCD's next item (same sweep order, so the L2 locality of the static lists stays), late starters find the
+    // counters exhausted; an XCD that runs dry steals from the next one (not with XCD column groups: their item lists are XCD-specific).
+    // Tickets come from a SCALAR atomic (lgkmcnt; the DMA ring's vmcnt accounting is untouched), drawn by wave 0 while it would wait for the
+    // ring anyway, one item ahead of the prefetch cursor; the last workgroup to finish re-zeroes the counters for the next launch.
+    const bool dyn = claim != nullptr;
+    int steal_x = xcd;                                            // XCD whose counter wave 0 draws from (moves on when that one is exhausted)
+    auto xcd_range = [&](int x, int& base, int& cnt) {
+        if (xn > 1) { base = 0; cnt = tmn * nsplit; return; }
+        const int q8 = total >> 3, r8 = total & 7;
+        base = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; cnt = x < r8 ? q8 + 1 : q8;
+    };
+    if (dyn) last = xn > 1 ? tmn * nsplit : total;               // item ids are global (or XCD-local with column groups); `last` = "no more items"
+    auto claim_item = [&]() -> int {                              // wave 0 only
+        for (int tries = 0; tries < (xn > 1 ? 1 : 8); ++tries) {
+            int base, cnt; xcd_range(steal_x, base, cnt);
+            const int t = vc_wave_ticket(claim + steal_x);
+            if (t < cnt) return base + t;
+            steal_x = (steal_x + 1) & 7;
+        }
+        return last;
+    };
+    int claimed = 0;                                              // sequence numbers whose items are in tk[] (all waves count alike; wave 0 writes)
+    auto claim_next = [&]() {
+        if (wave == 0) { const int it = claim_item(); if (lane == 0) tk[claimed & 7] = it; }
+        ++claimed;
+    };
+    // Tickets are drawn as late as possible — a workgroup that hoards items at the start leaves others idle when there are about as many items as
+    // workgroups: the first item here, item s + 1 at the ktile_begin in front of the prefetch cursor's LAST k-tile of item s (the prefetch that
+    // follows that barrier is the one that moves on and reads tk[s + 1]).
+    if (dyn) { claim_next(); vc_sync(); first = tk[0]; }
     const int nt = p.k_per_split / GD_BK, ktiles = p.K / GD_BK;  // k-tiles per slice (the last slice may be shorter)
     const bool use_bias = p.bias && !p.partial;
     const bool use_side = NJ == 2 && (p.residual || p.dact_src) && !p.partial;   // (the 256-wide tile has no registers for side inputs)
@@ -248,7 +282,9 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     };
     auto advance = [&](GdCursor& c) -> bool {   // true when the cursor moved on to a new item
         if (++c.kt < c.ntc) return false;
-        c.kt = 0; c.item += nbx; ++c.seq;
+        c.kt = 0; ++c.seq;
+        if (dyn) c.item = tk[c.seq & 7];                                  // (claimed ahead; visible since the last barrier)
+        else c.item += nbx;
         if (c.item < last) locate(c);
         return true;
     };
@@ -271,7 +307,11 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     if (first < last) { locate(pf); retarget(pf); }
     GdCursor cp = pf;
     int turn = 0;                                                // parity of the stage being consumed == the group that issued it
-    for (int s0 = 0; s0 < STAGES - 1 && pf.item < last; ++s0) { if (my_turn(s0 & 1)) issue(pf, s0); if (advance(pf) && pf.item < last) retarget(pf); }
+    for (int s0 = 0; s0 < STAGES - 1 && pf.item < last; ++s0) {
+        if (dyn && pf.kt == pf.ntc - 1 && claimed < pf.seq + 2) { claim_next(); vc_sync(); }      // (single-k-tile items: the cursor moves on right here)
+        if (my_turn(s0 & 1)) issue(pf, s0);
+        if (advance(pf) && pf.item < last) retarget(pf);
+    }
 
     vc_f32x16 acc[MI][NJ];
     int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
@@ -280,6 +320,9 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     // Every instruction here is paid 300+ times per launch by every wave (a wave issues one instruction per ~4 cycles, a
     // taken branch costs ~5 of those), so the body is kept to: wait, barrier, (every other k-tile) 12 DMA issues, 16 ds_read, 16 MFMA.
     auto ktile_begin = [&]() {
+        // (wave 0 draws the ticket in front of the cursor's last k-tile of the item — or one k-tile earlier when that is a k-tile whose stage wave 0's
+        // own group waits for below: the atomic's round trip then runs under the ring wait instead of holding the barrier up)
+        if (dyn && pf.item < last && claimed < pf.seq + 2 && (pf.kt == pf.ntc - 1 || (pf.kt == pf.ntc - 2 && (NW == 4 || turn == 0)))) claim_next();
         // stage `slot` must have landed.  VMEM retires in issue order on gfx9, so "at most N outstanding" with N = the number
         // of operations issued AFTER this stage's DMA — the younger stage's pieces and the epilogue stores of the last two
         // k-tiles — is exact: neither the prefetch nor the stores are waited for.  N must never over-count (the stage itself
@@ -357,7 +400,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     constexpr bool FOLD = BN == 256;
     const bool fold_bias = FOLD && use_bias && plain;
 
-    for (; cp.item < last; cp.item += nbx, ++cp.seq) {
+    for (; cp.item < last; ++cp.seq, cp.item = dyn ? tk[cp.seq & 7] : cp.item + nbx) {
         if (cp.seq) locate(cp);
         const int z = cp.z, tm = cp.tm, tn = cp.tn;
         // accumulators start at the tile's bias when the epilogue is plain (then the epilogue is convert + store: no per-element add); the bias row
@@ -615,4 +658,8 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
     }
     vc_wait_vmcnt<0>();            // no DMA may still be writing this workgroup's LDS when it is handed to the next one
+    if (dyn && wave == 0) {        // the last workgroup through re-zeroes the counters (every other one has drawn its last ticket by then)
+        const int done = vc_wave_ticket(claim + 8);
+        if (done == (int)gridDim.x - 1 && lane < 9) claim[lane] = 0;
+    }
 }

@@ -32,7 +32,8 @@ const char* vc_get_error();
 // Plain arguments — the library has no process-global switches.
 enum { VC_GF_TILE64 = 1, VC_GF_TILE128 = 2, VC_GF_DMA_NEVER = 4, VC_GF_DMA_ALWAYS = 8, VC_GF_WIDE_NEVER = 16, VC_GF_WIDE_ALWAYS = 32,
        VC_GF_MID_NEVER = 64, VC_GF_MID_ALWAYS = 128, VC_GF_XCD_COLS_SHIFT = 8 /* bits 8-11, XCD column groups of the persistent kernel: 0 automatic, 1 never, 2 / 4 / 8 forced */,
-       VC_GF_NGROUP_SHIFT = 12 /* bits 12-15, register-staged kernel: tile columns per sweep (gemm.h n_group): 0 automatic, 1-15 forced */ };
+       VC_GF_NGROUP_SHIFT = 12 /* bits 12-15, register-staged kernel: tile columns per sweep (gemm.h n_group): 0 automatic, 1-15 forced */,
+       VC_GF_DYNAMIC = 1 << 16 /* vcad_op_gemm: persistent kernel claims its items dynamically (counters carved from the scratch buffer) */ };
 struct GemmCall {
     int ct, sa, sb, to;         // compute / A-source / B-source / output dtypes
     int tra, trb;
@@ -40,6 +41,8 @@ struct GemmCall {
     GemmParams p;               // vecA/vecB/k_per_split/partial are filled by vc_gemm
     unsigned flags;             // VC_GF_*
     int* kernel_out;            // optional: receives the VC_TAG_* of the kernel family that ran
+    int* claim;                 // optional: 16 zeroed ints of device memory private to the launching stream — the persistent kernel then claims its items
+                                // dynamically (gemm_dma.h) and leaves them zeroed; null = static item lists
 };
 // scratch: fp32 workspace for split-K partial slabs (may be null -> no split)
 bool vc_profile_on();       // the HIP-event profiler is recording: per-kernel times must not overlap, so no side stream

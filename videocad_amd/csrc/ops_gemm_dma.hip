@@ -49,7 +49,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
             if (tiles_n % xn || a_bytes * xn > 0.5 * (double)tiles_mn * slice || tiles_m < 8 * 8 / xn) xn = 1;
         }
     }
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>), dim3(grid), dim3(NW * 64), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total, xn);
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>), dim3(grid), dim3(NW * 64), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total, xn, c.claim);
     }
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;

@@ -75,6 +75,13 @@ VC_DEV float vc_expf_fast(float x) { return __expf(x); }
 // a product that is rounded on its own: hipcc contracts `a * b - c` (and __fmul_rn, which is a plain multiply in the IR) into one FMA
 VC_DEV float vc_mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 VC_DEV int vc_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }     // x is known to be wave-uniform: keep it in an SGPR
+// one ticket per WAVE from a device counter: scalar atomic (SMEM path, lgkmcnt) — it does not touch the vmcnt accounting of a DMA ring
+// (tools/probe_satomic.hip: 4096 distinct tickets on MI355X).  Waits for the result.
+VC_DEV int vc_wave_ticket(int* ctr) {
+    int r;
+    asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(ctr), "0"(1) : "memory");
+    return r;
+}
 VC_DEV uint64_t vc_uniform64(uint64_t x) {     // 64-bit value known to be wave-uniform: both halves into SGPRs
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
 }
@@ -226,6 +233,7 @@ VC_DEV void vc_hpin2(uint32_t&, uint32_t&) {}
 template <int N> VC_DEV void vc_hwait2(uint32_t&, uint32_t&) {}
 template <typename T> VC_DEV void vc_undef(T&) {}
 VC_DEV int vc_uniform(int x) { return x; }
+VC_DEV int vc_wave_ticket(int* ctr) { int t = 0; if ((threadIdx.x & 63) == 0) t = __atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED); return vcemu::shfl_i(t, 0); }
 VC_DEV uint64_t vc_uniform64(uint64_t x) { return x; }
 template <int N> VC_DEV void vc_wait_vmcnt() {}
 VC_DEV void vc_barrier_raw() { vcemu::sync_block(); }

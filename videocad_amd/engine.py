@@ -110,7 +110,12 @@ class NativeEngine:
 
     # kernel-selection flags (tests: small batches on the kernels the C2 shapes take; lib.GEMM_*) / launches per kernel family / side stream
     def set_gemm_flags(self, flags: int):
+        self.gemm_flags = int(flags)
         L.check(self.lib, self.lib.vcad_set_gemm_flags(self.h, int(flags)), "set_gemm_flags")
+
+    def set_dynamic_items(self, on: bool = True):
+        """persistent GEMM draws its items with tickets (robust while communication kernels hold CUs): the data-parallel trainer turns it on"""
+        self.set_gemm_flags((getattr(self, "gemm_flags", 0) & ~L.GEMM_DYNAMIC) | (L.GEMM_DYNAMIC if on else 0))
 
     def kernel_launches(self, family: int) -> int:
         return int(self.lib.vcad_kernel_launches(self.h, int(family)))

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvcad_hip.so")
 VCAD_F32, VCAD_BF16, VCAD_BF16X3 = 0, 1, 2
 # kernel-selection flags (include/vcad.h VCAD_GEMM_*; tests only) and kernel families (vcad_kernel_launches / vcad_op_gemm kernel_out)
 GEMM_TILE64, GEMM_TILE128, GEMM_DMA_NEVER, GEMM_DMA_ALWAYS, GEMM_WIDE_NEVER, GEMM_WIDE_ALWAYS, GEMM_MID_NEVER, GEMM_MID_ALWAYS = 1, 2, 4, 8, 16, 32, 64, 128
+GEMM_DYNAMIC = 1 << 16
 KERNEL_GEMM_DMA, KERNEL_GEMM_REG, KERNEL_GEMM_MID, KERNEL_GEMM_GROUPED = 1, 2, 3, 4
 
 
@@ -145,6 +146,8 @@ def load_ab():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    lib.vcad_debug_hog.restype = _i
+    lib.vcad_debug_hog.argtypes = [_i, _i, _vp, _vp]
     lib._vcad_ab = True
     _lib = lib
     return lib

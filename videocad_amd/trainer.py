@@ -224,6 +224,7 @@ class GradSync:
         self.stream = torch.cuda.Stream(device=engine.device) if (self.world > 1 and engine.device.type == "cuda") else None
         self.skip_comm = False                                    # diagnostic only (bench: exposed communication time)
         if self.world > 1:
+            engine.set_dynamic_items(True)        # RCCL's kernels hold CUs under the backward: the persistent GEMM draws its items with tickets then
             src = dist.get_global_rank(group, 0) if group is not None else 0
             for buf in (engine.params, engine.m, engine.v):
                 dist.broadcast(buf, src=src, group=group)
