@@ -237,6 +237,8 @@ struct ColsumParams {
     const void* x; long ld; long rows; int cols; long batch_stride_x;
     float* out; long ld_out_rows; long batch_stride_out; int accumulate;    // out row g = block-row index (partials) or 0 (final)
     int rows_per_block;
+    int seg; float *out1, *out2;        // seg > 0 (single-level, unbatched): columns [0, seg) go to out, [seg, 2 seg) to out1, [2 seg, 3 seg) to out2 — the
+                                        // LayerNorm backward's dgamma / dbeta / bias-gradient partial rows in ONE launch instead of three
 };
 template <typename TX>
 VC_KERNEL __launch_bounds__(256) void colsum_pass_kernel(ColsumParams p) {
@@ -264,6 +266,7 @@ VC_KERNEL __launch_bounds__(256) void colsum_pass_kernel(ColsumParams p) {
     if (q == 0 && live) {
         const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         float* o = p.out + (long)blockIdx.z * p.batch_stride_out + (long)blockIdx.y * p.ld_out_rows + c;
+        if (p.seg > 0) { const int sg = c / p.seg; o = (sg == 0 ? p.out : (sg == 1 ? p.out1 : p.out2)) + (c - sg * p.seg); }
         *o = p.accumulate ? (*o + t) : t;
     }
 }

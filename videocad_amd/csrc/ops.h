@@ -62,6 +62,7 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
               float* colsum_ws, vc_stream_t s, float* dsum_out = nullptr);   // dsum_out: column sums of the emitted gradient (norm.h LnBwdParams::dsum)
 // out[b][c] (=|+=) sum_r x[b][r][c];  ws >= batch * nchunk(rows) * cols floats
 long vc_colsum_chunks(long rows);
+int vc_colsum_seg(const float* x, long ld, long rows, int seg, int nseg, float* out0, float* out1, float* out2, vc_stream_t s);
 int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
               int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s);
 // out (fp32 or T) = in (fp32) * dropout mask; cols % 4 == 0, 16-byte-aligned rows

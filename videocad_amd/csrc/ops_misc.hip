@@ -56,19 +56,25 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     else { vc_set_error("ln_bwd: dtype combo %d %d %d", td, tx, ty); return VC_ERR_UNSUPPORTED; }
     if (rc) return rc;
     if (partial_ws) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C)
-        if (dbeta == dgamma + C) {       // weight and bias adjacent in the flat gradient buffer: one reduction over 2C columns
-            rc = vc_colsum(VC_F32, partial_ws, PS, nblk, 2 * C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
-        } else {
-            rc = vc_colsum(VC_F32, partial_ws, PS, nblk, C, dgamma, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
-            rc = vc_colsum(VC_F32, partial_ws + C, PS, nblk, C, dbeta, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc;
-        }
-        if (p.dsum) { rc = vc_colsum(VC_F32, partial_ws + 2 * C, PS, nblk, C, dsum_out, 0, 1, 0, 0, colsum_ws, s); if (rc) return rc; }
+        // partial is [nblk][2 or 3][C] (nblk <= 512): dgamma, dbeta and the emitted gradient's column sums in ONE launch (r02: two or three)
+        (void)colsum_ws;
+        rc = vc_colsum_seg(partial_ws, PS, nblk, C, p.dsum ? 3 : 2, dgamma, dbeta, dsum_out, s); if (rc) return rc;
     }
     return VC_OK;
 }
 
 long vc_colsum_chunks(long rows) { return VC_CEIL_DIV(rows, 128) + VC_CEIL_DIV(VC_CEIL_DIV(rows, 128), 128) + 2; }   // partial rows, both ping-pong levels
 
+// one launch for up to three equally wide column segments of an fp32 partial matrix with <= COLSUM_ROWS rows (the LayerNorm backward's partial rows)
+int vc_colsum_seg(const float* x, long ld, long rows, int seg, int nseg, float* out0, float* out1, float* out2, vc_stream_t s) {
+    if (rows <= 0 || seg <= 0) return VC_OK;
+    if (rows > COLSUM_ROWS || nseg < 1 || nseg > 3) { vc_set_error("vc_colsum_seg: %ld rows / %d segments", rows, nseg); return VC_ERR_ARG; }
+    ProfScope ps(VC_CAT_OTHER, 0, (double)rows * seg * nseg * 4, s);
+    ColsumParams p = ColsumParams();
+    p.x = x; p.ld = ld; p.rows = rows; p.cols = seg * nseg; p.rows_per_block = COLSUM_ROWS; p.out = out0; p.out1 = out1; p.out2 = out2; p.seg = seg;
+    VC_LAUNCH((colsum_pass_kernel<float>), dim3(VC_CEIL_DIV(seg * nseg, 64), 1, 1), dim3(256), 0, s, p);
+    return VC_OK;
+}
 int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, int accumulate,
               int batch, long bstride_x, long bstride_out, float* ws, vc_stream_t s) {
     if (rows <= 0 || cols <= 0) return VC_OK;
@@ -79,7 +85,7 @@ int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, i
     while (true) {
         const bool last = cur_rows <= COLSUM_ROWS;
         const long nblk = last ? 1 : VC_CEIL_DIV(cur_rows, COLSUM_ROWS);
-        ColsumParams p;
+        ColsumParams p; p.seg = 0; p.out1 = p.out2 = nullptr;
         p.x = cur; p.ld = cur_ld; p.rows = cur_rows; p.cols = cols; p.batch_stride_x = cur_bs; p.rows_per_block = COLSUM_ROWS;
         float* dst = last ? out : (useA ? wsA : wsB);
         p.out = dst; p.ld_out_rows = last ? 0 : cols; p.batch_stride_out = last ? bstride_out : nblk * cols; p.accumulate = last ? accumulate : 0;
