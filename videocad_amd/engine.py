@@ -54,6 +54,7 @@ class NativeEngine:
         self.params = self.grads = self.m = self.v = self.shadow = None
         self.ws = None
         self.step_count = 0
+        self.gemm_flags = 0           # kernel-selection flags of this engine's GEMMs (lib.GEMM_*; the data-parallel trainer sets GEMM_DYNAMIC)
         self.fwd_serial = 0           # bumped by every call that overwrites the engine's single activation set (forward, infer_begin)
         self.fp8 = False
         self.allocate(self.device)
@@ -115,7 +116,7 @@ class NativeEngine:
 
     def set_dynamic_items(self, on: bool = True):
         """persistent GEMM draws its items with tickets (robust while communication kernels hold CUs): the data-parallel trainer turns it on"""
-        self.set_gemm_flags((getattr(self, "gemm_flags", 0) & ~L.GEMM_DYNAMIC) | (L.GEMM_DYNAMIC if on else 0))
+        self.set_gemm_flags((self.gemm_flags & ~L.GEMM_DYNAMIC) | (L.GEMM_DYNAMIC if on else 0))
 
     def kernel_launches(self, family: int) -> int:
         return int(self.lib.vcad_kernel_launches(self.h, int(family)))
