@@ -171,6 +171,7 @@ def _ddp_worker(rank, world, port, tmp, q):
         pk = {"loader": [tb], "sampler": None}
         tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=rank)
         assert tr.gradsync.world == world
+        assert model._engine.gemm_flags & L.GEMM_DYNAMIC, "data-parallel runs draw the persistent GEMM's items with tickets (RCCL holds CUs)"
         # GradSync's constructor broadcast rank 0's parameters (what the DDP wrap did in the reference, experiment.py:104-109)
         w0 = torch.from_numpy(synth.make_param("embed_state.weight", shapes["embed_state.weight"]))
         assert torch.equal(model.embed_state.weight.detach(), w0), "initial parameters were not broadcast from rank 0"
