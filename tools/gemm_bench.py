@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from videocad_amd import lib as L
 
 if os.environ.get("VCAD_ABL"):      # ablated build (tools/gemm_ablate.sh): timing only, results are garbage
-    L._lib = L.declare(C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", f"libvcad_abl{os.environ['VCAD_ABL']}.so")))
+    os.environ["VCAD_AB_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", f"libvcad_abl{os.environ['VCAD_ABL']}.so")
 lib = L.load_ab()
 dev = "cuda:0"
 BF, F32 = torch.bfloat16, torch.float32
