@@ -1,6 +1,8 @@
 """Host side of the input path: the collate twin against a literal restatement of the reference's
 pad / stack semantics (reference data_loader/data_loader.py:313-366), PIL-exact grayscale, the uint8 <-> fp32 equivalence the
 patchify kernel relies on, and the staging iterator on the CPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -157,3 +159,35 @@ def test_pkl_dataset_items_match_the_reference_getitem(tmp_path):
     assert b["frames"].shape == (2, 6, 224, 224, 3) and int(b["frames"][0, 4:].max()) == 0 and b["cad_image"].shape == (2, 1, 224, 224)
     with pytest.raises(IndexError):
         ds["f32"][3]
+
+
+def test_pkl_dataset_multiview_items(tmp_path):
+    """reference data_loader.py:416-431, 479-490: `view_ids` -> [V,1,H,W] views read from <multiview_dir>/<id[:4]>/<id>_<view>.png, each
+    BGR2GRAY -> /255 -> Normalize like the CAD image; stacked by the collate into [B,V,1,H,W] (what `vcad_set_multiview` takes)"""
+    Image = pytest.importorskip("PIL.Image")
+    ids, raw = _write_dataset(str(tmp_path / "data"))
+    rng = np.random.default_rng(5)
+    views = {}
+    for cid in ids:
+        os.makedirs(tmp_path / "mv" / cid[:4], exist_ok=True)
+        for v in ("a", "b"):
+            img = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8); views[(cid, v)] = img
+            Image.fromarray(img).save(str(tmp_path / "mv" / cid[:4] / f"{cid}_{v}.png"))
+    with pytest.raises(ValueError):
+        D.PklClipDataset(str(tmp_path / "data"), mode="f32", view_ids=["a"])                    # no multiview_dir
+    ds = D.PklClipDataset(str(tmp_path / "data"), mode="f32", view_ids=["a", "b"], multiview_dir=str(tmp_path / "mv"))
+    d8 = D.PklClipDataset(str(tmp_path / "data"), mode="gray8", view_ids=["a", "b"], multiview_dir=str(tmp_path / "mv"))
+    for i, cid in enumerate(sorted(ids)):
+        mv = ds[i]["multiview_images"]
+        assert mv.shape == (2, 1, 224, 224) and mv.dtype == torch.float32
+        for j, v in enumerate(("a", "b")):
+            bgr = views[(cid, v)][..., ::-1].astype(np.uint32)
+            gray = ((bgr[..., 0] * 1868 + bgr[..., 1] * 9617 + bgr[..., 2] * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+            ref = (torch.from_numpy(gray.astype(np.float32) / 255.0).unsqueeze(0) - 0.5) / 0.5
+            assert torch.equal(mv[j], ref)
+        assert d8[i]["multiview_images"].dtype == torch.uint8 and torch.equal(D.normalize_u8(d8[i]["multiview_images"]), mv)
+    b = D.collate_with_padding([ds[0], ds[1]], pin=False)
+    assert b["multiview_images"].shape == (2, 2, 1, 224, 224)
+    os.remove(str(tmp_path / "mv" / sorted(ids)[0][:4] / f"{sorted(ids)[0]}_b.png"))
+    with pytest.raises(ValueError):
+        ds[0]

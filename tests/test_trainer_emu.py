@@ -270,3 +270,90 @@ def test_cached_sequential_inference_matches_the_oracle_step_by_step(emu, over):
         with torch.no_grad():
             oc, op = O.model_forward(P, frames, torch.cat(fed, 1), cad, ocfg)[:2]
         assert U.relerr(c2, oc) < 2e-5 and U.relerr(p2, op) < 2e-5
+
+
+def test_frozen_mode_groups_round_trip_through_the_reference_layout(emu, tmp_path, monkeypatch):
+    """`frozen` (reference trainer.py:236-248): three param_groups (CAD ViT, state ViT, the rest) with their own learning rates.  The name-keyed
+    exchange keeps them: `state_dict_for` emits one group per native group (dead reference parameters ride in the last one), a torch Adam built
+    with the reference's three groups accepts it, and `load_state_dict_from` maps each checkpoint group's lr onto the native group that holds its
+    parameters — whatever the order of the groups in the checkpoint."""
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), "class_weights.json")
+    ref_names = json.load(open(os.path.join(HERE, "golden", "reference_param_order.json")))["named_parameters"]
+    cfg, ocfg = small()
+    model, mtype, shapes = make_model(cfg, ocfg)
+    names = [n for n in ref_names if n in shapes or not n.startswith(("state_embedding_model.", "cad_embedding_model.", "transformer_decoder."))]
+    nb, tb = tbatch(1, 2, 4)
+    pk = {"loader": [tb], "sampler": None}
+    tc = {"lr": 3e-5, "lr_cad": 1e-6, "lr_state": 2e-6, "frozen": True, "use_mse": True, "experiment_name": "fz"}
+    tr = create_trainer(pk, pk, pk, model, tc, "cpu", mtype, rank=0)
+    tr._process_batch(tb)
+    sd = tr.optimizer.state_dict_for(names)
+    assert [g["lr"] for g in sd["param_groups"]] == [1e-6, 2e-6, 3e-5]
+    assert sorted(i for g in sd["param_groups"] for i in g["params"]) == list(range(len(names)))
+    assert all(names[i].startswith("cad_embedding_model.") for i in sd["param_groups"][0]["params"])
+    assert all(names[i].startswith("state_embedding_model.") for i in sd["param_groups"][1]["params"])
+    assert any(names[i] not in shapes for i in sd["param_groups"][2]["params"])                     # the dead trunk rides with "the rest"
+    # a checkpoint whose groups come in another order and with other rates (what a reference run with different lr_* would have written)
+    other = {"state": sd["state"], "param_groups": [dict(sd["param_groups"][2], lr=7e-4), dict(sd["param_groups"][0], lr=5e-4), dict(sd["param_groups"][1], lr=6e-4)]}
+    model2, _, _ = make_model(cfg, ocfg)
+    tr2 = create_trainer(pk, pk, pk, model2, dict(tc, experiment_name="fz2"), "cpu", mtype, rank=0)
+    tr2.optimizer.load_state_dict_from(other, names)
+    assert [g["lr"] for g in tr2.optimizer.param_groups] == [5e-4, 6e-4, 7e-4] and tr2.optimizer.lr == [7e-4, 5e-4, 6e-4, 6e-4]
+    assert torch.equal(tr2.engine.m, tr.engine.m) and tr2.engine.step_count == 1
+    # one native group split over two learning rates cannot be represented by the fused kernel: refused, not silently merged
+    cad = other["param_groups"][1]["params"]
+    bad = {"state": sd["state"], "param_groups": [dict(other["param_groups"][0]), dict(other["param_groups"][1], params=cad[: len(cad) // 2]),
+                                                  dict(other["param_groups"][2], params=other["param_groups"][2]["params"] + cad[len(cad) // 2:])]}
+    with pytest.raises(ValueError):
+        tr2.optimizer.load_state_dict_from(bad, names)
+
+
+def test_sample_writes_the_reference_files(emu, tmp_path, monkeypatch):
+    """reference trainer.py:1066-1128 `sample`: per drawn clip `pred_actions_<id>.csv` (arg-max command + masked arg-max parameters per step),
+    `actions_<id>.csv` (ground truth from step 1 on) and the CAD image — predictions checked against the oracle's arg-maxes."""
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), "class_weights.json")
+    cfg, ocfg = small()
+    model, mtype, shapes = make_model(cfg, ocfg)
+    nb, tb = tbatch(2, 3, 9)
+
+    class DS:
+        data_files = ["/x/00010001_data.pkl", "/x/00020002_data.pkl"]
+        def __len__(self): return 2
+        def __getitem__(self, i): return {k: (v[i] if v is not None else None) for k, v in tb.items()}
+
+    class Loader(list):
+        dataset = DS()
+
+    pk = {"loader": Loader([tb]), "sampler": None}
+    tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "s"}, "cpu", mtype, rank=0)
+    tr.sample(model, n=2, folder="out", mode="test")
+    ot = O.OracleTrainer({k: v.detach().numpy() for k, v in model.state_dict().items()}, ocfg)
+    with torch.no_grad():
+        ocmds, opars, _ = ot.forward(nb)
+    want = model.apply_action_mask(ocmds.argmax(-1), opars.argmax(-1)).numpy()
+    import csv as _csv
+    for i, cid in enumerate(("00010001", "00020002")):
+        pred = np.array([[float(x) for x in r] for r in _csv.reader(open(f"out/pred_actions_{cid}.csv"))])
+        gt = np.array([[float(x) for x in r] for r in _csv.reader(open(f"out/actions_{cid}.csv"))])
+        assert pred.shape == (3, 7) and gt.shape == (3, 7) and np.array_equal(gt, nb["actions"][i, 1:])
+        assert np.array_equal(pred[:, 0], ocmds[i].argmax(-1).numpy()) and np.array_equal(pred[:, 1:], want[i])
+    assert model.training is False
+    tr.sample(model, n=2, folder="out", mode="test")                  # existing files are skipped, not rewritten
+
+
+def test_enable_profiling_writes_torch_profiler_traces(emu, tmp_path, monkeypatch):
+    """reference trainer.py:394-439, 461-469: `enable_profiling` + `profile_warmup_steps` / `profile_active_steps` -> torch.profiler traces under
+    logs/<experiment>/profile_traces/epoch<E>/rank<R>"""
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), "class_weights.json")
+    cfg, ocfg = small()
+    model, mtype, _ = make_model(cfg, ocfg)
+    nb, tb = tbatch(1, 2, 4)
+    pk = {"loader": [tb, tb, tb], "sampler": None}
+    tc = {"lr": 1e-5, "use_mse": True, "experiment_name": "p", "enable_profiling": True, "profile_warmup_steps": 1, "profile_active_steps": 1, "log_frequency": 0}
+    tr = create_trainer(pk, pk, pk, model, tc, "cpu", mtype, rank=0)
+    tr.train(1)
+    d = os.path.join("logs", "p", "profile_traces", "epoch0", "rank0")
+    assert os.path.isdir(d) and any(f.endswith(".json") or f.endswith(".json.gz") for f in os.listdir(d)), os.listdir(d) if os.path.isdir(d) else d

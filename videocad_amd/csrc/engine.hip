@@ -1140,6 +1140,9 @@ static int infer_begin_any(vcad_engine* e, const void* cad, int u8, int B, int T
     vc_stream_t s = (vc_stream_t)stream; Ctx cx{e, s}; const vcad_config& c = e->c;
     const int H = c.hidden_size, D = c.vit_dim;
     int rc = cx.refresh_q8();                                 // (VCAD_FP8: quantised weight copies, no-op otherwise)
+    // the re-plan moved the persistent GEMM's ticket counters (Lane::claim) onto workspace bytes that held activations: zero them before any
+    // ticket-drawn launch (VCAD_GEMM_DYNAMIC stays on after data-parallel training) — every launch leaves them at zero again
+    for (int ln = 0; ln < 2 && !rc; ++ln) rc = vc_memset_async(e->lane[ln].claim, 0, 64 * sizeof(int), s);
     if (!rc) rc = vit_forward(cx, 1, cad, 1, (long)c.image_size * c.image_size);
     if (!rc) { Epi ep; ep.bias = cx.Pf(e->o_ei_b); rc = cx.lin_fwd(cx.AT(e->va[1].e, D), cx.W(e->o_ei_w, D), cx.AT(e->cadE, H), B, H, D, ep); }
     if (!rc && c.enable_past_actions && c.enable_past_states) {

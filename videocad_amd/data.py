@@ -80,16 +80,28 @@ class PklClipDataset:
     modes (normalised in-kernel), the same fp32 for 'f32'.  Stored frames and renders must already be image_size (the released dataset is
     `data_resized`): the reference's Resize / cv2.resize are identities there and are not restated."""
 
-    def __init__(self, dataset_path: str, image_dir: Optional[str] = None, mode: str = "rgb8", image_suffix: str = "_frame.png", image_size=(224, 224)):
+    def __init__(self, dataset_path: str, image_dir: Optional[str] = None, mode: str = "rgb8", image_suffix: str = "_frame.png", image_size=(224, 224),
+                 view_ids=None, multiview_dir: Optional[str] = None):
         import os
         assert mode in ("rgb8", "gray8", "f32")
         self.mode, self.image_size, self.image_suffix = mode, tuple(image_size), image_suffix
         self.image_dir = image_dir if image_dir is not None else dataset_path
-        files = []
+        self.view_ids = list(view_ids) if view_ids else []                      # reference :418-431: `<multiview_dir>/<id[:4]>/<id>_<view>.png`
+        self.multiview_dir = multiview_dir
+        if self.view_ids and not multiview_dir:
+            raise ValueError("PklClipDataset: view_ids needs multiview_dir (the reference leaves base_dir unbound without it, data_loader.py:421-423)")
+        files, png_ids = [], set()
         for root, _dirs, fs in os.walk(dataset_path):
             files += [os.path.join(root, f) for f in fs if f.endswith("_data.pkl")]
+            png_ids.update(f.split("_")[0] for f in fs if f.endswith(".png"))
         self.data_files = sorted(files)                                         # reference :307-310: sorted, one render per clip id
-        self.ids = [os.path.basename(f).split("_")[0] for f in self.data_files]
+        if png_ids:
+            # the reference pairs the idx-th sorted pkl PATH with the idx-th sorted PNG id found under the same tree (:297-311, :411) and asserts
+            # the two lists have one length; kept, so a directory layout whose two orders differ resolves exactly as it does there
+            self.ids = sorted(png_ids)
+            assert len(self.data_files) == len(self.ids), "Number of data files and image files must be the same"
+        else:                                                                   # renders live elsewhere (image_dir): the clip id is the pkl's own prefix
+            self.ids = [os.path.basename(f).split("_")[0] for f in self.data_files]
 
     def __len__(self):
         return len(self.data_files)
@@ -120,7 +132,26 @@ class PklClipDataset:
         else:
             ft = frames_from_rgb(frames, as_uint8=False); cad = normalize_u8(cad)
         return {"frames": ft, "actions": torch.from_numpy(actions.astype(np.float32)), "cad_image": cad,
-                "multiview_images": None, "timesteps": torch.arange(ft.shape[0])}
+                "multiview_images": self._multiview(self.ids[idx]), "timesteps": torch.arange(ft.shape[0])}
+
+    def _multiview(self, clip_id: str):
+        """reference data_loader.py:416-431, 479-490: the views of a clip, each cv2-read -> BGR2GRAY -> /255 -> Normalize: [V,1,H,W], uint8 gray in
+        the uint8 modes (normalised inside the patchify kernel like the CAD image), normalised fp32 in 'f32'; None without view_ids."""
+        if not self.view_ids:
+            return None
+        import os
+        from PIL import Image
+        views = []
+        for v in self.view_ids:
+            path = os.path.join(self.multiview_dir, clip_id[:4], f"{clip_id}_{v}.png")
+            if not os.path.exists(path):
+                raise ValueError(f"Missing view {v} for file {clip_id}")
+            rgb = np.asarray(Image.open(path).convert("RGB"))
+            if rgb.shape[:2] != self.image_size[::-1]:
+                raise ValueError(f"{path}: {rgb.shape[:2]} render, expected {self.image_size[::-1]} (resize offline)")
+            views.append(torch.from_numpy(cv2_bgr2gray_u8(rgb[..., ::-1])).unsqueeze(0))
+        mv = torch.stack(views)
+        return mv if self.mode != "f32" else normalize_u8(mv)
 
 
 # ------------------------------------------------------------------------------------------------ collate

@@ -156,17 +156,36 @@ class NativeAdam:
         missing = [n for n in named if n not in pos]
         if missing:
             raise KeyError(f"state_dict_for: {len(missing)} trained parameters are not in param_names (e.g. {missing[:3]})")
-        g = self._group(self.param_groups[-1]["lr"], list(range(len(param_names))))
-        return {"state": {pos[n]: st for n, st in named.items()}, "param_groups": [g]}
+        # one param_group per native group (the reference's `frozen` mode, trainer.py:236-248: CAD ViT, state ViT, everything else — each with
+        # its own lr); names this model does not hold (the reference's dead GPT-2 trunk etc.) belong to the reference's last group ("neither ViT")
+        mine = {self.names[i]: gi for gi, g in enumerate(self.param_groups) for i in g["params"]}
+        groups = [self._group(g["lr"], []) for g in self.param_groups]
+        for i, n in enumerate(param_names):
+            groups[mine.get(n, len(groups) - 1)]["params"].append(i)
+        return {"state": {pos[n]: st for n, st in named.items()}, "param_groups": groups}
 
     def load_state_dict_from(self, sd, param_names):
-        """inverse of state_dict_for: accepts the optimizer_state_dict of an Adam built over `param_names` (a reference checkpoint)"""
+        """inverse of state_dict_for: accepts the optimizer_state_dict of an Adam built over `param_names` (a reference checkpoint).  Learning
+        rates are mapped through parameter NAMES: each native group takes the lr of the checkpoint group that holds its parameters (so the
+        reference's three `frozen` groups, in whatever order and with its extra dead parameters, land on the right buckets)."""
         idx = {n: i for i, n in enumerate(self.names)}
         conv = {idx[param_names[int(i)]]: st for i, st in sd.get("state", {}).items() if param_names[int(i)] in idx}
         self.load_state_dict({"state": conv, "param_groups": []})
-        if sd.get("param_groups"):
-            for g in self.param_groups:
-                g["lr"] = sd["param_groups"][0]["lr"]
+        src_groups = sd.get("param_groups") or []
+        if not src_groups:
+            return
+        lr_of = {}
+        for g in src_groups:
+            for i in g["params"]:
+                if 0 <= int(i) < len(param_names):
+                    lr_of[param_names[int(i)]] = g["lr"]
+        for g in self.param_groups:
+            lrs = {lr_of[self.names[i]] for i in g["params"] if self.names[i] in lr_of}
+            if len(lrs) > 1:
+                raise ValueError(f"load_state_dict_from: the checkpoint trains one native parameter group at {len(lrs)} learning rates {sorted(lrs)}; "
+                                 "the fused Adam kernel keeps one lr per gradient bucket (CAD ViT / state ViT / rest)")
+            if lrs:
+                g["lr"] = lrs.pop()
 
     def load_state_dict(self, sd):
         eng = self.engine
@@ -261,7 +280,12 @@ class GradSync:
         # (r02 reduced it last, leaving bucket 1 + bucket 3 = 99 MB with nothing to hide behind; now only bucket 3 is exposed).
         eng.backward(dcmds, dpars, stage=0); reduce_bucket(0)
         eng.backward(dcmds, dpars, stage=1, side=True)
+        # When the engine did NOT fork (enable_past_states off, side stream disabled, profiler on, stream creation failed) stage 1 ran on `cur`
+        # and join_side() is a no-op: the communication stream must then wait for `cur` itself.  When it did fork this event sits right
+        # behind stage 0's kernels (which the comm stream has waited for already), so the wait is free.
+        ev1 = torch.cuda.Event(); ev1.record(cur)
         with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev1)
             eng.join_side()                                         # comm stream <- side-stream event
             if not self.skip_comm:
                 lo, hi = eng.buckets[1]
@@ -454,10 +478,40 @@ class BaseTrainer:
         self._params_changed()
         self.log(f"Loaded best model from epoch {best_state['epoch']}")
 
-    # ---- reference trainer.py:384-478 (torch.profiler hook omitted: rocprofv3 / vcad_profile_* are the tools here)
+    def _make_profiler(self, epoch):
+        """reference trainer.py:394-439: `enable_profiling` -> a torch.profiler over the first `profile_warmup_steps` + `profile_active_steps`
+        batches of the epoch, traces under logs/<experiment>/profile_traces/epoch<E>/rank<R> (same keys, schedule and directory layout; on ROCm the
+        CUDA activity is the HIP kernels of this library)."""
+        if not self.training_config.get("enable_profiling", False):
+            return None, 0, None
+        warm, active = self.training_config.get("profile_warmup_steps", 5), self.training_config.get("profile_active_steps", 15)
+        base = f"./logs/{self.experiment_name}/profile_traces"
+        rank_dir = f"{base}/epoch{epoch}/rank{self.rank}"
+        if self.is_master:
+            os.makedirs(f"{base}/epoch{epoch}", exist_ok=True)
+        d = _dist()
+        if d is not None:
+            d.barrier()
+        try:
+            os.makedirs(rank_dir, exist_ok=True)
+        except OSError as e:
+            print(f"Warning: Rank {self.rank} could not create profiler directory: {e}")
+            rank_dir = f"./profile_traces_epoch{epoch}_rank{self.rank}"
+            os.makedirs(rank_dir, exist_ok=True)
+        acts = [torch.profiler.ProfilerActivity.CPU]
+        if torch.device(self.device).type == "cuda":
+            acts.append(torch.profiler.ProfilerActivity.CUDA)
+        prof = torch.profiler.profile(activities=acts, schedule=torch.profiler.schedule(wait=0, warmup=warm, active=active, repeat=1),
+                                      on_trace_ready=torch.profiler.tensorboard_trace_handler(rank_dir), record_shapes=True, profile_memory=True,
+                                      with_stack=True)
+        prof.__enter__()
+        return prof, warm + active, rank_dir
+
+    # ---- reference trainer.py:384-478
     def _train_epoch(self, epoch, noise=False):
         self.model.train()
         metrics = self.init_metrics()
+        prof, prof_steps, prof_dir = self._make_profiler(epoch)
         loader = DeviceStager(self.train_loader, self.device) if (self.stage_inputs and torch.device(self.device).type == "cuda") else self.train_loader
         running = torch.zeros((), device=self.device)
         counters = torch.zeros(L.NMETRIC, dtype=torch.int64, device=self.device)
@@ -471,6 +525,11 @@ class BaseTrainer:
             if log_every and (batch_idx + 1) % log_every == 0:
                 m = self.init_metrics(); self.update_metrics(m, metrics_from_counters(counters.tolist()))
                 self.log_metrics(epoch, self.training_config.get("epochs", 0), batch_idx, len(self.train_loader), float(loss), metrics=m)
+            if prof is not None and batch_idx < prof_steps:
+                prof.step()
+        if prof is not None:
+            prof.__exit__(None, None, None)
+            self.log(f"Profiler trace for epoch {epoch} (rank {self.rank}) saved to: {prof_dir}")
         self.update_metrics(metrics, metrics_from_counters(counters.tolist()))
         return (float(running) / n if n else 0.0), metrics
 
@@ -485,13 +544,23 @@ class BaseTrainer:
     def _handle_early_stopping(self, epoch, avg_loss, val_metrics, best_value, patience, best_state):
         if not self.early_stopping_enabled:
             return best_value, patience, best_state, False
-        cur = avg_loss
-        if self.early_stopping_metric == "accuracy" and val_metrics and val_metrics.get("total_predictions", 0):
-            cur = val_metrics["correct_predictions"] / val_metrics["total_predictions"]
+        # ONE decision for all ranks (no rank may leave the loop alone: the next all-reduce would deadlock), computed ONCE from all-reduced raw
+        # numerators / denominators — not from an average of per-rank values, which would mix a rank that fell back to its loss with ranks that
+        # report accuracy, and let one rank's non-finite loss poison every rank's decision
+        correct = float(val_metrics.get("correct_predictions", 0)) if val_metrics else 0.0
+        total = float(val_metrics.get("total_predictions", 0)) if val_metrics else 0.0
+        finite = 1.0 if (avg_loss == avg_loss and abs(avg_loss) != float("inf")) else 0.0
+        v = [correct, total, float(avg_loss) if finite else 0.0, finite]
         d = _dist()
-        if d is not None:       # ONE decision for all ranks: the monitored value is averaged (avg_loss is per rank, validation may have been
-            v = torch.tensor([float(cur)], dtype=torch.float64, device=self.device)        # skipped or left unreduced), so patience, best_value
-            d.all_reduce(v); cur = float(v.item()) / d.get_world_size()                   # and the best-weights snapshot advance in lock-step
+        if d is not None:
+            t = torch.tensor(v, dtype=torch.float64, device=self.device)
+            d.all_reduce(t); v = t.tolist()
+        if self.early_stopping_metric == "accuracy" and v[1] > 0:
+            cur = v[0] / v[1]
+        elif v[3] > 0:
+            cur = v[2] / v[3]                                        # mean training loss over the ranks that have a finite one
+        else:
+            cur = float("inf") if self.early_stopping_mode == "min" else float("-inf")     # nothing usable anywhere: counts as "no improvement"
         improved = cur < best_value - self.early_stopping_min_delta if self.early_stopping_mode == "min" else cur > best_value + self.early_stopping_min_delta
         if improved:
             self.log(f"Validation {self.early_stopping_metric} improved from {best_value:.4f} to {cur:.4f}")
