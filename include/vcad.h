@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless it says "host"; the caller (PyTorch caching allocator) owns
- *     every buffer including the workspace; the library keeps no device state of its own
+ *     every buffer including the workspace.  The library allocates no device MEMORY; the device objects it owns are, per engine, one
+ *     non-blocking side stream + four events (created on first use, destroyed with the engine: the CAD ViT runs there beside the frame ViT)
+ *     and, per process, the HIP-event profiler's event list between vcad_profile_begin / _end (off by default)
  *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); nothing here synchronises the device
  *   - return value 0 = ok; non-zero = error, text via vcad_last_error() (thread-local)
  *   - dtype: VCAD_F32 = exact-fp32 parity mode (f32 MFMA), VCAD_BF16 = bf16 MFMA with fp32 accumulate,
@@ -54,8 +56,9 @@ int vcad_param_count(const vcad_engine* e);                       /* number of n
 /* name -> host char buffer; shape[4] padded with 0; offset/numel in floats */
 int vcad_param_info(const vcad_engine* e, int index, char* name, size_t name_cap, int64_t* offset, int64_t* numel,
                     int64_t shape[4], int* ndim);
-/* number of DDP buckets and the [begin,end) float range of bucket i; bucket i's gradients are final when
- * vcad_backward_stage(i) has been enqueued (heads+decoder+stem first, ViT patch-embed last) */
+/* number of DDP buckets (5) and the [begin,end) float range of bucket i; bucket i's gradients are final when
+ * vcad_backward_stage(i) has been enqueued: 0 = heads + decoder, 1 = stem, 2 = CAD ViT, 3 = frame ViT upper half, 4 = lower half +
+ * patch embed */
 int vcad_bucket_count(const vcad_engine* e);
 int vcad_bucket_range(const vcad_engine* e, int bucket, int64_t* begin, int64_t* end);
 
@@ -127,8 +130,12 @@ int vcad_dlogits_offsets(const vcad_engine* e, size_t* off_cmds, size_t* off_par
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dparams, void* stream);
 /* the same, one DDP bucket at a time (stage 0 .. vcad_bucket_count-1, in order) so the caller can overlap RCCL */
 int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
-/* Stage 1 (the CAD ViT's backward, independent of stages 2-3) on the library's side stream: the caller runs stages 2 and 3
-   and their all-reduces, then vcad_join_side() (its stream waits for stage 1) and only then reduces bucket 1. */
+/* Stage vcad_side_stage() (= 2: the CAD ViT's backward, independent of the frame ViT's stages 3-4) on the library's side stream: the caller
+   goes on with stages 3 and 4 and their all-reduces; vcad_join_side(stream) makes `stream` (the caller's, or its communication stream) wait
+   for that stage, after which bucket 2 may be reduced.  When the engine cannot fork (enable_past_states off, vcad_set_side_stream(0), the
+   HIP-event profiler recording) the stage runs on the caller's stream in line and vcad_join_side is a no-op: a communication stream must
+   then wait for the caller's stream itself (videocad_amd/trainer.py: GradSync does both). */
+int vcad_side_stage(const vcad_engine* e);
 int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
 int vcad_join_side(vcad_engine* e, void* stream);
 
@@ -138,7 +145,7 @@ int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, floa
                         float grad_scale, float* norm_out, void* stream);
 
 /* per-bucket learning rates (lr_per_bucket: HOST, vcad_bucket_count() floats): the reference's `frozen` mode (trainer.py:237-251)
- * gives cad_embedding_model, state_embedding_model and the rest their own lr = buckets 1, 2-3 and 0; the clip norm stays global */
+ * gives cad_embedding_model, state_embedding_model and the rest their own lr = buckets 2, 3-4 and 0-1; the clip norm stays global */
 int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_per_bucket, float beta1, float beta2, float eps, float max_norm,
                                int step, float grad_scale, float* norm_out, void* stream);
 

@@ -153,7 +153,20 @@ def test_multiview_model_through_factory_and_trainer_under_emulator(emu, tmp_pat
         model.sequential_inference(bd["frames"][:, :-1], bd["cad_image"])          # as in the reference, inference has no multiview input
 
 
-def _ddp_worker(rank, world, port, tmp, q):
+def _q_get(q, procs, timeout=900):
+    """q.get that gives up as soon as a worker has died (instead of sitting out the whole timeout)"""
+    import queue, time
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                raise AssertionError(f"a worker died: exit codes {[p.exitcode for p in procs]}")
+    raise AssertionError("workers timed out")
+
+
+def _ddp_worker(rank, world, port, tmp, q, wrap=False):
     import torch.distributed as dist
     _cwd_with_class_weights(tmp)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -166,21 +179,75 @@ def _ddp_worker(rank, world, port, tmp, q):
         if rank == 0:                                 # ... and only rank 0 holds the weights the check expects
             model.load_state_dict({k: torch.from_numpy(synth.make_param(k, s)) for k, s in shapes.items()}, strict=True)
         model.eval()
+        native = model
+        calls = {"n": 0, "elems": 0}
+        if wrap:
+            # exactly what reference experiment.py:104-109 does to the model before create_trainer (device_ids only exist on a GPU)
+            from torch.nn.parallel import DistributedDataParallel
+            model = DistributedDataParallel(model, find_unused_parameters=True)
+            real = dist.all_reduce
+            def counted(t, *a, **k):
+                calls["n"] += 1; calls["elems"] += t.numel()
+                return real(t, *a, **k)
+            dist.all_reduce = counted
         batch = synth.make_batch(1, 2, seed=10 + rank)
         tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
         pk = {"loader": [tb], "sampler": None}
         tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=rank)
         assert tr.gradsync.world == world
-        assert model._engine.gemm_flags & L.GEMM_DYNAMIC, "data-parallel runs draw the persistent GEMM's items with tickets (RCCL holds CUs)"
+        assert native._engine.gemm_flags & L.GEMM_DYNAMIC, "data-parallel runs draw the persistent GEMM's items with tickets (RCCL holds CUs)"
         # GradSync's constructor broadcast rank 0's parameters (what the DDP wrap did in the reference, experiment.py:104-109)
         w0 = torch.from_numpy(synth.make_param("embed_state.weight", shapes["embed_state.weight"]))
-        assert torch.equal(model.embed_state.weight.detach(), w0), "initial parameters were not broadcast from rank 0"
+        assert torch.equal(native.embed_state.weight.detach(), w0), "initial parameters were not broadcast from rank 0"
+        calls["n"] = calls["elems"] = 0
         tr._process_batch(tb)
+        if wrap:
+            # ONE gradient exchange per step: GradSync's collectives cover the flat gradient buffer exactly once, and the DDP wrapper's own reducer
+            # never ran (its forward is never entered, so no autograd hook fired: no .grad was produced on any parameter)
+            eng = native._engine
+            assert tr.native is native and calls["n"] == len(eng.buckets), calls
+            assert calls["elems"] == eng.buckets[-1][1] - eng.buckets[0][0], calls
+            assert all(p.grad is None for p in model.parameters())
+            if rank == 0:                                                       # the summed gradient itself (Adam's first step hides a doubled gradient)
+                q.put({"__grads__": {n: eng.view(n, eng.grads).detach().clone().numpy() for n in shapes}})
         if rank == 0:
-            q.put({n: p.detach().clone().numpy() for n, p in model.named_parameters()})
+            q.put({n: p.detach().clone().numpy() for n, p in native.named_parameters()})
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_ddp_wrapped_model_does_one_gradient_exchange(tmp_path):
+    """`north_star`: "drops into experiment.py unchanged" — so the wrap at reference experiment.py:104-109
+    (`DistributedDataParallel(model, find_unused_parameters=True)`) WILL sit around the native module (whose parameters are views of one flat
+    buffer).  `create_trainer` unwraps it; the step's only gradient exchange is GradSync's (one collective sweep over the flat buffer — DDP's
+    reducer never runs because its forward is never entered), and the summed gradient / the updated weights equal the oracle's mean-gradient step."""
+    import torch.multiprocessing as mp
+    U.load_emu()
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 7
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q, True)) for r in range(world)]
+    [p.start() for p in procs]
+    first = _q_get(q, procs); second = _q_get(q, procs)
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    grads, got = (first["__grads__"], second) if "__grads__" in first else (second["__grads__"], first)
+    _, ocfg = small_model(None)
+    shapes = O.param_shapes(ocfg)
+    ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in shapes.items()}, ocfg)
+    gsum = None
+    for r in range(world):
+        ot.loss_and_grads(synth.make_batch(1, 2, seed=10 + r))
+        g = {k: p.grad.clone() for k, p in ot.P.items()}
+        gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
+    # the flat buffer holds the SUM over ranks (1/world is folded into the Adam kernel): a second, redundant all-reduce would show as 2x here
+    worst = max((U.relerr(torch.from_numpy(grads[n]), gsum[n]), n) for n in grads if float(gsum[n].norm()) > 1e-6)
+    assert worst[0] < 2e-4, worst
+    ot.apply_grads({k: v / world for k, v in gsum.items()})
+    d = max((float(np.abs(got[n] - ot.P[n].detach().numpy())[np.abs(gsum[n].numpy()) > 2e-6].max(initial=0.0)), n) for n in got)
+    assert d[0] < 2e-6, d
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -195,7 +262,7 @@ def test_gloo_data_parallel_step_matches_mean_of_gradients(tmp_path, world):
     port = 29500 + (os.getpid() % 2000) + world
     procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
     [p.start() for p in procs]
-    got = q.get(timeout=900)
+    got = _q_get(q, procs)
     [p.join(timeout=300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     _, ocfg = small_model(None)

@@ -412,8 +412,8 @@ def test_multiview_branch_matches_reference_goldens(golden_dir, dtype, tol, gtol
 
 
 def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
-    """The data-parallel order (stage 0, stage 1 on the side stream, stages 2-3, join) must produce exactly the gradients of
-    the single-call backward: same kernels, only the stream they are issued on differs."""
+    """The data-parallel order (stages 0-1, the CAD ViT's stage on the side stream, the frame ViT's stages, join) must produce exactly the
+    gradients of the single-call backward: same kernels, only the stream they are issued on differs."""
     eng = build(L.VCAD_BF16)
     B, T = 2, 8
     batch = synth.make_batch_torch(B, T, 11, DEV, None)
@@ -427,9 +427,11 @@ def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
         if not staged:
             eng.backward()
         else:
-            eng.backward(stage=0)
-            eng.backward(stage=1, side=True)
-            for st in range(2, len(eng.buckets)):
+            assert len(eng.buckets) == 5 and eng.side_stage == 2
+            for st in range(eng.side_stage):
+                eng.backward(stage=st)
+            eng.backward(stage=eng.side_stage, side=True)
+            for st in range(eng.side_stage + 1, len(eng.buckets)):
                 eng.backward(stage=st)
             eng.join_side()
         torch.cuda.synchronize()

@@ -30,6 +30,19 @@ GRAD_PROBES = ["predict_action_class_0_999.weight", "predict_action_class_0_4.bi
 _ORACLE = {}
 
 
+def record(name, **vals):
+    """measured accuracy numbers of the full-size runs, appended as JSON lines under gpurun_out/ (copied to profiles/<round>_fullsize_measured.jsonl
+    when they are quoted): the gates below are ~1.5x these"""
+    import json, os
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "fullsize_measured.jsonl"), "a") as f:
+            f.write(json.dumps(dict(case=name, **vals)) + "\n")
+    except OSError:
+        pass
+
+
 def oracle_two_clips(T):
     """fp32 oracle on the 2-clip batch of horizon T (cached per T: C2/C3/C4 differ in T)."""
     if T not in _ORACLE:
@@ -98,12 +111,16 @@ def test_full_size_step_bf16_close_and_train_mode_sane(name, B, T):
     rel, mae = U.relerr(p, ref["pars"]), float((p - ref["pars"]).abs().mean())
     agree = float((p.argmax(-1) == ref["pars"].argmax(-1)).float().mean())
     print(f"\n[{name} bf16 vs fp32 oracle] logit MAE {mae:.3e}  rel {rel:.3e}  argmax agreement {agree:.4f}")
-    assert rel < 3e-2 and agree > 0.85
+    # gates at ~1.5x the measured values (profiles/r04_fullsize_measured.jsonl: rel 3.3e-3 .. 3.6e-3, arg-max 0.985 .. 0.992 on the three shapes):
+    # a 2x regression of the throughput mode at the benchmarked shape fails here
+    GATE = {"C2": (5.5e-3, 0.975), "C4_per_gpu": (5.5e-3, 0.975), "C3": (5.5e-3, 0.975)}[name]
+    assert rel < GATE[0] and agree > GATE[1], (name, rel, agree)
     assert torch.equal(pars[:2], pars[2 * (K - 1):])                       # repetitions are bit-identical: no cross-clip leakage at full grid size
     loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - ref["loss"]) < 2e-2 * abs(ref["loss"])
     eng.backward()
     worst = max(abs(float(eng.view(n, eng.grads).double().norm()) - w) / w for n, w in ref["gn"].items())
+    record(name + "_bf16", logit_mae=mae, rel_err=rel, argmax_agreement=agree, loss_rel=abs(float(loss[0]) - ref["loss"]) / abs(ref["loss"]), worst_grad_norm_rel=worst)
     assert worst < 8e-2, worst
     g_eval = float(eng.optimizer_step(lr=0.0)[0])                           # lr 0: weights untouched, norm reported
     w0 = eng.view("embed_state.weight").clone()
@@ -139,6 +156,7 @@ def test_full_size_fp8_forward_mode_c5_per_gpu_shape():
     eng.backward()
     worst = max(abs(float(eng.view(n, eng.grads).double().norm()) - w) / w for n, w in ref["gn"].items())
     print(f"[C5 per-GPU shape, fp8 forward] worst probed gradient-norm error {worst:.3e}")
+    record("C5_per_gpu_fp8_forward", logit_mae=mae, rel_err=rel, argmax_agreement=agree, worst_grad_norm_rel=worst)
     assert worst < 2.5e-1, worst
     g_eval = float(eng.optimizer_step(lr=0.0)[0])
     eng.set_dropout(0.1, seed=11)

@@ -24,7 +24,7 @@ PROBES = ["predict_action_class_0_999.weight", "transformer_decoder.layers.3.lin
 two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL over xGMI)")
 
 
-def _rank_main(rank, world, port, tmp, q):
+def _rank_main(rank, world, port, tmp, q, no_side=False):
     import torch.distributed as dist
     from videocad_amd.model_factory import ModelFactory
     from videocad_amd.trainer import create_trainer
@@ -43,9 +43,14 @@ def _rank_main(rank, world, port, tmp, q):
         tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": f"r{rank}",
                                                 "class_weights_path": os.path.join(HERE, "golden", "class_weights.json")}, dev, mtype, rank=rank)
         assert tr.gradsync.world == world and tr.gradsync.stream is not None
+        if no_side:                                             # the CAD ViT's stage then runs on the caller's stream: the communication stream must
+            model._engine.set_side_stream(False)                # wait for THAT before reducing its bucket (r03 advisor finding)
+        tr.gradsync.timing = True
         batch = synth.make_batch_torch(1, 2, 10 + rank, "cpu")
         loss, _ = tr._process_batch(batch)
         torch.cuda.synchronize()
+        rep = tr.gradsync.comm_report()
+        assert rep and len(rep["collectives"]) == 4 and all(c["done_ms"] >= c["issue_ms"] >= 0 for c in rep["collectives"]), rep
         if rank == 0:
             q.put({n: dict(model.named_parameters())[n].detach().cpu().numpy() for n in PROBES})
         dist.barrier()
@@ -54,12 +59,15 @@ def _rank_main(rank, world, port, tmp, q):
 
 
 @two_gpus
-def test_two_rank_rccl_step_matches_mean_of_oracle_gradients(tmp_path):
+@pytest.mark.parametrize("no_side", [False, True])
+def test_two_rank_rccl_step_matches_mean_of_oracle_gradients(tmp_path, no_side):
+    """no_side: the engine does not fork the CAD ViT's backward onto its side stream (also the case with enable_past_states off or the profiler on):
+    the bucket's all-reduce must still be ordered behind that stage"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + int(no_side)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, str(tmp_path), q, no_side)) for r in range(2)]
     [p.start() for p in procs]
     got = q.get(timeout=900)
     [p.join(timeout=300) for p in procs]
@@ -103,3 +111,57 @@ def test_bench_line_single_gpu_contract():
 def test_bench_gpus_2_starts_two_rccl_ranks():
     j = _bench(["--gpus", "2"])
     assert j["n_gpus"] == 2 and j["comm"]["rccl_ranks"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"
+
+
+def _one_rank_main(port, tmp, q, no_side):
+    import torch.distributed as dist
+    from videocad_amd.model_factory import ModelFactory
+    from videocad_amd.trainer import create_trainer
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    os.chdir(tmp)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        out = {}
+        for forced in (False, True):
+            model, mtype = ModelFactory().create_model("autoregressive", dict(CANON, compute_dtype="bf16"), dev)
+            model.load_state_dict({k: synth.make_param_torch(k, s, dev) for k, s in O.param_shapes().items()}, strict=True)
+            model.train()
+            pk = {"loader": [], "sampler": None}
+            tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": f"one{int(forced)}", "force_bucketed_exchange": forced,
+                                                    "class_weights_path": os.path.join(HERE, "golden", "class_weights.json")}, dev, mtype, rank=0)
+            assert tr.gradsync.staged == forced and (tr.gradsync.stream is not None) == forced
+            if no_side:
+                model._engine.set_side_stream(False)
+            tr.gradsync.timing = forced
+            model._drop_seed_base = 7                             # same dropout masks in both runs
+            batch = synth.make_batch_torch(2, 9, 31, "cpu")
+            loss, _ = tr._process_batch(batch)
+            torch.cuda.synchronize()
+            out[forced] = (float(loss), model._engine.grads.clone(), model._engine.params.clone())
+            if forced:
+                rep = tr.gradsync.comm_report()
+                assert rep and [c["bucket"] for c in rep["collectives"]] == ["0", "1-2", "3", "4"], rep
+                assert all(c["done_ms"] >= c["issue_ms"] >= 0 for c in rep["collectives"]) and rep["backward_joined_ms"] > 0, rep
+                q.put(rep)
+        assert out[False][0] == out[True][0]
+        assert bool(torch.equal(out[False][1], out[True][1])), float((out[False][1] - out[True][1]).abs().max())     # gradients bitwise the whole backward's
+        assert bool(torch.equal(out[False][2], out[True][2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("no_side", [False, True])
+def test_bucketed_exchange_on_a_one_rank_rccl_group_is_bitwise_the_plain_step(tmp_path, no_side):
+    """What a 1-GPU box can say about a17: the whole multi-stream choreography of GradSync (staged backward, side-stream stage, communication
+    stream, per-bucket `ncclAllReduce` through RCCL — a one-rank group, so each collective is RCCL's local copy kernel) runs on the device and
+    leaves exactly the gradients and weights of the plain single-call step; the per-collective issue / completion report is well formed."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_main, args=(29800 + (os.getpid() % 1000) + int(no_side), str(tmp_path), q, no_side))
+    p.start(); p.join(timeout=600)
+    assert p.exitcode == 0
+    rep = q.get(timeout=5)
+    print("comm report (1-rank RCCL group):", json.dumps(rep))

@@ -168,9 +168,9 @@ def test_attention_decoder_mfma(emu, T, window):
     U.check_attention(emu, "cpu", 2, 2, T, 256, window=window, causal=1, dt=BF16)
 
 
-@pytest.mark.parametrize("T,window", [(70, 70), (186, 186), (186, 10), (130, 1), (192, 100)])
+@pytest.mark.parametrize("T,window", [(70, 70), (186, 186), (186, 10), (130, 1), (192, 100), (200, 200), (321, 64), (257, 10)])
 def test_attention_decoder_mfma_long(emu, T, window):
-    """64 < T <= 192: the key-block kernels (forward, D_i pre-pass, dQ and dK/dV kernels)"""
+    """T > 64, any horizon (the reference allows max_ep_len = 1000): the block-streaming kernels (online-softmax forward, D_i sweep + dQ, dK/dV)"""
     U.check_attention(emu, "cpu", 1, 2, T, 256, window=window, causal=1, dt=BF16)
 
 
@@ -198,3 +198,9 @@ def test_gemm_mx8(emu, gemm_tile, to, bias, act, residual):
     if gemm_tile != 128:
         pytest.skip("tile-size fixture does not apply")
     U.check_mx8(emu, "cpu", 200, 256, 384, to, bias=bias, act=act, residual=residual)
+
+
+@pytest.mark.parametrize("T", [50, 64, 7])
+def test_attention_vit_bf16x3(emu, T):
+    """bf16x3 mode's ViT attention (attn_x3.h): fp32 tensors, hi / lo split operands on the bf16 matrix cores — forward and backward at the GEMMs' error level"""
+    U.check_attention(emu, "cpu", 3, 2, T, 64, window=T, causal=0, dt=F32, x3=True)

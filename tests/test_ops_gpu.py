@@ -157,7 +157,7 @@ def test_attention_decoder_mfma(hip, T, window):
     U.check_attention(hip, DEV, 4, 4, T, 256, window=window, causal=1, dt=BF16)
 
 
-@pytest.mark.parametrize("T,window", [(70, 70), (186, 186), (186, 10), (128, 1), (192, 100)])
+@pytest.mark.parametrize("T,window", [(70, 70), (186, 186), (186, 10), (128, 1), (192, 100), (200, 200), (321, 64), (500, 500), (1000, 10)])
 def test_attention_decoder_mfma_long(hip, T, window):
     U.check_attention(hip, DEV, 3, 4, T, 256, window=window, causal=1, dt=BF16)
 
@@ -180,3 +180,9 @@ def test_gemm_mx8(hip, to, bias, act, residual):
     v_cvt_pk_fp8_f32 behind a clamp), block-scaled fp8 MFMA GEMM against its dequantised operands; ragged M, several k-tiles"""
     U.check_mx8(hip, DEV, 5000, 512, 1024, to, bias=bias, act=act, residual=residual)
     U.check_mx8(hip, DEV, 300, 3072, 512, to, bias=bias, act=act, residual=residual, seed=5)
+
+
+@pytest.mark.parametrize("T", [50, 64, 7])
+def test_attention_vit_bf16x3(hip, T):
+    """bf16x3 mode's ViT attention (attn_x3.h): fp32 tensors, hi / lo split operands on the bf16 matrix cores — forward and backward at the GEMMs' error level"""
+    U.check_attention(hip, DEV, 3, 2, T, 64, window=T, causal=0, dt=F32, x3=True)

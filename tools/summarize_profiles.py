@@ -67,7 +67,20 @@ if pmc:
     d_ms = sum(float(r["TotalDurationNs"]) for r in ours if short(r["Name"]).startswith("gemm_dma_kernel")) / steps_traced / 1e6
     print(f"\ndominant kernel family `gemm_dma_kernel`: {d_n:.0f} launches / step, {d_ms:.3f} ms / step, average {d_ms * 1e3 / max(d_n, 1):.1f} us per launch, "
           f"{(d_rd + d_wr) * 1e3 / max(d_n, 1):.0f} MB of HBM-side traffic per launch")
-    json.dump({"tag": tag, "dominant_kernel": "gemm_dma_kernel", "dominant_launches_per_step": d_n, "dominant_ms_per_step": d_ms,
+    # provenance + a fingerprint of the library the counters were collected on: bench.py quotes `traffic` from this file only while the live
+    # library still launches the same dominant-kernel set (launch count and algorithmic bytes per launch agree), and names commit + box beside it
+    import socket, subprocess
+    def _cmd(c):
+        try:
+            return subprocess.run(c, shell=True, capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception:
+            return ""
+    box = {"hostname": socket.gethostname(), "gpu": _cmd("rocm-smi --showuniqueid --csv 2>/dev/null | sed -n 2p") or _cmd("rocminfo 2>/dev/null | grep -m1 -i uuid")}
+    rl = bench.get("roofline") or {}
+    json.dump({"tag": tag, "commit": os.environ.get("VCAD_COMMIT", "unknown"), "box": box, "collected_ms_per_step": bench.get("ms_per_step"),
+               "dominant_alg_bytes_per_launch": rl.get("alg_bytes_per_launch"), "dominant_alg_tflop_per_step": rl.get("alg_tflop_per_step"),
+               "dominant_instantiations": {short(r["Name"]): int(r["Calls"]) / steps_traced for r in ours if short(r["Name"]).startswith("gemm_dma_kernel")},
+               "dominant_kernel": "gemm_dma_kernel", "dominant_launches_per_step": d_n, "dominant_ms_per_step": d_ms,
                "dominant_avg_launch_us": d_ms * 1e3 / max(d_n, 1), "dominant_hbm_bytes_per_launch": (d_rd + d_wr) * 1e9 / max(d_n, 1),
                "gemm_read_GB_per_step": g_rd, "gemm_write_GB_per_step": g_wr, "gemm_launches_per_step": g_n,
                "gemm_hbm_bytes_per_launch": (g_rd + g_wr) * 1e9 / max(g_n, 1), "total_read_GB_per_step": sum(rd.values()),

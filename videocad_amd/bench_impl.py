@@ -208,6 +208,75 @@ def short_leg(dtype, fp8, B, T, steps, warmup, device, rank, world, seed, dropou
     return out
 
 
+def pmc_traffic(dom, d, dtype, B, T):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read inside this process; they come from the newest committed
+    rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/<round>_pmc.json; bf16 C2 workload only).  The file is
+    quoted only while it still describes THIS library: same dominant family, same launches per step and the same algorithmic bytes per launch as
+    the live profiled step (a changed dispatcher / tile policy makes it stale) — otherwise `traffic` is null and the source line says why."""
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
+        if not cands or dtype != "bf16" or (B, T) != (32, 64):
+            return None, None
+        name = cands[-1]
+        pj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        src = f"profiles/{name} (collected at commit {pj.get('commit', 'unknown')} on {json.dumps(pj.get('box', 'unknown box'))}, {pj.get('collected_ms_per_step', '?')} ms/step under the tracer)"
+        if pj.get("dominant_kernel") != dom or "dominant_hbm_bytes_per_launch" not in pj:
+            return None, f"stale: {src} — dominant kernel there is {pj.get('dominant_kernel')}, here {dom}"
+        if int(round(pj.get("dominant_launches_per_step", -1))) != int(d["launches"]):
+            return None, f"stale: {src} — {pj.get('dominant_launches_per_step')} launches per step there, {d['launches']} in this library"
+        alg = pj.get("dominant_alg_bytes_per_launch")
+        live = d["bytes"] / max(d["launches"], 1)
+        if alg and abs(alg - live) > 0.01 * live:
+            return None, f"stale: {src} — algorithmic bytes per launch {alg} there, {round(live)} in this library"
+        return round(pj["dominant_hbm_bytes_per_launch"]), src
+    except Exception as ex:
+        return None, f"unreadable: {ex!r}"
+
+
+def profile_step(tr, bd, dtype, B, T, fps_per_gpu, headline=False):
+    """ONE extra train step under the library's HIP-event profiler (events on the launch stream around every kernel family, single stream so the
+    times do not overlap) -> (per-category breakdown, roofline block of the dominant kernel family)."""
+    eng = tr.engine
+    lib = eng.lib
+    lib.vcad_profile_begin()
+    tr.train_step(bd)
+    torch.cuda.synchronize()
+    pms, pfl, pby, pln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
+    lib.vcad_profile_end(C.byref(pms), C.byref(pfl), C.byref(pby), C.byref(pln))
+    breakdown = {CATS[i]: {"ms": round(pms[i], 3), "launches": pln[i],
+                           "tflops": round(pfl[i] / (pms[i] * 1e-3) / 1e12, 1) if pms[i] > 0 and pfl[i] > 0 else None,
+                           "GBps": round(pby[i] / (pms[i] * 1e-3) / 1e9, 1) if pms[i] > 0 and pby[i] > 0 else None}
+                 for i in range(8)}
+    gemm_ms = pms[0] + pms[1] + pms[2]; gemm_fl = pfl[0] + pfl[1] + pfl[2]; gemm_n = pln[0] + pln[1] + pln[2]
+    peak = PEAK_TFLOPS[dtype]
+    fam = {}
+    for tag, name in ((1, "gemm_dma_kernel"), (2, "gemm_kernel"), (3, "gemm_mid_kernel"), (4, "gemm_grouped_kernel")):
+        o4 = (C.c_double * 4)(); lib.vcad_profile_kernel(tag, C.byref(o4))
+        fam[name] = {"ms": o4[0], "flops": o4[1], "bytes": o4[2], "launches": int(o4[3])}
+    # the dominant kernel: the persistent DMA-fed GEMM (every large ViT Linear, forward / dgrad / wgrad) — the family with the most time
+    dom = max(fam, key=lambda k: fam[k]["ms"]) if any(v["ms"] > 0 for v in fam.values()) else "gemm_dma_kernel"
+    d = fam[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    ach_all = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(dom, d, dtype, B, T) if headline else (None, None)
+    roof = {"bound": "mfma", "kernel": f"{dom} (dominant kernel family: {d['launches']} launches, {d['ms']:.2f} ms of the step; split-K launches include their slab reduction)",
+            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
+            "alg_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
+            "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 1),
+            "alg_tflop_per_step": round(d["flops"] / 1e12, 3),
+            "all_linear_launches": {"achieved": round(ach_all, 1), "frac": round(ach_all / peak, 4), "launches_per_step": gemm_n, "ms": round(gemm_ms, 3),
+                                    "alg_tflop_per_step": round(gemm_fl / 1e12, 3),
+                                    "by_kernel": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
+                                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None} for k, v in fam.items()}},
+            "step_level_frac": round(fps_per_gpu * train_gf_per_frame(T) * 1e9 / (peak * 1e12), 4)}
+    if not headline:      # legs: the compact form (dominant kernel + fraction); the headline block carries the details
+        roof = {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us", "alg_tflop_per_step", "step_level_frac")}
+        roof["all_linear_frac"] = round(ach_all / peak, 4)
+        roof["kernel_breakdown_ms"] = {k: v["ms"] for k, v in breakdown.items()}
+    return breakdown, roof
+
+
 def run(args):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +291,8 @@ def run(args):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)            # "nccl" IS RCCL on ROCm (reference main.py:31-35)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     B, T = args.batch, args.seq
     model, tr = build_trainer(args.dtype, args.dropout, device, rank)
     eng = model._engine
@@ -254,52 +325,14 @@ def run(args):
         comm = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(eng.buckets),
                 "bucket_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in eng.buckets],
                 "ms_per_step_without_allreduce": round(ms_nc, 3), "exposed_comm_ms": round(ms - ms_nc, 3)}
+        # one more step with issue / completion events around every collective (ms since the backward started): where each all-reduce sat
+        tr.gradsync.timing = True
+        tr.train_step(bd)
+        comm["last_step"] = tr.gradsync.comm_report()
+        tr.gradsync.timing = False
 
     # ---- one extra, profiled step (outside the timed region): HIP events on the launch stream around every kernel family
-    lib = eng.lib
-    lib.vcad_profile_begin()
-    tr.train_step(bd)
-    torch.cuda.synchronize()
-    pms, pfl, pby, pln = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int * 8)()
-    lib.vcad_profile_end(C.byref(pms), C.byref(pfl), C.byref(pby), C.byref(pln))
-    breakdown = {CATS[i]: {"ms": round(pms[i], 3), "launches": pln[i],
-                           "tflops": round(pfl[i] / (pms[i] * 1e-3) / 1e12, 1) if pms[i] > 0 and pfl[i] > 0 else None,
-                           "GBps": round(pby[i] / (pms[i] * 1e-3) / 1e9, 1) if pms[i] > 0 and pby[i] > 0 else None}
-                 for i in range(8)}
-    gemm_ms = pms[0] + pms[1] + pms[2]; gemm_fl = pfl[0] + pfl[1] + pfl[2]; gemm_n = pln[0] + pln[1] + pln[2]
-    peak = PEAK_TFLOPS[args.dtype]
-    fam = {}
-    for tag, name in ((1, "gemm_dma_kernel"), (2, "gemm_kernel"), (3, "gemm_mid_kernel"), (4, "gemm_grouped_kernel")):
-        o4 = (C.c_double * 4)(); lib.vcad_profile_kernel(tag, C.byref(o4))
-        fam[name] = {"ms": o4[0], "flops": o4[1], "bytes": o4[2], "launches": int(o4[3])}
-    # the dominant kernel: the persistent DMA-fed GEMM (every large ViT Linear, forward / dgrad / wgrad) — the family with the most time
-    dom = max(fam, key=lambda k: fam[k]["ms"]) if any(v["ms"] > 0 for v in fam.values()) else "gemm_dma_kernel"
-    d = fam[dom]
-    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-    ach_all = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read inside this process; they come from the committed
-    # rocprofv3 --pmc passes of this same command (tools/collect_profiles.sh -> profiles/<round>_pmc.json), bf16 C2 workload only.
-    traffic, traffic_src = None, None
-    try:
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc.json"))
-        if cands and args.dtype == "bf16" and (B, T) == (32, 64):
-            pj = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))
-            key = "dominant_hbm_bytes_per_launch" if dom == "gemm_dma_kernel" and "dominant_hbm_bytes_per_launch" in pj else None
-            if key:
-                traffic = round(pj[key]); traffic_src = "profiles/" + cands[-1]
-    except Exception:
-        pass
-    roof = {"bound": "mfma", "kernel": f"{dom} (dominant kernel family: {d['launches']} launches, {d['ms']:.2f} ms of the step; split-K launches include their slab reduction)",
-            "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-            "alg_bytes_per_launch": round(d["bytes"] / max(d["launches"], 1)),
-            "launches_per_step": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 1),
-            "alg_tflop_per_step": round(d["flops"] / 1e12, 3),
-            "all_linear_launches": {"achieved": round(ach_all, 1), "frac": round(ach_all / peak, 4), "launches_per_step": gemm_n, "ms": round(gemm_ms, 3),
-                                    "alg_tflop_per_step": round(gemm_fl / 1e12, 3),
-                                    "by_kernel": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],
-                                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else None} for k, v in fam.items()}},
-            "step_level_frac": round(fps / world * train_gf_per_frame(T) * 1e9 / (peak * 1e12), 4)}
+    breakdown, roof = profile_step(tr, bd, args.dtype, B, T, fps / world, headline=True)
 
     # ---- BASELINE configs[3]'s per-GPU shape (seq_len 186 — the maximum horizon — at 16 clips per GPU) and configs[2] (seq_len 128, batch 64 on
     # one GPU), a few steps each, reported beside the headline configuration (north_star asks for both horizons; BASELINE.md §3 lists
@@ -316,8 +349,9 @@ def run(args):
             e2, _ = _timed(tr, bd2, K2, world, device, per2)
             leg = {"workload": f"seq_len={T2} batch={B2} per GPU (BASELINE configs[{3 if name == 'c4' else 2}]" + (" per-GPU shape)" if name == "c4" else ")"),
                    "value": round(world * B2 * T2 / (e2 / K2), 1), "unit": "frames/s", "ms_per_step": round(e2 / K2 * 1e3, 3),
-                   "ms_per_step_median": round(float(np.median(per2)), 3), "steps": K2, "warmup": W2,
-                   "step_level_frac": round(B2 * T2 / (e2 / K2) * train_gf_per_frame(T2) * 1e9 / (peak * 1e12), 4)}
+                   "ms_per_step_median": round(float(np.median(per2)), 3), "steps": K2, "warmup": W2}
+            if rank == 0 and world == 1:
+                leg["roofline"] = profile_step(tr, bd2, args.dtype, B2, T2, B2 * T2 / (e2 / K2))[1]
             if name == "c4":
                 extra = leg
             else:
@@ -330,9 +364,11 @@ def run(args):
     modes = None
     if rank == 0 and world == 1 and (B, T) == (32, 64) and args.dtype == "bf16" and not getattr(args, "no_modes", False):
         modes = {}
-        for key, dt, f8, K3 in (("bf16x3", "bf16x3", False, 4), ("f32", "f32", False, 2), ("bf16_fp8_forward", "bf16", True, 4)):
+        # fp8: BASELINE configs[4] is seq_len 186 — its per-GPU shape (B=16, T=186), next to the bf16 leg at that shape above
+        for key, dt, f8, K3, B3, T3 in (("bf16x3", "bf16x3", False, 4, B, T), ("bf16x3_seq_len_186", "bf16x3", False, 3, 16, 186), ("f32", "f32", False, 2, B, T),
+                                        ("bf16_fp8_forward", "bf16", True, 4, 16, 186)):
             try:
-                modes[key] = short_leg(dt, f8, B, T, K3, 1, device, rank, world, 2000, args.dropout)
+                modes[key] = short_leg(dt, f8, B3, T3, K3, 1, device, rank, world, 2000, args.dropout, want_parity=(key != "bf16x3_seq_len_186"))
             except Exception as ex:               # a reporting leg never breaks the headline measurement
                 modes[key] = {"error": repr(ex)}
 
@@ -362,6 +398,12 @@ def run(args):
             out["seq_len_128_batch_64"] = extra_c3
         if modes:
             out["modes"] = modes
+            x3 = modes.get("bf16x3") or {}
+            if "value" in x3:        # the number to quote next to "matches the reference" (north_star: logits within 1e-3 rel, arg-max exact)
+                out["in_tolerance"] = {"dtype": "bf16x3", "workload": x3["workload"], "value": x3["value"], "unit": "frames/s", "ms_per_step": x3["ms_per_step"],
+                                       "rel_err": x3.get("parity", {}).get("rel_err"), "argmax_agreement": x3.get("parity", {}).get("argmax_agreement"),
+                                       "cmd_argmax_agreement": x3.get("parity", {}).get("cmd_argmax_agreement"),
+                                       "seq_len_186": {k: (modes.get("bf16x3_seq_len_186") or {}).get(k) for k in ("workload", "value", "ms_per_step")}}
         if pcie:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:

@@ -3,7 +3,7 @@
 // The SHIPPED library keeps no process-global switches: which kernel runs is decided per problem, and the few knobs the tests need (force a
 // tile size / the persistent kernels on small problems) are plain per-call flags (GemmCall::flags, vcad_op_gemm, vcad_set_gemm_flags).
 // Every other selector below picks between kernels that compute the same result and exists for the measurements in profiles/ — the slower
-// variants (ping-pong GEMM, four-wave form of the 256-wide tile, r01 attention kernels, fused-GELU epilogues in bf16 mode) and the
+// variants (four-wave form of the 256-wide tile, r01 attention kernels, fused-GELU epilogues in bf16 mode) and the
 // pipeline-stage ablation branches are compiled ONLY into the A/B build.  VC_AB(field, default) is a compile-time constant in the product.
 #pragma once
 #ifdef VCAD_AB
@@ -12,7 +12,7 @@ struct VcAb {
     int stagger;       // first-wave start offset of the register-staged kernel (units of s_sleep(127))
     int skip;          // pipeline-stage ablation mask (tools/gemm_ablate*.py)
     int epilogue;      // persistent kernel, k-contiguous B: -1 automatic, 0 row-per-lane (r01), 1 column-per-lane
-    int variant;       // 0 lockstep persistent kernel, 1 ping-pong wave groups (gemm_pp.h; measured slower)
+    int variant;       // (unused since r04: the ping-pong kernel — measured 1.6-2x slower, profiles/r02_gemm_pingpong_ab.txt — was deleted)
     int waves;         // 256-wide tile: 8 waves (64 x 128 each) or 4 (128 x 128 each; measured slower)
     int attn_variant;  // 0 current attention kernels, 1 r01 kernels
     int split_gelu;    // bf16 ViT MLP: 1 = activation as its own pass behind a plain GEMM, 0 = fused epilogue (r01)

@@ -1031,300 +1031,242 @@ VC_KERNEL __launch_bounds__(256, 1) void attn_dec_bwd_cw_kernel(AttnParams p) {
 }
 
 // ====================================================================================================================
-// Decoder attention for 64 < T <= 192 (three 64-step blocks; the canonical maximum horizon is 186): the same machinery per
-// (query block, key block) pair.
-//   forward  : one wave per (clip, head, query block); the <= 3 visible key blocks' S^T grids stay in registers, one softmax
-//              over all of them, then O chunk by chunk.
-//   backward : attn_dec_bwd_q (lane = query) first accumulates D_i over its <= 3 key blocks, then writes their dS to LDS as bf16
-//              [query][key] tiles and reads them back as the A operand of dQ = dS K; attn_dec_bwd_kv (lane = key, launched
-//              after it, reads D_i) does the same with P' and dS of its <= 3 query blocks for dV = P'^T dO and dK = dS^T Q
-//              (transposed LDS reads).
+// Decoder attention for T > 64 (any horizon; the canonical maximum is 186 = three 64-step blocks, the reference allows max_ep_len = 1000):
+// the same machinery per (query block, key block) pair, STREAMED over the blocks of the other side.
+//
+// r04 form.  r01-r03 ran ONE wave per (clip, head, 64-row block) that walked the four 64-wide head-dim chunks of every visible block pair through
+// two small LDS tiles: 192 single-wave workgroups on 1 024 SIMDs, each a chain of ~30-40 dependent global-load -> LDS -> MFMA phases
+// (109 us per backward-dQ launch for 2.3 GFLOP at T = 186; three key blocks at most because the score grids of all of them sat in registers).
+// Here a workgroup is NCH waves (one per head-dim chunk, as in the T <= 64 `cw` kernels above): per block pair ONE memory round trip stages every
+// chunk, every wave accumulates the full score grids over the chunks in the order 0 .. NCH-1 (redundant MFMAs on four different SIMDs; the same
+// order in all three kernels, so exp(s - lse) is exactly 1 where a query sees a single key and dS = 0 bit for bit, as in the reference) and owns
+// its chunk of the outputs.
+//   forward  : NCH waves per (clip, head, query block); key blocks visited in ascending order with a running (max, sum) per query
+//              (online softmax: P = exp(s - running max) feeds PV unnormalised, O is rescaled when the max moves and divided by the sum at the end)
+//   backward : attn_dec_bwd_q (lane = query) accumulates D_i = sum_key P dP over its key blocks in a first sweep with exactly the P and dP the second
+//              sweep uses (the rowsum(dO * O) identity would leave rounding noise where a query sees one key), then dQ_c += dS K_c per key block
+//              straight from the accumulator registers; attn_dec_bwd_kv (lane = key, launched after it, reads D_i) sweeps its query blocks and
+//              accumulates dV_c += P'^T dO_c, dK_c += dS^T Q_c.
 // ====================================================================================================================
-constexpr int AM_MAXB = 3;
-constexpr size_t AM_LONG_Q_LDS = (size_t)(4 + AM_MAXB) * AM_T * AM_S * 2, AM_LONG_KV_LDS = (size_t)(4 + 2 * AM_MAXB) * AM_T * AM_S * 2;
+constexpr size_t am_blk_fwd_lds_bytes(int nch) { return (size_t)3 * nch * AM_T * AM_S * 2; }
+constexpr size_t am_blk_bwd_lds_bytes(int nch) { return (size_t)4 * nch * AM_T * AM_S * 2 + 2 * AM_T * sizeof(float); }
 
 // first / last key block a query block can see, and vice versa (causal + window band)
 VC_DEV int am_kb_lo(int qb, int window) { const int k = qb * AM_T - window + 1; return k > 0 ? k / AM_T : 0; }
 VC_DEV int am_qb_hi(int kb, int window, int nblk) { const int q = (kb * AM_T + AM_T - 1 + window - 1) / AM_T; return q < nblk - 1 ? q : nblk - 1; }
-// A fragment from a row-major [m][k] bf16 LDS tile with the SAME k-slot order the transposed B fragments use
-// (k = k0 + 4h + {0..3, 8..11}): two 8-byte reads
-VC_DEV vc_s16x8 am_frag_kmap(const vc_bf16* tile, int row0, int k0, int lane) {
-    const vc_bf16* p = tile + (row0 + (lane & 31)) * AM_S + k0 + 4 * (lane >> 5);
-    const vc_u32x2 lo = *reinterpret_cast<const vc_u32x2*>(p), hi = *reinterpret_cast<const vc_u32x2*>(p + 8);
-    vc_s16x8 r;
-    r[0] = (short)(lo.x & 0xffffu); r[1] = (short)(lo.x >> 16); r[2] = (short)(lo.y & 0xffffu); r[3] = (short)(lo.y >> 16);
-    r[4] = (short)(hi.x & 0xffffu); r[5] = (short)(hi.x >> 16); r[6] = (short)(hi.y & 0xffffu); r[7] = (short)(hi.y >> 16);
-    return r;
-}
-// write an accumulator grid to an LDS tile as bf16; TRANSPOSE: grid element (register row, lane column) -> tile[column][row]
-template <bool TRANSPOSE>
-VC_DEV void am_grid_to_lds(vc_bf16* tile, const vc_f32x16 (&g)[2][2], int lane) {
+
+// two [T x 64] head slices into two wave-private LDS tiles, all sixteen 16-byte loads in flight before the first LDS store (am_stage twice
+// would make the second tensor's loads wait behind the first one's stores)
+VC_DEV void am_stage2(vc_bf16* tile_a, const vc_bf16* ga, long lda, vc_bf16* tile_b, const vc_bf16* gb, long ldb, int T, int lane) {
+    vc_u32x4 va[AM_T / 8], vb[AM_T / 8];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = ti * 32 + am_row(r, lane), col = tj * 32 + (lane & 31);
-                tile[TRANSPOSE ? col * AM_S + row : row * AM_S + col] = vc_f32_to_bf16(g[ti][tj][r]);
-            }
-}
-// out[m][d] += sum_k A[m][k] Y[k][d]: A row-major LDS tile (k-mapped fragments), Y token-major LDS tile (transposed reads)
-VC_DEV void am_mm_lds_rowA(vc_f32x16 (&out)[2][2], const vc_bf16* A, const vc_bf16* Y, int lane) {
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        vc_s16x8 a[2], b[2];
-#pragma unroll
-        for (int o = 0; o < 2; ++o) { a[o] = am_frag_kmap(A, o * 32, 16 * s4, lane); b[o] = am_frag_tr(Y, 16 * s4, o * 32, lane); }
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
+    for (int it = 0; it < AM_T / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        const int rr = row < T ? row : T - 1;
+        va[it] = *reinterpret_cast<const vc_u32x4*>(ga + (long)rr * lda + c);
+        vb[it] = *reinterpret_cast<const vc_u32x4*>(gb + (long)rr * ldb + c);
     }
-}
-// out[m][d] += sum_k A[k][m] Y[k][d]: both operands token-major LDS tiles (transposed reads)
-VC_DEV void am_mm_lds_colA(vc_f32x16 (&out)[2][2], const vc_bf16* A, const vc_bf16* Y, int lane) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        vc_s16x8 a[2], b[2];
-#pragma unroll
-        for (int o = 0; o < 2; ++o) { a[o] = am_frag_tr(A, 16 * s4, o * 32, lane); b[o] = am_frag_tr(Y, 16 * s4, o * 32, lane); }
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int d = 0; d < 2; ++d) out[o][d] = vc_mfma_32x32x16_bf16(a[o], b[d], out[o][d]);
+    for (int it = 0; it < AM_T / 8; ++it) {
+        const int row = it * 8 + (lane >> 3), c = (lane & 7) * 8;
+        vc_u32x4 wa = va[it], wb = vb[it];
+        if (row >= T) { wa.x = wa.y = wa.z = wa.w = 0u; wb.x = wb.y = wb.z = wb.w = 0u; }
+        *reinterpret_cast<vc_u32x4*>(tile_a + row * AM_S + c) = wa;
+        *reinterpret_cast<vc_u32x4*>(tile_b + row * AM_S + c) = wb;
     }
 }
 
 template <bool DROP, int NCH>
-VC_KERNEL __launch_bounds__(64) void attn_dec_fwd_long_mfma_kernel(AttnParams p) {
-    VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[2][AM_T * AM_S];
-    const int lane = threadIdx.x;
+VC_KERNEL __launch_bounds__(64 * NCH, 1) void attn_dec_fwd_blk_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, lds);
+    constexpr int TILE = AM_T * AM_S;
+    const int tid = threadIdx.x, lane = tid & 63, c = vc_uniform(tid >> 6);
+    auto Qt = [&](int cc) { return lds + cc * TILE; };
+    auto Kt = [&](int cc) { return lds + (NCH + cc) * TILE; };
+    auto Vt = [&](int cc) { return lds + (2 * NCH + cc) * TILE; };
     const int T = p.Tq, nblk = (T + AM_T - 1) / AM_T;
     const int qb = blockIdx.x % nblk; const long bh = blockIdx.x / nblk;
     const int h = (int)(bh % p.H); const long n = bh / p.H;
     const long rowq = n * T;
-    const int hd = h * AM_D * NCH;
-    const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;            // rows of this query block
+    const int hd = h * AM_D * NCH + c * AM_D;                                 // this wave's head-dim chunk
+    const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;             // rows of this query block
     const int kb0 = am_kb_lo(qb, p.window);
-    vc_f32x16 st[AM_MAXB][2][2];
-#pragma unroll
-    for (int i = 0; i < AM_MAXB; ++i) am_zero(st[i]);
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        vc_wave_barrier();
-        am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
-#pragma unroll
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int kb = kb0 + i;
-            if (kb <= qb) {
-                const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
-                vc_wave_barrier();
-                am_stage(tiles[1], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
-                vc_wave_barrier();
-                am_mm_nt(st[i], tiles[1], tiles[0], lane);
-            }
-        }
-    }
     const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    am_stage(Qt(c), (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd, p.ldq, tq, lane);
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};           // running max / sum of this lane's two query columns
+    vc_f32x16 o[2][2];                                                        // [query tile][d tile]: registers walk the head dim, lane = query
+    am_zero(o);
+#pragma unroll 1
+    for (int kb = kb0; kb <= qb; ++kb) {
+        const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
+        if (kb != kb0) vc_sync();                                             // the previous block's K / V fragments are consumed
+        am_stage2(Kt(c), (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd, p.ldk, Vt(c), (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd, p.ldv, tk, lane);
+        vc_sync();
+        vc_f32x16 st[2][2];                                                   // S^T: [key tile][query tile], lane column = query
+        am_zero(st);
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int ql = qt * 32 + (lane & 31);
-        const int query = q0 + (ql < tq ? ql : tq - 1);                       // padding columns: keep the row finite (never stored)
-        float m = -INFINITY;
+        for (int cc = 0; cc < NCH; ++cc) am_mm_nt(st, Kt(cc), Qt(cc), lane);
+        uint64_t keep = 0;
+        if (DROP) keep = am_keep_bits_g<true>(p.drop, dbase0, T, q0, k0, lane);
 #pragma unroll
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int kb = kb0 + i;
+        for (int qt = 0; qt < 2; ++qt) {
+            const int ql = qt * 32 + (lane & 31);
+            const int query = q0 + (ql < tq ? ql : tq - 1);                   // padding columns: keep the row finite (never stored)
+            float m = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = kb * AM_T + kt * 32 + am_row(r, lane);
-                    const float sc = (kb <= qb && am_visible(query, key, T, p.window)) ? st[i][kt][qt][r] * p.scale : -INFINITY;
-                    st[i][kt][qt][r] = sc; m = fmaxf(m, sc);
+                    const int key = k0 + kt * 32 + am_row(r, lane);
+                    const float sc = am_visible(query, key, T, p.window) ? st[kt][qt][r] * p.scale : -INFINITY;
+                    st[kt][qt][r] = sc; m = fmaxf(m, sc);
                 }
-        }
-        m = fmaxf(m, vc_shfl_xor(m, 32));
-        float l = 0.f;
-#pragma unroll
-        for (int i = 0; i < AM_MAXB; ++i)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float e = expf(st[i][kt][qt][r] - m); st[i][kt][qt][r] = e; l += e; }
-        l += vc_shfl_xor(l, 32);
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int i = 0; i < AM_MAXB; ++i)
+            m = fmaxf(m, vc_shfl_xor(m, 32));
+            const float m_new = fmaxf(m_run[qt], m);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;             // a query that sees no key of the blocks so far: everything stays 0
+            const float alpha = expf(m_run[qt] - m_use);
+            float l = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[i][kt][qt][r] *= inv;
-        if (p.lse && lane < 32 && ql < tq) p.lse[(n * p.H + h) * T + q0 + ql] = m + logf(l);
-    }
-    if (DROP) {
+                for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m_use); st[kt][qt][r] = e; l += e; }
+            l += vc_shfl_xor(l, 32);
+            l_run[qt] = l_run[qt] * alpha + l; m_run[qt] = m_new;
 #pragma unroll
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int kb = kb0 + i;
-            if (kb <= qb) {
-                const uint64_t keep = am_keep_bits_g<true>(p.drop, dbase0, T, q0, kb * AM_T, lane);
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) st[i][kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);
-            }
+                for (int r = 0; r < 16; ++r) o[qt][dt][r] *= alpha;
+            const vc_f32x16 W[2] = {st[0][qt], st[1][qt]};
+            am_mm_tok1k<DROP>(o[qt], W, Vt(c), lane, keep, qt, p.drop.scale);      // O[query][d] += sum_key P'[query][key] V[key][d], this wave's 64 columns
         }
     }
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        vc_f32x16 o[2][2];
-        am_zero(o);
+    vc_sync();                                                                // every wave is done with the Q tiles: the own one becomes the store staging
 #pragma unroll
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int kb = kb0 + i;
-            if (kb <= qb) {
-                const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
-                vc_wave_barrier();
-                am_stage(tiles[0], (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd + c * AM_D, p.ldv, tk, lane);
-                vc_wave_barrier();
-                am_mm_tok(o, st[i], tiles[0], lane);
-            }
-        }
-        am_store((vc_bf16*)p.o + (rowq + q0) * p.ldo + hd + c * AM_D, p.ldo, o, tq, lane, 1.0f);
+    for (int qt = 0; qt < 2; ++qt) {
+        const int ql = qt * 32 + (lane & 31);
+        am_store_rows(Qt(c), (vc_bf16*)p.o + (rowq + q0) * p.ldo + hd, p.ldo, o[qt], qt, tq, lane, 1.0f / l_run[qt]);
+        if (c == 0 && p.lse && lane < 32 && ql < tq) p.lse[(n * p.H + h) * T + q0 + ql] = m_run[qt] + logf(l_run[qt]);
     }
 }
 
-// backward, lane = query: D_i and dQ of one query block.  D_i = sum_key P dP is accumulated over the key blocks in a first
-// pass with exactly the P and dP the second pass uses (so a query that sees a single key gets dS == 0 bit-exactly, as in the
-// reference — the rowsum(dO * O) identity would leave rounding noise there that Adam amplifies to lr-sized steps); it is also
-// written to p.delta for the dK/dV kernel that is launched next.
+// backward, lane = query: D_i and dQ of one query block (D_i is also written to p.delta for the dK/dV kernel that is launched next)
 template <bool DROP, int NCH>
-VC_KERNEL __launch_bounds__(64) void attn_dec_bwd_q_long_mfma_kernel(AttnParams p) {
-    VC_DYN_SHARED(vc_bf16, smem);                             // (4 + AM_MAXB) tiles
-    vc_bf16 (*tiles)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem);                       // Q, dO (query block) ; K, V (key block) chunk
-    vc_bf16 (*dst)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem + 4 * AM_T * AM_S);       // dS[query][key] per key block
-    const int lane = threadIdx.x;
+VC_KERNEL __launch_bounds__(64 * NCH, 1) void attn_dec_bwd_q_blk_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, lds);
+    constexpr int TILE = AM_T * AM_S;
+    const int tid = threadIdx.x, lane = tid & 63, c = vc_uniform(tid >> 6);
+    auto Qt = [&](int cc) { return lds + cc * TILE; };
+    auto Ot = [&](int cc) { return lds + (NCH + cc) * TILE; };
+    auto Kt = [&](int cc) { return lds + (2 * NCH + cc) * TILE; };
+    auto Vt = [&](int cc) { return lds + (3 * NCH + cc) * TILE; };
     const int T = p.Tq, nblk = (T + AM_T - 1) / AM_T;
     const int qb = blockIdx.x % nblk; const long bh = blockIdx.x / nblk;
     const int h = (int)(bh % p.H); const long n = bh / p.H;
     const long rowq = n * T;
-    const int hd = h * AM_D * NCH;
+    const int hd = h * AM_D * NCH + c * AM_D;
     const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;
     const int kb0 = am_kb_lo(qb, p.window);
     const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
-    const float* lse = p.lse + (n * p.H + h) * T + q0;
-    float dsum[2] = {0.f, 0.f};
+    am_stage2(Qt(c), (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd, p.ldq, Ot(c), (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd, p.lddo, tq, lane);
+    float ls[2], dsum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) { const int ql = qt * 32 + (lane & 31); ls[qt] = ql < tq ? p.lse[(n * p.H + h) * T + q0 + ql] : 0.f; }
+    vc_f32x16 dq[2][2];                                                       // [query tile][d tile]: registers walk the head dim, lane = query
+    am_zero(dq);
+    bool first = true;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll 1
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int kb = kb0 + i;
-            if (kb > qb) break;
+        for (int kb = kb0; kb <= qb; ++kb) {
             const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
-            vc_f32x16 st[2][2], dpt[2][2];
-            am_zero(st); am_zero(dpt);
+            if (!first) vc_sync();                                            // the previous block's K / V fragments are consumed
+            first = false;
+            am_stage2(Kt(c), (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd, p.ldk, Vt(c), (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd, p.ldv, tk, lane);
+            vc_sync();
+            vc_f32x16 sg[2][2], dg[2][2];                                     // S^T, dP'^T: [key tile][query tile]
+            am_zero(sg); am_zero(dg);
 #pragma unroll 1
-            for (int c = 0; c < NCH; ++c) {
-                vc_wave_barrier();
-                am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
-                am_stage(tiles[1], (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd + c * AM_D, p.lddo, tq, lane);
-                am_stage(tiles[2], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
-                am_stage(tiles[3], (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd + c * AM_D, p.ldv, tk, lane);
-                vc_wave_barrier();
-                am_mm_nt(st, tiles[2], tiles[0], lane);          // S^T[key][query]
-                am_mm_nt(dpt, tiles[3], tiles[1], lane);         // dP'^T[key][query]
-            }
+            for (int cc = 0; cc < NCH; ++cc) { am_mm_nt(sg, Kt(cc), Qt(cc), lane); am_mm_nt(dg, Vt(cc), Ot(cc), lane); }
             uint64_t keep = 0;
             if (DROP) keep = am_keep_bits_g<true>(p.drop, dbase0, T, q0, k0, lane);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 const int ql = qt * 32 + (lane & 31);
                 const bool qok = ql < tq;
-                const float ls = qok ? lse[ql] : 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = k0 + kt * 32 + am_row(r, lane);
                         const bool ok = qok && am_visible(q0 + ql, key, T, p.window);
-                        const float pr = ok ? expf(st[kt][qt][r] * p.scale - ls) : 0.f;
-                        const float dpm = dpt[kt][qt][r] * (DROP ? am_keep(keep, kt, qt, r, p.drop.scale) : 1.0f);   // dP = dP' * mask
+                        const float pr = ok ? expf(sg[kt][qt][r] * p.scale - ls[qt]) : 0.f;
+                        const float dpm = dg[kt][qt][r] * (DROP ? am_keep(keep, kt, qt, r, p.drop.scale) : 1.0f);      // dP = dP' * mask
                         if (pass == 0) dsum[qt] += pr * dpm;
-                        else st[kt][qt][r] = pr * (dpm - dsum[qt]);                                                    // dS^T
+                        else sg[kt][qt][r] = pr * (dpm - dsum[qt]);                                                       // dS^T (scale folded into the store)
                     }
+                if (pass == 1) {
+                    const vc_f32x16 W[2] = {sg[0][qt], sg[1][qt]};
+                    am_mm_tok1k<false>(dq[qt], W, Kt(c), lane, 0, 0, 1.0f);   // dQ[query][d] += sum_key dS[query][key] K[key][d], this wave's 64 columns
+                }
             }
-            if (pass == 1) am_grid_to_lds<true>(dst[i], st, lane);   // -> [query][key]
         }
         if (pass == 0) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 dsum[qt] += vc_shfl_xor(dsum[qt], 32);
                 const int ql = qt * 32 + (lane & 31);
-                if (lane < 32 && ql < tq) p.delta[(n * p.H + h) * T + q0 + ql] = dsum[qt];
+                if (c == 0 && lane < 32 && ql < tq) p.delta[(n * p.H + h) * T + q0 + ql] = dsum[qt];
             }
         }
     }
-    vc_wave_barrier();
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        vc_f32x16 dq[2][2];
-        am_zero(dq);
-#pragma unroll 1
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int kb = kb0 + i;
-            if (kb > qb) break;
-            const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
-            vc_wave_barrier();
-            am_stage(tiles[2], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
-            vc_wave_barrier();
-            am_mm_lds_rowA(dq, dst[i], tiles[2], lane);      // dQ[query][d] += sum_key dS[query][key] K[key][d]
-        }
-        am_store((vc_bf16*)p.dq + (rowq + q0) * p.lddq + hd + c * AM_D, p.lddq, dq, tq, lane, p.scale);
-    }
+    vc_sync();                                                                // Q tiles free: the own one becomes the store staging
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) am_store_rows(Qt(c), (vc_bf16*)p.dq + (rowq + q0) * p.lddq + hd, p.lddq, dq[qt], qt, tq, lane, p.scale);
 }
 
 // backward, lane = key: dK, dV of one key block
 template <bool DROP, int NCH>
-VC_KERNEL __launch_bounds__(64) void attn_dec_bwd_kv_long_mfma_kernel(AttnParams p) {
-    VC_DYN_SHARED(vc_bf16, smem);                             // 4 + 2 * AM_MAXB tiles = 90 KiB
-    vc_bf16 (*tiles)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem);                                   // Q, dO ; K, V chunk
-    vc_bf16 (*pt)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem + 4 * AM_T * AM_S);                    // P'[query][key] per query block
-    vc_bf16 (*dst)[AM_T * AM_S] = reinterpret_cast<vc_bf16 (*)[AM_T * AM_S]>(smem + (4 + AM_MAXB) * AM_T * AM_S);       // dS[query][key] per query block
-    const int lane = threadIdx.x;
+VC_KERNEL __launch_bounds__(64 * NCH, 1) void attn_dec_bwd_kv_blk_kernel(AttnParams p) {
+    VC_DYN_SHARED(vc_bf16, lds);
+    constexpr int TILE = AM_T * AM_S;
+    float* lse_s = reinterpret_cast<float*>(lds + 4 * NCH * TILE);
+    float* del_s = lse_s + AM_T;
+    const int tid = threadIdx.x, lane = tid & 63, c = vc_uniform(tid >> 6);
+    auto Kt = [&](int cc) { return lds + cc * TILE; };
+    auto Vt = [&](int cc) { return lds + (NCH + cc) * TILE; };
+    auto Qt = [&](int cc) { return lds + (2 * NCH + cc) * TILE; };
+    auto Ot = [&](int cc) { return lds + (3 * NCH + cc) * TILE; };
     const int T = p.Tq, nblk = (T + AM_T - 1) / AM_T;
     const int kb = blockIdx.x % nblk; const long bh = blockIdx.x / nblk;
     const int h = (int)(bh % p.H); const long n = bh / p.H;
     const long rowq = n * T;
-    const int hd = h * AM_D * NCH;
+    const int hd = h * AM_D * NCH + c * AM_D;
     const int k0 = kb * AM_T, tk = T - k0 < AM_T ? T - k0 : AM_T;
     const int qb1 = am_qb_hi(kb, p.window, nblk);
     const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
+    am_stage2(Kt(c), (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd, p.ldk, Vt(c), (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd, p.ldv, tk, lane);
+    vc_f32x16 dv[2][2], dk[2][2];                                             // [key tile][d tile]: registers walk the head dim, lane = key
+    am_zero(dv); am_zero(dk);
 #pragma unroll 1
-    for (int i = 0; i < AM_MAXB; ++i) {
-        const int qb = kb + i;
-        if (qb > qb1) break;
+    for (int qb = kb; qb <= qb1; ++qb) {
         const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;
-        const float* lse = p.lse + (n * p.H + h) * T + q0;
-        const float* del = p.delta + (n * p.H + h) * T + q0;
-        vc_f32x16 sn[2][2], dp[2][2];
-        am_zero(sn); am_zero(dp);
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            vc_wave_barrier();
-            am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
-            am_stage(tiles[1], (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd + c * AM_D, p.lddo, tq, lane);
-            am_stage(tiles[2], (const vc_bf16*)p.k + (rowq + k0) * p.ldk + hd + c * AM_D, p.ldk, tk, lane);
-            am_stage(tiles[3], (const vc_bf16*)p.v + (rowq + k0) * p.ldv + hd + c * AM_D, p.ldv, tk, lane);
-            vc_wave_barrier();
-            am_mm_nt(sn, tiles[0], tiles[2], lane);          // S[query][key]
-            am_mm_nt(dp, tiles[1], tiles[3], lane);          // dP'[query][key]
+        if (qb != kb) vc_sync();                                              // the previous block's Q / dO fragments and statistics are consumed
+        am_stage2(Qt(c), (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd, p.ldq, Ot(c), (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd, p.lddo, tq, lane);
+        if (tid < AM_T) {
+            lse_s[tid] = tid < tq ? p.lse[(n * p.H + h) * T + q0 + tid] : 0.f;
+            del_s[tid] = tid < tq ? p.delta[(n * p.H + h) * T + q0 + tid] : 0.f;
         }
+        vc_sync();
         uint64_t keep = 0;
         if (DROP) keep = am_keep_bits_g<false>(p.drop, dbase0, T, q0, k0, lane);
+        // one 32-key column tile at a time (score-shaped grids of 2 x 1 tiles: with the four 2 x 2 output grids that stay live across the sweep a
+        // 2 x 2 score pair would not fit the register file)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
+            vc_f32x16 sg[2], dg[2];                                           // S, dP': [query tile], lane column = key of tile kt
+            am_zero1(sg); am_zero1(dg);
+#pragma unroll 1
+            for (int cc = 0; cc < NCH; ++cc) { am_mm_nt1(sg, Qt(cc), Kt(cc), kt, lane); am_mm_nt1(dg, Ot(cc), Vt(cc), kt, lane); }
             const int key = k0 + kt * 32 + (lane & 31);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
@@ -1332,33 +1274,19 @@ VC_KERNEL __launch_bounds__(64) void attn_dec_bwd_kv_long_mfma_kernel(AttnParams
                 for (int r = 0; r < 16; ++r) {
                     const int ql = qt * 32 + am_row(r, lane);
                     const bool ok = ql < tq && am_visible(q0 + ql, key, T, p.window);
-                    const float pr = ok ? expf(sn[qt][kt][r] * p.scale - lse[ql < tq ? ql : 0]) : 0.f;
+                    const float pr = ok ? expf(sg[qt][r] * p.scale - lse_s[ql]) : 0.f;
                     const float ms = DROP ? am_keep(keep, qt, kt, r, p.drop.scale) : 1.0f;
-                    dp[qt][kt][r] = pr * (dp[qt][kt][r] * ms - (ql < tq ? del[ql] : 0.f));                       // dS
-                    sn[qt][kt][r] = pr * ms;                                                                      // P'
+                    dg[qt][r] = pr * (dg[qt][r] * ms - del_s[ql]);                                                        // dS
+                    sg[qt][r] = pr;                                                                                       // P (the mask is applied while packing)
                 }
+            am_mm_tok1k<DROP>(dv[kt], sg, Ot(c), lane, keep, kt, p.drop.scale);       // dV[key][d] += sum_query P'[query][key] dO[query][d]
+            am_mm_tok1k<false>(dk[kt], dg, Qt(c), lane, 0, 0, 1.0f);                  // dK[key][d] += sum_query dS[query][key] Q[query][d]
         }
-        am_grid_to_lds<false>(pt[i], sn, lane);
-        am_grid_to_lds<false>(dst[i], dp, lane);
     }
-    vc_wave_barrier();
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-        vc_f32x16 dv[2][2], dk[2][2];
-        am_zero(dv); am_zero(dk);
-#pragma unroll 1
-        for (int i = 0; i < AM_MAXB; ++i) {
-            const int qb = kb + i;
-            if (qb > qb1) break;
-            const int q0 = qb * AM_T, tq = T - q0 < AM_T ? T - q0 : AM_T;
-            vc_wave_barrier();
-            am_stage(tiles[0], (const vc_bf16*)p.q + (rowq + q0) * p.ldq + hd + c * AM_D, p.ldq, tq, lane);
-            am_stage(tiles[1], (const vc_bf16*)p.dout + (rowq + q0) * p.lddo + hd + c * AM_D, p.lddo, tq, lane);
-            vc_wave_barrier();
-            am_mm_lds_colA(dv, pt[i], tiles[1], lane);       // dV[key][d] += sum_q P'[q][key] dO[q][d]
-            am_mm_lds_colA(dk, dst[i], tiles[0], lane);      // dK[key][d] += sum_q dS[q][key] Q[q][d]
-        }
-        am_store((vc_bf16*)p.dv + (rowq + k0) * p.lddv + hd + c * AM_D, p.lddv, dv, tk, lane, 1.0f);
-        am_store((vc_bf16*)p.dk + (rowq + k0) * p.lddk + hd + c * AM_D, p.lddk, dk, tk, lane, p.scale);
+    vc_sync();                                                                // Q tiles free: the own one becomes the store staging
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        am_store_rows(Qt(c), (vc_bf16*)p.dv + (rowq + k0) * p.lddv + hd, p.lddv, dv[kt], kt, tk, lane, 1.0f);
+        am_store_rows(Qt(c), (vc_bf16*)p.dk + (rowq + k0) * p.lddk + hd, p.lddk, dk[kt], kt, tk, lane, p.scale);
     }
 }

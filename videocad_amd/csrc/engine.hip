@@ -53,7 +53,9 @@ struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float*
 struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* st1; float* x1; void* q_c; void* kv_c; float* lse_c; void* ao_c;
                       float* s2; float* st2; float* x2; void* f1; float* s3; float* st3; float* x3;
                       // per-layer homes of the backward's dY tensors, so the layer's 7 weight gradients can be deferred (see Deferred)
-                      void *g_du_ff, *g_df1, *g_du_ca, *g_dq, *g_dkv, *g_du_sa, *g_dqkv; };
+                      void *g_du_ff, *g_df1, *g_du_ca, *g_dq, *g_dkv, *g_du_sa, *g_dqkv;
+                      // ... and of the three LayerNorm backwards' dgamma / dbeta partial rows ([vc_ln_bwd_blocks(M)][2][H]), reduced by the same grouped column sum
+                      float* ln_part[3]; };
 
 }  // namespace
 
@@ -110,11 +112,15 @@ struct vcad_engine {
         std::vector<ColsumJob> cs; ColsumJob* d_cs = nullptr; float* cs_partial = nullptr; int cs_strips = 0, cs_chunks = 0;
         bool ready = false;
     } def;
+    // The eight cross-attention K / V projections depend only on the decoder's memory: ONE grouped launch in front of the layer loop (8 x 16 x 16 = 2 048
+    // tiles of 128 x 128 over the 256 CUs) instead of eight dependent 2 048-row launches of 256 tiles each inside it (r04)
+    struct KvForward { std::vector<GemmCall> calls; GemmParams* d_probs = nullptr; int* d_tiles = nullptr; int total_tiles = 0; double flops = 0; bool ready = false; } kvf;
 };
 
 namespace {
 
-const int NB_BUCKETS = 4;
+const int NB_BUCKETS = 5;      // heads + decoder | stem | CAD ViT | frame ViT upper | frame ViT lower + embed
+const int CAD_STAGE = 2;       // the stage that may run on the side stream (vcad_backward_stage_side)
 
 long add_param(vcad_engine* e, const std::string& name, std::initializer_list<long> shape) {
     PInfo p; p.name = name; p.ndim = (int)shape.size(); p.numel = 1;
@@ -156,7 +162,7 @@ void add_vit_embed(vcad_engine* e, int v, const std::string& pre) {
 void build_params(vcad_engine* e) {
     const vcad_config& c = e->c;
     const long H = c.hidden_size, ff = c.dim_feedforward;
-    // ---- bucket 0: heads, decoder L-1..0, stem
+    // ---- bucket 0: heads, decoder L-1..0
     long b0 = e->ptotal;
     e->o_h6_w = add_param(e, "predict_action_class_0_999.weight", {(long)c.num_params * c.num_params_values, H});
     e->o_h6_b = add_param(e, "predict_action_class_0_999.bias", {(long)c.num_params * c.num_params_values});
@@ -176,6 +182,8 @@ void build_params(vcad_engine* e) {
         w.sa_ow = add_param(e, p + "self_attn.out_proj.weight", {H, H}); w.sa_ob = add_param(e, p + "self_attn.out_proj.bias", {H});
         w.sa_w = add_param(e, p + "self_attn.in_proj_weight", {3 * H, H}); w.sa_b = add_param(e, p + "self_attn.in_proj_bias", {3 * H});
     }
+    // ---- bucket 1: stem (small; split off so the heads + decoder all-reduce — 360 MB, 71 % of the bytes — starts before the stem's backward runs)
+    e->buckets.push_back({b0, e->ptotal}); b0 = e->ptotal;
     e->o_ea_w = add_param(e, "embed_action.weight", {H, (long)c.act_dim}); e->o_ea_b = add_param(e, "embed_action.bias", {H});
     e->o_ts = c.enable_timestep_embedding ? add_param(e, "timestep_embedding.weight", {(long)c.max_ep_len, H}) : -1;
     // image_projection's fan-in is the reference's num_inputs = CAD + (past states) + (multiview), model/autoregressive_transformer.py:69-76
@@ -184,7 +192,7 @@ void build_params(vcad_engine* e) {
     e->o_ei_w = add_param(e, "embed_image.weight", {H, (long)c.vit_dim}); e->o_ei_b = add_param(e, "embed_image.bias", {H});
     e->o_es_w = add_param(e, "embed_state.weight", {H, (long)c.vit_dim}); e->o_es_b = add_param(e, "embed_state.bias", {H});
     e->buckets.push_back({b0, e->ptotal});
-    // ---- bucket 1: CAD ViT;  buckets 2,3: state ViT (upper / lower half)
+    // ---- bucket 2: CAD ViT;  buckets 3,4: state ViT (upper / lower half)
     for (int v = 1; v >= 0; --v) {
         std::string pre = v == 0 ? "state_embedding_model." : "cad_embedding_model.";
         e->wv[v].l.resize(c.vit_depth);
@@ -245,13 +253,15 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         d.f1 = b.take<void>(M * c.dim_feedforward * es); d.s3 = b.take<float>(M * H * 4); d.st3 = b.take<float>(M * 2 * 4); d.x3 = b.take<float>(M * H * 4);
         d.g_du_ff = b.take<void>(M * H * es); d.g_df1 = b.take<void>(M * c.dim_feedforward * es); d.g_du_ca = b.take<void>(M * H * es);
         d.g_dq = b.take<void>(M * H * es); d.g_dkv = b.take<void>(M * 2 * H * es); d.g_du_sa = b.take<void>(M * H * es); d.g_dqkv = b.take<void>(M * 3 * H * es);
+        for (int i = 0; i < 3; ++i) d.ln_part[i] = b.take<float>((size_t)vc_ln_bwd_blocks(M) * 2 * H * 4);
     }
     {   // deferred-wgrad descriptor tables (device) + column-sum partials
         const int nl = c.num_decoder_layers;
         for (int g = 0; g < 2; ++g) { e->def.d_probs[g] = b.take<GemmParams>((size_t)nl * 4 * sizeof(GemmParams)); e->def.d_tiles[g] = b.take<int>((size_t)(nl * 4 + 1) * 4); }
-        e->def.d_cs = b.take<ColsumJob>((size_t)nl * 7 * sizeof(ColsumJob));
-        e->def.cs_partial = b.take<float>((size_t)nl * (VC_CEIL_DIV(M, 128) + 1) * (7L * H + 2L * H + c.dim_feedforward) * 4);
+        e->def.d_cs = b.take<ColsumJob>((size_t)nl * 10 * sizeof(ColsumJob));
+        e->def.cs_partial = b.take<float>((size_t)nl * (VC_CEIL_DIV(M, 128) + 1) * (7L * H + 2L * H + c.dim_feedforward + 3 * 2L * H) * 4);
         e->def.ready = false;
+        e->kvf.d_probs = b.take<GemmParams>((size_t)nl * sizeof(GemmParams)); e->kvf.d_tiles = b.take<int>((size_t)(nl + 1) * 4); e->kvf.ready = false;
     }
     // backward temporaries + scratch, per lane: lane 0 (caller's stream) sized for the frame ViT / decoder, lane 1 (side stream) for the CAD ViT
     for (int ln = 0; ln < 2; ++ln) {
@@ -408,7 +418,7 @@ struct Ctx {
     // `du` (optional): also emit the masked copy du = T(dx * mask(site d)) that masked() would produce from dx32 in a second pass
     int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
                const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C,
-               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr) const {
+               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr, float* defer_partial = nullptr) const {
         LnBwdParams p; memset(&p, 0, sizeof(p));
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
@@ -417,6 +427,8 @@ struct Ctx {
             else *du = A32(dx32, lddx);
         }
         // du_colsum: the bias gradient of the Linear that consumes du, reduced by this kernel instead of a column-sum pass over du
+        // defer_partial: the dgamma / dbeta partial rows are left in that buffer (the caller reduces them later, in a grouped column sum)
+        if (defer_partial) return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, defer_partial, nullptr, nullptr, L().scr_colsum, s, nullptr);
         return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s, du ? du_colsum : nullptr);
     }
 };
@@ -463,7 +475,7 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
         ap.q = q; ap.k = q + (size_t)inner * e->esz; ap.v = q + (size_t)2 * inner * e->esz; ap.o = l.ao;
         ap.ldq = ap.ldk = ap.ldv = 3 * inner; ap.ldo = inner; ap.lse = l.lse;
         ap.B = (int)N; ap.H = c.vit_heads; ap.Tq = ap.Tk = P + 1; ap.window = P + 1; ap.causal = 0; ap.scale = scale;
-        ap.drop = cx.site(v + 1, L, Ctx::K_ATTN);
+        ap.drop = cx.site(v + 1, L, Ctx::K_ATTN); ap.x3 = e->ct == VC_X3;
         const vc_drop d_out = cx.site(v + 1, L, Ctx::K_OUT), d_act = cx.site(v + 1, L, Ctx::K_MLP_ACT), d_mlp = cx.site(v + 1, L, Ctx::K_MLP_OUT);
         if (!cls_only) {
             const bool q8 = e->fp8 && e->dt == VC_BF16;       // VCAD_FP8: these four Linears on the block-scaled fp8 matrix cores
@@ -557,7 +569,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             p.dout = cx.L().t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
             p.lddq = p.lddk = p.lddv = 3 * inner;
             p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
-            p.drop = cx.site(v + 1, L, Ctx::K_ATTN);
+            p.drop = cx.site(v + 1, L, Ctx::K_ATTN); p.x3 = e->ct == VC_X3;
             if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero
                 CK(vc_memset_async(cx.L().t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
                 p.Tq = 1; p.ldq = 3 * TI; p.lddq = 3 * TI;
@@ -609,6 +621,32 @@ int dec_attn(const Ctx& cx, bool bwd, const void* q, long ldq, const void* k, co
     if (!bwd) return vc_attn_fwd(e->dt, hd, p, cx.s);
     p.dout = dout; p.lddo = c.hidden_size; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = p.lddv = lddkv; p.delta = cx.L().t_delta;
     return vc_attn_bwd(e->dt, hd, p, cx.s);
+}
+
+// descriptor table of the batched cross-attention K / V projections (vcad_engine::KvForward): per layer kv_c = memory W_kv^T + b_kv
+int build_kv_forward(const Ctx& cx) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c;
+    const int H = c.hidden_size; const long M = (long)e->B * e->T;
+    vcad_engine::KvForward& kf = e->kvf;
+    kf.calls.clear(); kf.flops = 0;
+    for (int L = 0; L < c.num_decoder_layers; ++L) {
+        const DecW& w = e->wd[L]; const DecLayerActs& d = e->da[L];
+        const Mat A = cx.A32(e->mem, H), Wm = cx.W(w.ca_w + (long)H * H, H), C = cx.AT(d.kv_c, 2 * H);
+        GemmCall gc; memset(&gc, 0, sizeof(gc));
+        gc.ct = e->ct; gc.sa = A.dt; gc.sb = Wm.dt; gc.to = C.dt; gc.tra = 0; gc.trb = 0;
+        GemmParams& p = gc.p;
+        p.A = A.p; p.B = Wm.p; p.C = (void*)C.p; p.M = (int)M; p.N = 2 * H; p.K = H; p.lda = A.ld; p.ldb = Wm.ld; p.ldc = C.ld; p.alpha = 1.0f;
+        p.bias = cx.Pf(w.ca_b + H); p.rowadd_div = 1;
+        kf.calls.push_back(gc); kf.flops += 2.0 * M * 2 * H * H;
+    }
+    const int n = (int)kf.calls.size();
+    std::vector<GemmParams> probs(n); std::vector<int> tiles(n + 1);
+    CK(vc_gemm_grouped_prepare(kf.calls.data(), n, probs.data(), tiles.data()));
+    kf.total_tiles = tiles[n];
+    CK(vc_upload(kf.d_probs, probs.data(), (size_t)n * sizeof(GemmParams), cx.s));
+    CK(vc_upload(kf.d_tiles, tiles.data(), (size_t)(n + 1) * sizeof(int), cx.s));
+    kf.ready = true;
+    return 0;
 }
 
 int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t s) {
@@ -667,6 +705,13 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     const float* tgt = pa ? e->act : (ps ? e->ui : e->mem);
     const int sa_window = pa ? T : c.window_size;
     const float* x = tgt;
+    // every layer's cross-attention K / V projection of the memory in one grouped launch (bf16 mode; the other modes keep the per-layer launches)
+    const bool kv_batched = e->dt == VC_BF16 && e->ct == VC_BF16 && vc_gemm_grouped_has_forward();
+    if (kv_batched) {
+        if (!e->kvf.ready) CK(build_kv_forward(cx));
+        CK(vc_gemm_grouped_launch(e->kvf.calls[0], e->kvf.d_probs, e->kvf.d_tiles, (int)e->kvf.calls.size(), e->kvf.total_tiles, e->kvf.flops, s));
+        e->kernel_launches[VC_TAG_GEMM_GROUPED]++;
+    }
     for (int L = 0; L < c.num_decoder_layers; ++L) {
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
         { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, 3 * H), (int)M, 3 * H, H, ep)); }
@@ -675,7 +720,7 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
         { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_SA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), (int)M, H, H, ep)); }
         CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, nullptr, 0, d.st1, M, H));
         { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), (int)M, H, H, ep)); }
-        { Epi ep; ep.bias = cx.Pf(w.ca_b + H); CK(cx.lin_fwd(cx.A32(e->mem, H), cx.W(w.ca_w + (long)H * H, H), cx.AT(d.kv_c, 2 * H), (int)M, 2 * H, H, ep)); }
+        if (!kv_batched) { Epi ep; ep.bias = cx.Pf(w.ca_b + H); CK(cx.lin_fwd(cx.A32(e->mem, H), cx.W(w.ca_w + (long)H * H, H), cx.AT(d.kv_c, 2 * H), (int)M, 2 * H, H, ep)); }
         { const char* kv = (const char*)d.kv_c;
           CK(dec_attn(cx, false, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, d.ao_c, d.lse_c, c.window_size, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_CA))); }
         { Epi ep; ep.bias = cx.Pf(w.ca_ob); ep.residual = d.x1; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_CA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_c, H), cx.W(w.ca_ow, H), cx.A32(d.s2, H), (int)M, H, H, ep)); }
@@ -693,7 +738,7 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     return 0;
 }
 
-// stage 0: heads + decoder + stem (bucket 0).  Leaves d(cls_state) in t_des and d(cls_cad) in t_dec.
+// stage 0: heads + decoder (bucket 0).  Leaves the gradient of the decoder input in t_dcur and that of the memory in t_dmem.
 // Descriptor tables of the deferred decoder weight gradients (vcad_engine::Deferred): group 0 = activations kept in the
 // compute dtype (f1, ao_c, ao_s), group 1 = fp32 residual-stream inputs (x2, x1, memory, layer input).
 int build_deferred(const Ctx& cx, const float* tgt0) {
@@ -721,6 +766,14 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
         add(1, cx.AT(d.g_dkv, 2 * H), cx.A32(e->mem, H), w.ca_w + (long)H * H, H, w.ca_b + H, 2 * H, H);
         add(0, cx.AT(d.g_du_sa, H), cx.AT(d.ao_s, H), w.sa_ow, H, w.sa_ob, H, H);
         add(1, cx.AT(d.g_dqkv, 3 * H), cx.A32(xin, H), w.sa_w, H, w.sa_b, 3 * H, H);
+        // the three LayerNorm backwards' partial rows [blocks][dgamma | dbeta]: norm{1,2,3}.weight and .bias are adjacent in the flat buffer
+        const long nw[3] = {w.n1w, w.n2w, w.n3w}, nb[3] = {w.n1b, w.n2b, w.n3b};
+        for (int i = 0; i < 3; ++i) {
+            if (nb[i] != nw[i] + H) { vc_set_error("internal: LayerNorm weight / bias not adjacent"); return VC_ERR_ARG; }
+            ColsumJob j; memset(&j, 0, sizeof(j));
+            j.x = d.ln_part[i]; j.ld = 2L * H; j.rows = (int)vc_ln_bwd_blocks(M); j.cols = 2 * H; j.out = cx.Gf(nw[i]); j.is_bf16 = 0;
+            df.cs.push_back(j);
+        }
     }
     for (int g = 0; g < 2; ++g) {
         const int n = (int)df.calls[g].size();
@@ -731,8 +784,8 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
         CK(vc_upload(df.d_probs[g], probs.data(), (size_t)n * sizeof(GemmParams), cx.s));
         CK(vc_upload(df.d_tiles[g], tiles.data(), (size_t)(n + 1) * sizeof(int), cx.s));
     }
-    int strips = 0; long poff = 0; const int chunks = (int)VC_CEIL_DIV(M, 128);
-    for (auto& j : df.cs) { j.strip_start = strips; j.part_off = poff; strips += VC_CEIL_DIV(j.cols, 256); poff += (long)chunks * j.cols; }
+    int strips = 0; long poff = 0; const int chunks = (int)VC_CEIL_DIV(M, 128);      // (no job has more rows than M)
+    for (auto& j : df.cs) { j.strip_start = strips; j.part_off = poff; strips += VC_CEIL_DIV(j.cols, 256); poff += (long)VC_CEIL_DIV(j.rows, 128) * j.cols; }
     df.cs_strips = strips; df.cs_chunks = chunks;
     CK(vc_upload(df.d_cs, df.cs.data(), df.cs.size() * sizeof(ColsumJob), cx.s));
     df.ready = true;
@@ -762,14 +815,14 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         const float* xin = L == 0 ? tgt0 : e->da[L - 1].x3;
         // ---- FFN   x3 = LN3(x2 + drop(W2 drop(relu(W1 x2 + b1)) + b2))
         Mat du;
-        CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du, d.g_du_ff));
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s3, H, d.st3, w.n3w, w.n3b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_FF_OUT), &du, d.g_du_ff, nullptr, defer ? d.ln_part[2] : nullptr));
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.f1, ff), cx.Gf(w.w2), ff, cx.Gf(w.b2), (int)M, H, ff));
         { Epi ep; ep.dact = d.f1; ep.lddact = ff; ep.dkind = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT);   // f1 > 0 <=> z > 0 and kept
           CK(cx.lin_dgrad(du, cx.W(w.w2, ff), cx.AT(d.g_df1, ff), (int)M, H, ff, ep)); }
         if (!defer) CK(cx.lin_wgrad(cx.AT(d.g_df1, ff), cx.A32(d.x2, H), cx.Gf(w.w1), H, cx.Gf(w.b1), (int)M, ff, H));
         { Epi ep; ep.residual = dx; ep.ldr = H; CK(cx.lin_dgrad(cx.AT(d.g_df1, ff), cx.W(w.w1, H), cx.A32(dx, H), (int)M, ff, H, ep)); }
         // ---- cross attention
-        CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du, d.g_du_ca));
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s2, H, d.st2, w.n2w, w.n2b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_CA_OUT), &du, d.g_du_ca, nullptr, defer ? d.ln_part[1] : nullptr));
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_c, H), cx.Gf(w.ca_ow), H, cx.Gf(w.ca_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.ca_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* kv = (const char*)d.kv_c; char* dkv = (char*)d.g_dkv;
@@ -783,7 +836,7 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         { Epi ep; if (L != c.num_decoder_layers - 1) { ep.residual = e->t_dmem; ep.ldr = H; }
           CK(cx.lin_dgrad(cx.AT(d.g_dkv, 2 * H), cx.W(w.ca_w + (long)H * H, H), cx.A32(e->t_dmem, H), (int)M, 2 * H, H, ep)); }
         // ---- self attention
-        CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du, d.g_du_sa));
+        CK(cx.ln_bwd(VC_F32, dx, H, d.s1, H, d.st1, w.n1w, w.n1b, nullptr, 0, dx, H, M, H, cx.site(3, L, Ctx::K_SA_OUT), &du, d.g_du_sa, nullptr, defer ? d.ln_part[0] : nullptr));
         if (!defer) CK(cx.lin_wgrad(du, cx.AT(d.ao_s, H), cx.Gf(w.sa_ow), H, cx.Gf(w.sa_ob), (int)M, H, H));
         CK(cx.lin_dgrad(du, cx.W(w.sa_ow, H), cx.AT(e->t_dao_d, H), (int)M, H, H, Epi()));
         { const char* q = (const char*)d.qkv_s; char* dq = (char*)d.g_dqkv;
@@ -802,7 +855,16 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
             CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], gs));
         CK(vc_colsum_grouped(df.d_cs, (int)df.cs.size(), df.cs_strips, df.cs_chunks, df.cs_partial, gs));
     }
-    // ---- stem (reference model/autoregressive_transformer.py:144-178); dx = gradient of the decoder's tgt input
+    return 0;
+}
+
+// stage 1: stem (bucket 1; reference model/autoregressive_transformer.py:144-178).  dx = gradient of the decoder's tgt input (left in t_dcur by stage 0).
+// Leaves d(cls_state) in t_des and d(cls_cad) in t_dec.
+int backward_stage_stem(vcad_engine* e, vc_stream_t s) {
+    Ctx cx{e, s}; const vcad_config& c = e->c;
+    const int B = e->B, T = e->T, H = c.hidden_size, D = c.vit_dim; const long M = (long)B * T;
+    float* dx = e->t_dcur;
+    const bool pa = c.enable_past_actions, ps = c.enable_past_states, tsE = c.enable_timestep_embedding;
     float* dpre = e->t_dpre;
     if (tsE) CK(vc_memset_async(cx.Gf(e->o_ts), 0, (size_t)c.max_ep_len * H * 4, s));   // rows >= T receive no gradient
     if (pa) {                                                                          // tgt = tanh(embed_action(a) + ts)
@@ -919,7 +981,7 @@ int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, v
     if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
     e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = e->dt == VC_BF16 ? (vc_bf16*)shadow : nullptr;
     e->Spk = e->ct == VC_X3 ? (uint32_t*)shadow : nullptr;      // optional: without it the bf16x3 GEMMs split the fp32 weights while staging
-    e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false;
+    e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false; e->kvf.ready = false;
     return 0;
 }
 int vcad_sync_shadow(vcad_engine* e, void* stream) {
@@ -987,7 +1049,9 @@ static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, con
                        float* cmds_out, float* pars_out, void* stream) {
     if (!e->P) { vc_set_error("vcad_forward: parameters not bound"); return VC_ERR_ARG; }
     if (B < 1 || T < 1 || T > e->c.max_ep_len) { vc_set_error("vcad_forward: bad B=%d T=%d", B, T); return VC_ERR_ARG; }
-    if (T > 192) { vc_set_error("vcad_forward: T=%d exceeds the attention kernels' 192-key limit", T); return VC_ERR_UNSUPPORTED; }
+    // bf16 mode: the block-streaming decoder attention (attn_mfma.h) takes any horizon up to max_ep_len; the fp32 / bf16x3 modes' wave-per-row
+    // kernels (attn.h) hold at most three 64-key pieces per query in registers
+    if (T > 192 && e->dt != VC_BF16) { vc_set_error("vcad_forward: T=%d exceeds the fp32 attention kernels' 192-key limit (bf16 mode has none)", T); return VC_ERR_UNSUPPORTED; }
     if ((double)B * T * 50.0 * 3072.0 >= 4294967296.0) { vc_set_error("vcad_forward: B*T=%d too large for 32-bit dropout indices", B * T); return VC_ERR_UNSUPPORTED; }
     if (!e->ws) { vc_set_error("vcad_forward: no workspace"); return VC_ERR_WORKSPACE; }
     if (B != e->B || T != e->T || e->planned_ws != e->ws) {     // same (B, T, workspace): pointers, deferred tables and W^T jobs stay valid
@@ -1052,24 +1116,27 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
     int rc = 0;
     switch (stage) {
         case 0: rc = backward_stage0(e, dcmds ? dcmds : e->dl_cmds, dpars ? dpars : e->dl_pars, s); break;
-        case 1: { Ctx c1{e, e->bwd_fork ? e->side : s, 1}; rc = vit_backward(c1, 1, e->t_dec, 0, e->c.num_views > 0 ? e->cadmv : e->in_cad, 1, img2); } break;
-        case 2: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride) : 0; break;
-        case 3: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride) : 0; break;
+        case 1: rc = backward_stage_stem(e, s); break;
+        case CAD_STAGE: { Ctx c1{e, e->bwd_fork ? e->side : s, 1}; rc = vit_backward(c1, 1, e->t_dec, 0, e->c.num_views > 0 ? e->cadmv : e->in_cad, 1, img2); } break;
+        case 3: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 1, e->in_frames, e->T, e->in_fbstride) : 0; break;
+        case 4: rc = e->c.enable_past_states ? vit_backward(cx, 0, e->t_des, 2, e->in_frames, e->T, e->in_fbstride) : 0; break;
         default: vc_set_error("vcad_backward_stage: stage %d out of range", stage); return VC_ERR_ARG;
     }
     if (rc) return rc;
     if (vc_last_launch_error()) { vc_set_error("vcad_backward: kernel launch failed"); return VC_ERR_LAUNCH; }
     return 0;
 }
-// Data-parallel callers: stage 1 (the CAD ViT's backward) launched on the side stream; its bucket may be all-reduced only after
-// vcad_join_side() has made the caller's stream wait for it — so the caller runs stages 2 and 3 (and their all-reduces) first.
+int vcad_side_stage(const vcad_engine*) { return CAD_STAGE; }
+// Data-parallel callers: the CAD ViT's backward (stage vcad_side_stage()) launched on the side stream; its bucket may be all-reduced only after
+// vcad_join_side() has made the waiting stream wait for it.  *forked (optional) reports whether the side stream was used: when it was not
+// (enable_past_states off, side stream disabled, profiler recording, stream creation failed) the stage ran on the caller's stream in line.
 int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dpars, void* stream) {
-    if (stage != 1) { vc_set_error("vcad_backward_stage_side: only stage 1 (CAD ViT) can run on the side stream"); return VC_ERR_ARG; }
+    if (stage != CAD_STAGE) { vc_set_error("vcad_backward_stage_side: only stage %d (CAD ViT) can run on the side stream", CAD_STAGE); return VC_ERR_ARG; }
     vc_stream_t s = (vc_stream_t)stream;
     const bool fork = e->c.enable_past_states && ensure_side(e);
     if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
     e->bwd_fork = fork;
-    int rc = vcad_backward_stage(e, 1, dcmds, dpars, stream);
+    int rc = vcad_backward_stage(e, CAD_STAGE, dcmds, dpars, stream);
     e->bwd_fork = false;
     if (rc) return rc;
     if (fork) { CK(vc_event_record(e->ev_join, e->side)); e->side_pending = true; }
@@ -1080,8 +1147,8 @@ int vcad_join_side(vcad_engine* e, void* stream) {
     return 0;
 }
 
-// Whole backward: after stage 0 (heads + decoder + stem) the CAD ViT's backward (stage 1) is independent of the frame ViT's
-// (stages 2-3), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
+// Whole backward: after stages 0-1 (heads + decoder, stem) the CAD ViT's backward (stage 2) is independent of the frame ViT's
+// (stages 3-4), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
 // soon as its stage returns) keeps everything on the caller's stream.
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
     vc_stream_t s = (vc_stream_t)stream;
@@ -1090,13 +1157,14 @@ int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* 
     int rc0 = vcad_backward_stage(e, 0, dcmds, dpars, stream);
     e->bwd_side = false;
     if (rc0) return rc0;
+    CK(vcad_backward_stage(e, 1, dcmds, dpars, stream));
     if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
     e->bwd_fork = fork;
-    int rc = vcad_backward_stage(e, 1, dcmds, dpars, stream);
+    int rc = vcad_backward_stage(e, CAD_STAGE, dcmds, dpars, stream);
     e->bwd_fork = false;
     if (rc) return rc;
     if (fork) CK(vc_event_record(e->ev_join, e->side));
-    for (int st = 2; st < NB_BUCKETS; ++st) CK(vcad_backward_stage(e, st, dcmds, dpars, stream));
+    for (int st = CAD_STAGE + 1; st < NB_BUCKETS; ++st) CK(vcad_backward_stage(e, st, dcmds, dpars, stream));
     if (fork) CK(vc_stream_wait_event(s, e->ev_join));
     return 0;
 }
@@ -1237,8 +1305,8 @@ int vcad_infer_step(vcad_engine* e, int t, const void* frame, int64_t frame_bstr
 
 int vcad_optimizer_step(vcad_engine* e, float lr, float b1, float b2, float eps, float max_norm, int step, float gscale,
                         float* norm_out, void* stream) {
-    const float lr4[NB_BUCKETS] = {lr, lr, lr, lr};
-    return vcad_optimizer_step_groups(e, lr4, b1, b2, eps, max_norm, step, gscale, norm_out, stream);
+    float lrs[NB_BUCKETS]; for (int i = 0; i < NB_BUCKETS; ++i) lrs[i] = lr;
+    return vcad_optimizer_step_groups(e, lrs, b1, b2, eps, max_norm, step, gscale, norm_out, stream);
 }
 int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1, float b2, float eps, float max_norm, int step, float gscale,
                                float* norm_out, void* stream) {
@@ -1251,7 +1319,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
     // the norm the reference clips against is that of the (already averaged) gradients
     CK(vc_grad_norm(e->G, e->ptotal, max_norm, gscale, e->norm_part, e->norm_out, s));
     // one launch per run of buckets that share a learning rate (the reference's `frozen` mode, trainer.py:237-251, gives the CAD ViT,
-    // the frame ViT and everything else their own lr: exactly buckets 1, 2-3 and 0 of the flat layout); the clip norm stays global
+    // the frame ViT and everything else their own lr: exactly buckets 2, 3-4 and 0-1 of the flat layout); the clip norm stays global
     for (int b0 = 0; b0 < NB_BUCKETS;) {
         int b1i = b0; while (b1i + 1 < NB_BUCKETS && lr_bucket[b1i + 1] == lr_bucket[b0]) ++b1i;
         const long lo = e->buckets[b0].first, hi = e->buckets[b1i].second;

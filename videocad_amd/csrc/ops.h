@@ -53,6 +53,7 @@ int vc_gemm_mid_launch(GemmCall c, vc_stream_t s);          // gemm_mid.h (ops_g
 int vc_gemm_mid_tile_m(int trb); int vc_gemm_mid_tile_n(int trb);
 // grouped launch of many same-signature problems in one grid (see ops_gemm.hip)
 int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start);
+bool vc_gemm_grouped_has_forward();
 int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s);
 
 int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s);

@@ -2,6 +2,7 @@
 #include "ops.h"
 #include "attn_mfma.h"
 #include "attn_f32.h"
+#include "attn_x3.h"
 
 static int clampw(const AttnParams& p) { int mx = (p.Tq + p.qpos) > p.Tk ? (p.Tq + p.qpos) : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
 static int max_keys(const AttnParams& p) { int w = clampw(p); return w < p.Tk ? w : p.Tk; }        // visible keys per query
@@ -57,6 +58,14 @@ static bool mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv && al(p.dq, p.lddq) && al(p.dk, p.lddk) && al(p.dv, p.lddv);   // (16-byte row stores)
 }
+// bf16x3 mode (attn_x3.h): fp32 tensors, 64-dim heads, <= 64 tokens, full attention, 16-byte-aligned head slices (the ViT)
+static bool x3_ok(int t, int D, const AttnParams& p, bool bwd) {
+    auto al = [](const void* q, long ld) { return q && ((uintptr_t)q % 16 == 0) && (ld % 4 == 0); };
+    bool ok = t == VC_F32 && p.x3 && D == AM_D && p.Tq == p.Tk && p.Tq <= AM_T && !p.causal && clampw(p) >= p.Tk && !p.qpos && !p.kv_rows &&
+              al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    if (!bwd) return ok && al(p.o, p.ldo);
+    return ok && al(p.dout, p.lddo) && p.lse && al(p.dq, p.lddq) && al(p.dk, p.lddk) && al(p.dv, p.lddv);
+}
 // decoder attention on the matrix cores (attn_mfma.h): bf16, head dim 256, causal (+ window band), T <= 64
 static bool dec_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
@@ -64,12 +73,13 @@ static bool dec_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
     if (!bwd) return ok && al(p.o, p.ldo);
     return ok && al(p.dout, p.lddo) && p.lse && p.dq && p.dk && p.dv && al(p.dq, p.lddq) && al(p.dk, p.lddk) && al(p.dv, p.lddv);   // (16-byte row stores)
 }
-// ... and for 64 < T <= 192 (key-block loop)
+// ... and for T > 64 (any horizon: NCH waves per 64-row block, streaming over the blocks of the other side)
 static bool dec_long_ok(int t, int D, const AttnParams& p, bool bwd) {
     auto al = [](const void* q, long ld) { return ((uintptr_t)q % 16 == 0) && (ld % 8 == 0); };
-    bool ok = t == VC_BF16 && (D == 4 * AM_D || D == 2 * AM_D) && p.Tq == p.Tk && p.Tq > AM_T && p.Tq <= AM_MAXB * AM_T && p.causal && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv);
+    bool ok = t == VC_BF16 && (D == 4 * AM_D || D == 2 * AM_D) && p.Tq == p.Tk && p.Tq > AM_T && p.causal && !p.qpos && !p.kv_rows && al(p.q, p.ldq) && al(p.k, p.ldk) && al(p.v, p.ldv) &&
+              (double)p.B * p.H * p.Tq * p.Tq < 4294967296.0;                 // (32-bit dropout indices)
     if (!bwd) return ok && al(p.o, p.ldo);
-    return ok && al(p.dout, p.lddo) && p.lse && p.delta && p.dq && p.dk && p.dv;
+    return ok && al(p.dout, p.lddo) && p.lse && p.delta && p.dq && p.dk && p.dv && al(p.dq, p.lddq) && al(p.dk, p.lddk) && al(p.dv, p.lddv);   // (16-byte row stores)
 }
 // fp32 tensors on the f32 matrix cores (attn_f32.h): full / causal / banded attention with Tq == Tk <= 64, head dims 64 / 128 / 256
 static bool f32_mfma_ok(int t, int D, const AttnParams& p, bool bwd) {
@@ -102,6 +112,11 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (t == VC_BF16 && p.Tq == 1 && !p.causal && p.Tk <= 64 && D == 64 && p.window >= p.Tk && !p.qpos && !p.kv_rows && g_vit_bwd_variant == 0 &&
         ((uintptr_t)p.o % 16 == 0) && (p.ldo % 8 == 0)) {         // cls-only query (last ViT layer)
         VC_LAUNCH(attn_fwd_single_query_bf16_kernel, dim3((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4)), dim3(256), 0, s, p);
+        return VC_OK;
+    }
+    if (x3_ok(t, D, p, false)) {                                   // bf16x3 mode: split operands on the bf16 matrix cores
+        if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_x3_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+        else VC_LAUNCH((attn_vit_fwd2_x3_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         return VC_OK;
     }
     if (mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {      // two waves per (frame, head)
@@ -139,9 +154,17 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
     }
 #endif
     if (dec_long_ok(t, D, p, false)) {
+        static unsigned attr = 0;
+        if (!(attr & vc_device_bit())) {
+            if (int rc = set_dyn_lds(attn_dec_fwd_blk_kernel<true, 4>, am_blk_fwd_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_fwd_blk_kernel<false, 4>, am_blk_fwd_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_fwd_blk_kernel<true, 2>, am_blk_fwd_lds_bytes(2))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_fwd_blk_kernel<false, 2>, am_blk_fwd_lds_bytes(2))) return rc;
+            attr |= vc_device_bit();
+        }
         const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
-        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 4>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 4>), g, dim3(64), 0, s, p); }
-        else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<true, 2>), g, dim3(64), 0, s, p); else VC_LAUNCH((attn_dec_fwd_long_mfma_kernel<false, 2>), g, dim3(64), 0, s, p); }
+        if (D == 4 * AM_D) { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_blk_kernel<true, 4>), g, dim3(256), am_blk_fwd_lds_bytes(4), s, p); else VC_LAUNCH((attn_dec_fwd_blk_kernel<false, 4>), g, dim3(256), am_blk_fwd_lds_bytes(4), s, p); }
+        else               { if (p.drop.key) VC_LAUNCH((attn_dec_fwd_blk_kernel<true, 2>), g, dim3(128), am_blk_fwd_lds_bytes(2), s, p); else VC_LAUNCH((attn_dec_fwd_blk_kernel<false, 2>), g, dim3(128), am_blk_fwd_lds_bytes(2), s, p); }
         return VC_OK;
     }
     if (f32_mfma_ok(t, D, p, false)) {                            // one wave per 32-query block, everything on the f32 matrix cores
@@ -166,6 +189,17 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         dim3 g((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4));
         if (t == VC_BF16) VC_LAUNCH((attn_bwd_single_query_kernel<vc_bf16, 1>), g, dim3(256), 0, s, p);
         else VC_LAUNCH((attn_bwd_single_query_kernel<float, 1>), g, dim3(256), 0, s, p);
+        return VC_OK;
+    }
+    if (x3_ok(t, D, p, true)) {                                    // bf16x3 mode
+        static unsigned attr = 0;
+        if (!(attr & vc_device_bit())) {
+            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<true>, ax_bwd_lds_bytes())) return rc;
+            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<false>, ax_bwd_lds_bytes())) return rc;
+            attr |= vc_device_bit();
+        }
+        if (p.drop.key) VC_LAUNCH((attn_vit_bwd4_x3_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(256), ax_bwd_lds_bytes(), s, p);
+        else VC_LAUNCH((attn_vit_bwd4_x3_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(256), ax_bwd_lds_bytes(), s, p);
         return VC_OK;
     }
     if (mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {       // four waves per (frame, head)
@@ -205,19 +239,19 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (dec_long_ok(t, D, p, true)) {
         static unsigned attr = 0;
         if (!(attr & vc_device_bit())) {
-            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<true, 4>, AM_LONG_Q_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 4>, AM_LONG_Q_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 4>, AM_LONG_KV_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<false, 4>, AM_LONG_KV_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<true, 2>, AM_LONG_Q_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_q_long_mfma_kernel<false, 2>, AM_LONG_Q_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<true, 2>, AM_LONG_KV_LDS)) return rc;
-            if (int rc = set_dyn_lds(attn_dec_bwd_kv_long_mfma_kernel<false, 2>, AM_LONG_KV_LDS)) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_blk_kernel<true, 4>, am_blk_bwd_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_blk_kernel<false, 4>, am_blk_bwd_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_blk_kernel<true, 4>, am_blk_bwd_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_blk_kernel<false, 4>, am_blk_bwd_lds_bytes(4))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_blk_kernel<true, 2>, am_blk_bwd_lds_bytes(2))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_q_blk_kernel<false, 2>, am_blk_bwd_lds_bytes(2))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_blk_kernel<true, 2>, am_blk_bwd_lds_bytes(2))) return rc;
+            if (int rc = set_dyn_lds(attn_dec_bwd_kv_blk_kernel<false, 2>, am_blk_bwd_lds_bytes(2))) return rc;
             attr |= vc_device_bit();
         }
         const dim3 g((unsigned)((long)p.B * p.H * VC_CEIL_DIV(p.Tq, AM_T)));
-#define VC_LONG_BWD(DROP_, NCH_) do { VC_LAUNCH((attn_dec_bwd_q_long_mfma_kernel<DROP_, NCH_>), g, dim3(64), AM_LONG_Q_LDS, s, p); \
-                                      VC_LAUNCH((attn_dec_bwd_kv_long_mfma_kernel<DROP_, NCH_>), g, dim3(64), AM_LONG_KV_LDS, s, p); } while (0)
+#define VC_LONG_BWD(DROP_, NCH_) do { VC_LAUNCH((attn_dec_bwd_q_blk_kernel<DROP_, NCH_>), g, dim3(64 * NCH_), am_blk_bwd_lds_bytes(NCH_), s, p); \
+                                      VC_LAUNCH((attn_dec_bwd_kv_blk_kernel<DROP_, NCH_>), g, dim3(64 * NCH_), am_blk_bwd_lds_bytes(NCH_), s, p); } while (0)
         if (D == 4 * AM_D) { if (p.drop.key) VC_LONG_BWD(true, 4); else VC_LONG_BWD(false, 4); }
         else               { if (p.drop.key) VC_LONG_BWD(true, 2); else VC_LONG_BWD(false, 2); }
 #undef VC_LONG_BWD

@@ -2,9 +2,6 @@
 // compiles in parallel with the register-staged kernels of ops_gemm.hip.
 #include "ops.h"
 #include "gemm_dma.h"
-#ifdef VCAD_AB
-#include "gemm_pp.h"       // ping-pong variant: A/B build only (measured 1.6-2x slower, profiles/r02_gemm_pingpong_ab.txt)
-#endif
 
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
 template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
@@ -21,20 +18,6 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
                  (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_DMA);
     const int tiles_n = c.p.N / BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
     const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
-#ifdef VCAD_AB
-    // the ping-pong kernel carries the plain epilogue (bias, k-slice slabs); per-element side inputs stay on the lockstep kernel
-    if (NW == 8 && BN == GD_BN && g_ab.variant == 1 && !c.p.act && !c.p.dact_src && !c.p.aux && !c.p.residual && !c.p.drop.key) {
-#ifndef VC_EMU
-        static unsigned attr_pp = 0;
-        if (!(attr_pp & vc_device_bit())) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_pp_kernel<TO, TRA, TRB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GP_LDS_BYTES);
-            if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
-            attr_pp |= vc_device_bit();
-        }
-#endif
-        VC_LAUNCH((gemm_pp_kernel<TO, TRA, TRB>), dim3(grid), dim3(GD_THREADS), GP_LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total);
-    } else
-#endif
     {
     // XCD column groups (see the kernel): only for k-contiguous forward-layout GEMMs whose weight matrix would not stay in one XCD's L2
     int xn = 1;

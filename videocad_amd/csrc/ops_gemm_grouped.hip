@@ -37,12 +37,16 @@ static int grouped_launch(const GemmCall& sig, GemmGroup grp, int total_tiles, d
     return VC_OK;
 }
 
-// Device half: probs / tile_start are DEVICE pointers holding what vc_gemm_grouped_prepare produced.  Only the wgrad layout
-// (tra = trb = 1, fp32 output) is instantiated — that is what the engine defers.
+bool vc_gemm_grouped_has_forward() { return true; }
+// Device half: probs / tile_start are DEVICE pointers holding what vc_gemm_grouped_prepare produced.  Instantiated: the wgrad layout
+// (tra = trb = 1, fp32 output) — what the engine defers — and the bf16 forward layout on fp32 activations (batched K / V projections).
 int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s) {
     if (n <= 0) return VC_OK;
     GemmGroup grp{probs, tile_start, n};
-    if (!(sig.tra && sig.trb) || sig.to != VC_F32) { vc_set_error("vc_gemm_grouped: only the wgrad layout is instantiated"); return VC_ERR_UNSUPPORTED; }
+    // forward layout (r04: the decoder's batched cross-attention K / V projections): fp32 activations x bf16 weights -> bf16, fused bias epilogue
+    if (!sig.tra && !sig.trb && sig.ct == VC_BF16 && sig.sa == VC_F32 && sig.sb == VC_BF16 && sig.to == VC_BF16)
+        return grouped_launch<vc_bf16, float, vc_bf16, vc_bf16, false, false>(sig, grp, total_tiles, flops, s);
+    if (!(sig.tra && sig.trb) || sig.to != VC_F32) { vc_set_error("vc_gemm_grouped: only the wgrad layout (and the bf16 forward layout with fp32 activations) is instantiated"); return VC_ERR_UNSUPPORTED; }
     if (sig.ct == VC_F32) return grouped_launch<float, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
     if (sig.ct == VC_X3) return grouped_launch<vc_x3, float, float, float, true, true>(sig, grp, total_tiles, flops, s);
     if (sig.sa == VC_BF16 && sig.sb == VC_BF16) return grouped_launch<vc_bf16, vc_bf16, vc_bf16, float, true, true>(sig, grp, total_tiles, flops, s);

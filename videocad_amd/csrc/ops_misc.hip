@@ -55,7 +55,7 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     else if (td == VC_F32 && tx == VC_F32 && ty == VC_BF16) rc = ln_bwd_m<float, float, vc_bf16>(C, mode, p, nblk, s);
     else { vc_set_error("ln_bwd: dtype combo %d %d %d", td, tx, ty); return VC_ERR_UNSUPPORTED; }
     if (rc) return rc;
-    if (partial_ws) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C)
+    if (partial_ws && dgamma) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C); dgamma == null: the caller reduces the rows later
         // partial is [nblk][2 or 3][C] (nblk <= 512): dgamma, dbeta and the emitted gradient's column sums in ONE launch (r02: two or three)
         (void)colsum_ws;
         rc = vc_colsum_seg(partial_ws, PS, nblk, C, p.dsum ? 3 : 2, dgamma, dbeta, dsum_out, s); if (rc) return rc;

@@ -51,6 +51,7 @@ class NativeEngine:
             lo, hi = C.c_int64(), C.c_int64()
             L.check(self.lib, self.lib.vcad_bucket_range(h, b, C.byref(lo), C.byref(hi)), "bucket_range")
             self.buckets.append((lo.value, hi.value))
+        self.side_stage = int(self.lib.vcad_side_stage(h))      # the backward stage (CAD ViT) that may run on the library's side stream
         self.params = self.grads = self.m = self.v = self.shadow = None
         self.ws = None
         self.step_count = 0
@@ -219,7 +220,7 @@ class NativeEngine:
         return dc, dp
 
     def backward(self, dcmds=None, dpars=None, stage: Optional[int] = None, side: bool = False):
-        """stage=None: whole backward.  stage=k: one gradient bucket's worth (data-parallel callers).  side=True (stage 1 only): launch on
+        """stage=None: whole backward.  stage=k: one gradient bucket's worth (data-parallel callers).  side=True (stage `side_stage` only): launch on
         the library's side stream — call join_side() before touching that bucket's gradients."""
         if dcmds is not None:
             dcmds = dcmds.contiguous().float(); dpars = dpars.contiguous().float()

@@ -3,7 +3,7 @@
 `.sample(...)`, `.find_first_mistake(...)`, `.save_checkpoint(...)`.
 
 The hot loop (`_process_batch`, reference :480-496) is ONE pass through the C ABI:
-    vcad_forward -> vcad_loss (loss + ~45 metric counters + dlogits, no host sync) -> vcad_backward_stage x4
+    vcad_forward -> vcad_loss (loss + ~45 metric counters + dlogits, no host sync) -> vcad_backward_stage x5
     (gradient all-reduce of each finished bucket over RCCL on a side stream, world_size > 1) -> vcad_optimizer_step
     (global-norm clip 1.0 + Adam, reference :493-494).
 The epoch loop keeps the reference's contract — per-epoch validation (`val_frequency`), checkpoints every `save_frequency`
@@ -117,7 +117,7 @@ class NativeAdam:
             for i, n in enumerate(self.names):
                 idx["cad" if n.startswith("cad_embedding_model.") else "state" if n.startswith("state_embedding_model.") else "rest"].append(i)
             self.param_groups = [self._group(groups["lr_cad"], idx["cad"]), self._group(groups["lr_state"], idx["state"]), self._group(lr, idx["rest"])]
-            self.bucket_lr = [lr, groups["lr_cad"], groups["lr_state"], groups["lr_state"]]
+            self.bucket_lr = [lr, lr, groups["lr_cad"], groups["lr_state"], groups["lr_state"]]   # buckets: heads + decoder, stem, CAD ViT, frame ViT x2
 
     def _group(self, lr, params):
         return {"lr": lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None,
@@ -127,7 +127,7 @@ class NativeAdam:
     def lr(self):
         if self.bucket_lr is not None:
             g = self.param_groups
-            return [g[2]["lr"], g[0]["lr"], g[1]["lr"], g[1]["lr"]]
+            return [g[2]["lr"], g[2]["lr"], g[0]["lr"], g[1]["lr"], g[1]["lr"]]
         return self.param_groups[0]["lr"]
 
     def zero_grad(self, set_to_none=True):
@@ -231,17 +231,25 @@ class GradSync:
 
     Construction does what the DDP constructor did for the reference: rank 0's parameters (and optimiser state) are broadcast,
     so every replica starts from the same weights whatever each process's RNG drew.
-    Each backward stage finalises one contiguous bucket of the flat gradient buffer (heads+decoder+stem first — 75 % of the
-    bytes — then CAD ViT, then the two halves of the frame ViT); its all-reduce(SUM) is issued on a side stream right away
-    so it runs over xGMI underneath the next stage's kernels.  The 1/world mean is folded into the Adam kernel.
-    Only live parameters travel (508 MB fp32 instead of the reference's 818 MB incl. dead GPT-2 zeros)."""
+    Each backward stage finalises one contiguous bucket of the flat gradient buffer: heads + decoder first (360 MB, 71 % of the bytes —
+    its all-reduce starts before the stem's backward is even launched), then the stem (16 MB), the CAD ViT (65 MB, computed on the engine's
+    side stream), and the two halves of the frame ViT.  Every all-reduce(SUM) is issued on a communication stream right away so it runs over
+    xGMI underneath the next stage's kernels; the stem's bucket travels with the CAD ViT's (adjacent ranges: one collective).  The 1/world
+    mean is folded into the Adam kernel.  Only live parameters travel (508 MB fp32 instead of the reference's 818 MB incl. dead GPT-2 zeros).
+    `timing = True` records issue / completion events around every collective; `comm_report()` turns the last step's into milliseconds
+    relative to the start of the backward (the first N-GPU run is then diagnosable from one line)."""
 
-    def __init__(self, engine, group=None, on_params_changed=None):
+    def __init__(self, engine, group=None, on_params_changed=None, force_staged=False):
         import torch.distributed as dist
         self.eng, self.dist, self.group = engine, dist, group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.stream = torch.cuda.Stream(device=engine.device) if (self.world > 1 and engine.device.type == "cuda") else None
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if inited else 1
+        # force_staged: take the bucketed multi-stream path even in a 1-rank group (each all-reduce is then RCCL's one-rank copy): how the
+        # stream / event choreography is exercised on a box with a single GPU (tests; training_config["force_bucketed_exchange"])
+        self.staged = self.world > 1 or (bool(force_staged) and inited)
+        self.stream = torch.cuda.Stream(device=engine.device) if (self.staged and engine.device.type == "cuda") else None
         self.skip_comm = False                                    # diagnostic only (bench: exposed communication time)
+        self.timing, self._ev = False, []                         # diagnostic only: per-collective (label, MB, start, issue, done) events
         if self.world > 1:
             engine.set_dynamic_items(True)        # RCCL's kernels hold CUs under the backward: the persistent GEMM draws its items with tickets then
             src = dist.get_global_rank(group, 0) if group is not None else 0
@@ -255,7 +263,7 @@ class GradSync:
 
     def backward(self, dcmds=None, dpars=None):
         eng = self.eng
-        if self.world == 1:
+        if not self.staged:
             eng.backward(dcmds, dpars)
             return
         if self.stream is None:                                   # CPU / gloo (tests): sequential
@@ -264,35 +272,52 @@ class GradSync:
                 self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
             return
         cur = torch.cuda.current_stream(eng.device)
+        side = eng.side_stage
+        t0 = None
+        if self.timing:
+            t0 = torch.cuda.Event(enable_timing=True); t0.record(cur); self._ev = []
 
-        def reduce_bucket(st):
-            if self.skip_comm:
-                return
-            lo, hi = eng.buckets[st]
+        def reduce_range(b_lo, b_hi, wait_side=False):
+            """all-reduce buckets b_lo..b_hi (adjacent ranges of the flat buffer) on the communication stream, behind everything enqueued on `cur`"""
+            lo, hi = eng.buckets[b_lo][0], eng.buckets[b_hi][1]
             ev = torch.cuda.Event(); ev.record(cur)
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                if wait_side:
+                    eng.join_side()                                 # comm stream <- completion event of the engine's side stream (no-op when it did not fork)
+                if self.skip_comm:
+                    return
+                if self.timing:
+                    a = torch.cuda.Event(enable_timing=True); a.record(self.stream)
                 self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
+                if self.timing:
+                    b = torch.cuda.Event(enable_timing=True); b.record(self.stream)
+                    self._ev.append((f"{b_lo}-{b_hi}" if b_hi != b_lo else str(b_lo), (hi - lo) * 4 / 1e6, t0, a, b))
 
-        # stage 1 (CAD ViT: ~230 small kernels) runs on the engine's side stream beside the frame ViT's stages 2-3.  Its bucket (65 MB) is
-        # all-reduced as soon as THAT stream is done: the communication stream — not the compute stream — waits for the side stream's
-        # completion event (vcad_join_side on the communication stream), so the exchange runs under stages 2 and 3 instead of after them
-        # (r02 reduced it last, leaving bucket 1 + bucket 3 = 99 MB with nothing to hide behind; now only bucket 3 is exposed).
-        eng.backward(dcmds, dpars, stage=0); reduce_bucket(0)
-        eng.backward(dcmds, dpars, stage=1, side=True)
-        # When the engine did NOT fork (enable_past_states off, side stream disabled, profiler on, stream creation failed) stage 1 ran on `cur`
-        # and join_side() is a no-op: the communication stream must then wait for `cur` itself.  When it did fork this event sits right
-        # behind stage 0's kernels (which the comm stream has waited for already), so the wait is free.
-        ev1 = torch.cuda.Event(); ev1.record(cur)
-        with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev1)
-            eng.join_side()                                         # comm stream <- side-stream event
-            if not self.skip_comm:
-                lo, hi = eng.buckets[1]
-                self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
-        for st in range(2, len(eng.buckets)):
-            eng.backward(dcmds, dpars, stage=st); reduce_bucket(st)
+        # The CAD ViT's stage (~230 small kernels) runs on the engine's side stream beside the frame ViT's stages.  Its bucket (+ the stem's) is
+        # all-reduced as soon as THAT stream is done: the communication stream — not the compute stream — waits for the side stream's completion
+        # event (vcad_join_side on the communication stream), so the exchange runs under the frame ViT's stages instead of after them.  If the
+        # engine did not fork (enable_past_states off, side stream disabled, profiler on) the stage ran on `cur` and join_side() is a no-op: the
+        # event recorded on `cur` AFTER the stage's launch (reduce_range does that) is what orders the collective behind it; when it did fork
+        # that event sits right behind the stem's kernels, so the wait costs nothing.
+        eng.backward(dcmds, dpars, stage=0); reduce_range(0, 0)
+        for st in range(1, side):
+            eng.backward(dcmds, dpars, stage=st)
+        eng.backward(dcmds, dpars, stage=side, side=True)
+        reduce_range(1, side, wait_side=True)
+        for st in range(side + 1, len(eng.buckets)):
+            eng.backward(dcmds, dpars, stage=st); reduce_range(st, st)
         cur.wait_stream(self.stream)                                # (covers the side stream too: the comm stream waited for it)
+        if self.timing:
+            self._t_end = torch.cuda.Event(enable_timing=True); self._t_end.record(cur)
+
+    def comm_report(self):
+        """[{bucket, MB, issue_ms, done_ms}] of the last timed step (ms since the backward started) + when the backward's compute rejoined"""
+        if not self._ev:
+            return None
+        torch.cuda.synchronize(self.eng.device)
+        rep = [{"bucket": lab, "MB": round(mb, 1), "issue_ms": round(t0.elapsed_time(a), 3), "done_ms": round(t0.elapsed_time(b), 3)} for lab, mb, t0, a, b in self._ev]
+        return {"collectives": rep, "backward_joined_ms": round(self._ev[0][2].elapsed_time(self._t_end), 3)}
 
 
 # ------------------------------------------------------------------------------------------------ trainer
@@ -326,7 +351,7 @@ class BaseTrainer:
         self.restore_best_weights = cfg("restore_best_weights", False)
         self.stage_inputs = cfg("stage_inputs", True)             # double-buffered H2D staging of the train loader (data.DeviceStager)
         self.native._drop_rank = rank                             # every rank draws its own dropout masks
-        self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed)
+        self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed, force_staged=cfg("force_bucketed_exchange", False))
         self.action_mask = self.native.action_mask.to(device) if hasattr(self.native.action_mask, "to") else self.native.action_mask
         self._best_params = None
 
