@@ -117,6 +117,24 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
                               ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, flags | GEMM_FLAGS, None, stream_of(device))
         L.check(lib, rc, "gemm (pre-split B)")
         assert torch.equal(C2.cpu(), Cbuf.cpu()), "pre-split B operand: result differs from the in-kernel split"
+    if pack_b and (not tra or trb):
+        # r04: A pre-split too, and (forward / dgrad layouts) the output written pre-split — same hi / lo values as the in-kernel split, so the fp32
+        # result is bit-identical and the pre-split output holds exactly the words vcad_op_pack_x3 makes of it
+        pack = lambda t: (lambda o: (L.check(lib, lib.vcad_op_pack_x3(ptr(t), ptr(o), t.numel(), stream_of(device)), "pack_x3"), o)[1])(torch.empty(t.shape, dtype=torch.int32, device=device))
+        Ap = pack(A)
+        C3 = torch.full((M, N + pad), 7.0, dtype=to, device=device)
+        rc = lib.vcad_op_gemm(TD[ct], 3, 3, TD[to], tra, trb, ptr(Ap), ptr(Bp), ptr(C3), M, N, K, lda, ldb, N + pad,
+                              ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, flags | GEMM_FLAGS, None, stream_of(device))
+        L.check(lib, rc, "gemm (pre-split A and B)")
+        assert torch.equal(C3.cpu(), Cbuf.cpu()), "pre-split A operand: result differs from the in-kernel split"
+        if not tra:
+            C4 = torch.full((M, N + pad), 0x40E00000, dtype=torch.int32, device=device)          # (bit pattern of 7.0f in the pad columns)
+            rc = lib.vcad_op_gemm(TD[ct], 3, 3, 3, tra, trb, ptr(Ap), ptr(Bp), ptr(C4), M, N, K, lda, ldb, N + pad,
+                                  ptr(bias_t), act, ptr(res_t), N, 1.0, ptr(scratch), (scratch.numel() * 4) if splitk else 0, flags | GEMM_FLAGS, None, stream_of(device))
+            L.check(lib, rc, "gemm (pre-split output)")
+            assert torch.equal(C4[:, :N].cpu(), pack(Cbuf)[:, :N].cpu()), "pre-split output differs from pack(fp32 output)"
+            if pad:
+                assert bool((C4[:, N:] == 0x40E00000).all()), "gemm (pre-split output) wrote outside the N columns"
     if kernel is not None:
         assert tag.value == kernel, f"gemm M{M} N{N} K{K} tra={tra} trb={trb} flags={flags}: ran on kernel family {tag.value}, expected {kernel}"
     ref = A_q.double() @ B_q.double().t()
@@ -215,6 +233,19 @@ def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=
     tolb = (5e-5 if x3 else 1e-5) if dt == torch.float32 else 1.5e-2
     for i, g in enumerate((qr.grad, kr.grad, vr.grad)):
         assert relerr(dqkv[:, :, i], g) < tolb, ("attn bwd", i, relerr(dqkv[:, :, i], g))
+    if x3:       # r04: the same kernels on pre-split tensors (what the bf16x3 engine hands them): outputs == pack(fp32-tensor outputs), word for word
+        pack = lambda t: (lambda o_: (L.check(lib, lib.vcad_op_pack_x3(ptr(t), ptr(o_), t.numel(), st), "pack_x3"), o_)[1])(torch.empty(t.shape, dtype=torch.int32, device=device))
+        qp, dop = pack(qkv), pack(do)
+        bp = qp.data_ptr()
+        o2 = torch.zeros(B, T, H, D, dtype=torch.int32, device=device); lse2 = torch.empty_like(lse)
+        L.check(lib, lib.vcad_op_attention_fwd(3, D, C.c_void_p(bp), C.c_void_p(bp + H * D * 4), C.c_void_p(bp + 2 * H * D * 4), ptr(o2),
+                                               ld, ld, ld, H * D, ptr(lse2), B, H, T, T, window, causal, scale, st), "attn_fwd (pre-split)")
+        assert torch.equal(o2.cpu(), pack(o).cpu()) and torch.equal(lse2.cpu(), lse.cpu()), "pre-split attention forward differs"
+        dq2 = torch.zeros(B, T, 3, H, D, dtype=torch.int32, device=device); d2 = dq2.data_ptr()
+        L.check(lib, lib.vcad_op_attention_bwd_o(3, D, C.c_void_p(bp), C.c_void_p(bp + H * D * 4), C.c_void_p(bp + 2 * H * D * 4), ptr(o2), H * D,
+                                                 ptr(dop), ld, ld, ld, H * D, ptr(lse), ptr(delta), C.c_void_p(d2), C.c_void_p(d2 + H * D * 4),
+                                                 C.c_void_p(d2 + 2 * H * D * 4), ld, ld, ld, B, H, T, T, window, causal, scale, st), "attn_bwd (pre-split)")
+        assert torch.equal(dq2.cpu(), pack(dqkv).cpu()), "pre-split attention backward differs"
 
 
 def check_attention_single_query(lib, device, B, H, Tk, dt, seed=0):

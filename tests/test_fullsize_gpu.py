@@ -111,17 +111,16 @@ def test_full_size_step_bf16_close_and_train_mode_sane(name, B, T):
     rel, mae = U.relerr(p, ref["pars"]), float((p - ref["pars"]).abs().mean())
     agree = float((p.argmax(-1) == ref["pars"].argmax(-1)).float().mean())
     print(f"\n[{name} bf16 vs fp32 oracle] logit MAE {mae:.3e}  rel {rel:.3e}  argmax agreement {agree:.4f}")
-    # gates at ~1.5x the measured values (profiles/r04_fullsize_measured.jsonl: rel 3.3e-3 .. 3.6e-3, arg-max 0.985 .. 0.992 on the three shapes):
-    # a 2x regression of the throughput mode at the benchmarked shape fails here
-    GATE = {"C2": (5.5e-3, 0.975), "C4_per_gpu": (5.5e-3, 0.975), "C3": (5.5e-3, 0.975)}[name]
-    assert rel < GATE[0] and agree > GATE[1], (name, rel, agree)
+    # gates at ~1.5x the measured values (profiles/r04_fullsize_measured.jsonl: rel 3.42e-3 .. 3.51e-3, arg-max agreement 0.9935 .. 0.9955, loss 5.5e-4 .. 6.1e-4,
+    # worst probed gradient norm 1.46e-3 .. 1.62e-3 on the three shapes): a 2x regression of the throughput mode at the benchmarked shape fails here
+    assert rel < 5.3e-3 and agree > 0.990, (name, rel, agree)
     assert torch.equal(pars[:2], pars[2 * (K - 1):])                       # repetitions are bit-identical: no cross-clip leakage at full grid size
     loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
-    assert abs(float(loss[0]) - ref["loss"]) < 2e-2 * abs(ref["loss"])
+    assert abs(float(loss[0]) - ref["loss"]) < 1e-3 * abs(ref["loss"])
     eng.backward()
     worst = max(abs(float(eng.view(n, eng.grads).double().norm()) - w) / w for n, w in ref["gn"].items())
     record(name + "_bf16", logit_mae=mae, rel_err=rel, argmax_agreement=agree, loss_rel=abs(float(loss[0]) - ref["loss"]) / abs(ref["loss"]), worst_grad_norm_rel=worst)
-    assert worst < 8e-2, worst
+    assert worst < 2.5e-3, worst
     g_eval = float(eng.optimizer_step(lr=0.0)[0])                           # lr 0: weights untouched, norm reported
     w0 = eng.view("embed_state.weight").clone()
     eng.set_dropout(0.1, seed=7)
@@ -149,7 +148,7 @@ def test_full_size_fp8_forward_mode_c5_per_gpu_shape():
     rel, mae = U.relerr(p, ref["pars"]), float((p - ref["pars"]).abs().mean())
     agree = float((p.argmax(-1) == ref["pars"].argmax(-1)).float().mean())
     print(f"\n[C5 per-GPU shape, fp8 forward vs fp32 oracle] logit MAE {mae:.3e}  rel {rel:.3e}  argmax agreement {agree:.4f}")
-    assert rel < 8e-2 and agree > 0.7
+    assert rel < 1.25e-2 and agree > 0.977, (rel, agree)          # ~1.5x measured (8.1e-3, 0.985: profiles/r04_fullsize_measured.jsonl)
     assert torch.equal(pars[:2], pars[2 * (K - 1):])
     loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
     assert abs(float(loss[0]) - ref["loss"]) < 5e-2 * abs(ref["loss"])
@@ -157,7 +156,7 @@ def test_full_size_fp8_forward_mode_c5_per_gpu_shape():
     worst = max(abs(float(eng.view(n, eng.grads).double().norm()) - w) / w for n, w in ref["gn"].items())
     print(f"[C5 per-GPU shape, fp8 forward] worst probed gradient-norm error {worst:.3e}")
     record("C5_per_gpu_fp8_forward", logit_mae=mae, rel_err=rel, argmax_agreement=agree, worst_grad_norm_rel=worst)
-    assert worst < 2.5e-1, worst
+    assert worst < 1.1e-2, worst                                       # measured 6.9e-3
     g_eval = float(eng.optimizer_step(lr=0.0)[0])
     eng.set_dropout(0.1, seed=11)
     cmds, pars = eng.forward(frames[:, :-1], an, cad)

@@ -104,7 +104,7 @@ def test_bench_line_single_gpu_contract():
     j = _bench([])
     assert j["n_gpus"] == 1 and j["unit"] == "frames/s" and j["value"] > 0 and j["config"]["step"].endswith("train_step")
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] < 1
-    assert j["kernel_breakdown"]["attention"]["GBps"] and j["parity"]["argmax_agreement"] > 0.85 and j["parity"]["logit_mae"] < 5e-2
+    assert j["kernel_breakdown"]["attention"]["GBps"] and j["parity"]["argmax_agreement"] >= 0.97 and j["parity"]["logit_mae"] < 1.1e-2 and j["parity"]["rel_err"] < 6e-3          # ~1.5x measured (7.2e-3, 3.9e-3; one near-tie of 96 arg-maxes may flip with the kernel mix)
 
 
 @two_gpus

@@ -186,3 +186,24 @@ def test_gemm_mx8(hip, to, bias, act, residual):
 def test_attention_vit_bf16x3(hip, T):
     """bf16x3 mode's ViT attention (attn_x3.h): fp32 tensors, hi / lo split operands on the bf16 matrix cores — forward and backward at the GEMMs' error level"""
     U.check_attention(hip, DEV, 3, 2, T, 64, window=T, causal=0, dt=F32, x3=True)
+
+
+def test_layernorm_pre_split_outputs(hip):
+    """bf16x3 mode, r04: the typed outputs of the LayerNorm kernels (forward y, backward dx) written as pre-split hi | lo words for the GEMMs that
+    consume them == vcad_op_pack_x3 of the fp32 outputs, word for word"""
+    import ctypes as C_
+    dev = DEV
+    rows, Cn = 37, 512
+    x = U.rnd((rows, Cn), dev, seed=1, scale=2.0) + 0.5; g = U.rnd((Cn,), dev, seed=2, scale=0.2) + 1.0; b = U.rnd((Cn,), dev, seed=3, scale=0.1)
+    y32 = torch.empty(rows, Cn, device=dev); yp = torch.zeros(rows, Cn, dtype=torch.int32, device=dev); stats = torch.empty(rows, 2, device=dev)
+    st = U.stream_of(dev)
+    L.check(hip, hip.vcad_op_layernorm_fwd(L.VCAD_F32, 3, Cn, U.ptr(x), Cn, U.ptr(g), U.ptr(b), U.ptr(y32), U.ptr(yp), U.ptr(stats), rows, 1e-5, st), "ln_fwd pk")
+    want = torch.empty_like(yp); L.check(hip, hip.vcad_op_pack_x3(U.ptr(y32), U.ptr(want), y32.numel(), st), "pack")
+    assert torch.equal(yp.cpu(), want.cpu())
+    dy = U.rnd((rows, Cn), dev, seed=4); add = U.rnd((rows, Cn), dev, seed=5)
+    dx = torch.empty(rows, Cn, device=dev); dxp = torch.zeros(rows, Cn, dtype=torch.int32, device=dev); dg = torch.empty(Cn, device=dev); db = torch.empty(Cn, device=dev)
+    scratch = torch.empty(4 << 20, dtype=torch.float32, device=dev)
+    L.check(hip, hip.vcad_op_layernorm_bwd(L.VCAD_F32, 3, Cn, U.ptr(dy), U.ptr(x), Cn, U.ptr(stats), U.ptr(g), U.ptr(add), U.ptr(dx), U.ptr(dxp), U.ptr(dg), U.ptr(db),
+                                             rows, U.ptr(scratch), scratch.numel() * 4, st), "ln_bwd pk")
+    L.check(hip, hip.vcad_op_pack_x3(U.ptr(dx), U.ptr(want), dx.numel(), st), "pack")
+    assert torch.equal(dxp.cpu(), want.cpu())

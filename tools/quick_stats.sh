@@ -9,6 +9,6 @@ python - <<EOF
 import csv
 rows=list(csv.DictReader(open('$OUT/trace/q_kernel_stats.csv')))
 steps=[int(r['Calls']) for r in rows if r['Name'].startswith('adam_kernel')][0]
-for r in rows[:28]:
+for r in rows[:45]:
     print(f"{float(r['TotalDurationNs'])/1e6/steps:7.3f} ms {int(r['Calls'])/steps:6.1f} x {float(r['AverageNs'])/1e3:8.1f} us  {r['Name'][:110]}")
 EOF

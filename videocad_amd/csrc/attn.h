@@ -33,7 +33,8 @@ struct AttnParams {
     // cached single-step inference (forward, wave-per-row kernel only): query row i sits at absolute position qpos + i, and clip b's
     // keys / values start at row b * kv_rows of the cache (0 = the dense layout: b * Tk)
     int qpos; int kv_rows;
-    // fp32 tensors of the bf16x3 compute mode: the kernels that have an x3 form (attn_x3.h) run on the bf16 matrix cores with hi / lo split operands
+    // fp32 tensors of the bf16x3 compute mode: 1 = the kernels that have an x3 form (attn_x3.h) run on the bf16 matrix cores with hi / lo split operands;
+    // 2 = additionally q / k / v / dout / o / dq / dk / dv are pre-split hi | lo words (gemm.h vc_pk) — only shapes with an x3 kernel
     int x3;
 };
 

@@ -9,6 +9,9 @@
 // Structure, orientation tricks, masks and the dropout bit packing are those of attn_vit_fwd2_kernel / attn_vit_bwd4_body (attn_mfma.h): two
 // waves (forward) / four waves (backward) per (frame, head), tokens padded 50 -> 64; outputs leave as whole 256-byte fp32 rows through a
 // wave-private staging tile.  LDS: two planes per operand tile — 36 KiB (forward), 73 KiB (backward) per workgroup.
+// PK = true (AttnParams::x3 == 2): q / k / v / dout arrive as PRE-SPLIT words (written by the bf16x3 GEMM epilogues that produce them: unpacked
+// here, not split) and o / dq / dk / dv leave pre-split for the GEMMs that consume them — same hi / lo values either way, so the results are
+// bit-identical to the fp32-tensor form.
 #pragma once
 #include "attn_mfma.h"
 #include "attn_f32.h"      // AF_PITCH
@@ -17,8 +20,10 @@
 constexpr int AX_TILE = AM_T * AM_S;                 // elements of one plane
 constexpr int AX_STAGE_FLOATS = 32 * AF_PITCH;       // wave-private fp32 store staging: 32 rows x 68 floats = 8 704 bytes
 
-// stage one fp32 [T x 64] head slice as hi / lo bf16 planes with NT threads (rows >= T zero-filled); every load is issued before the first split
-template <int NT>
+// PK: the tensor holds pre-split hi | lo words (gemm.h vc_pk: written by the producing GEMM epilogue) — unpacked (4 byte-permutes per quad), not split
+template <bool PK> VC_DEV void ax_split4(const vc_u32x4& a, vc_u32x2& hi, vc_u32x2& lo) { if (PK) gemm_unpack4(a, hi, lo); else gemm_split4(a, hi, lo); }
+// stage one fp32 (or pre-split) [T x 64] head slice as hi / lo bf16 planes with NT threads (rows >= T zero-filled); every load is issued before the first split
+template <int NT, bool PK>
 VC_DEV void ax_stage_nt(vc_bf16* hi, vc_bf16* lo, const float* g, long ld, int T, int tid) {
     constexpr int N = AM_T * 8 / NT;
     vc_u32x4 v[N][2];
@@ -32,7 +37,7 @@ VC_DEV void ax_stage_nt(vc_bf16* hi, vc_bf16* lo, const float* g, long ld, int T
     for (int it = 0; it < N; ++it) {
         const int c = tid + NT * it, row = c >> 3, col = (c & 7) * 8;
         vc_u32x2 h0, l0, h1, l1;
-        gemm_split4(v[it][0], h0, l0); gemm_split4(v[it][1], h1, l1);
+        ax_split4<PK>(v[it][0], h0, l0); ax_split4<PK>(v[it][1], h1, l1);
         vc_u32x4 wh, wl;
         wh.x = h0.x; wh.y = h0.y; wh.z = h1.x; wh.w = h1.y; wl.x = l0.x; wl.y = l0.y; wl.z = l1.x; wl.w = l1.y;
         if (row >= T) { wh.x = wh.y = wh.z = wh.w = 0u; wl.x = wl.y = wl.z = wl.w = 0u; }
@@ -84,6 +89,7 @@ VC_DEV void ax_mm_tok1(vc_f32x16 (&out)[2], const vc_f32x16 (&W)[2], const vc_bf
 }
 // rows t*32 .. t*32+31 (< T) of a [token][64] fp32 result whose registers walk the head dim (lane = token row, 4 consecutive columns per
 // accumulator quad): transposed through a wave-private 32 x AF_PITCH fp32 staging tile (16-byte LDS writes), then written as whole 256-byte rows
+template <bool PK>
 VC_DEV void ax_store_rows(float* stage, float* g, long ld, const vc_f32x16 (&acc)[2], int t, int T, int lane, float mul) {
     float* w = stage + (lane & 31) * AF_PITCH + 4 * (lane >> 5);
 #pragma unroll
@@ -91,8 +97,10 @@ VC_DEV void ax_store_rows(float* stage, float* g, long ld, const vc_f32x16 (&acc
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             vc_u32x4 q;
-            q.x = vc_f32_bits(acc[dt][4 * gq] * mul); q.y = vc_f32_bits(acc[dt][4 * gq + 1] * mul);
-            q.z = vc_f32_bits(acc[dt][4 * gq + 2] * mul); q.w = vc_f32_bits(acc[dt][4 * gq + 3] * mul);
+            if (PK) { q.x = vc_pk_pack(acc[dt][4 * gq] * mul); q.y = vc_pk_pack(acc[dt][4 * gq + 1] * mul);
+                      q.z = vc_pk_pack(acc[dt][4 * gq + 2] * mul); q.w = vc_pk_pack(acc[dt][4 * gq + 3] * mul); }
+            else { q.x = vc_f32_bits(acc[dt][4 * gq] * mul); q.y = vc_f32_bits(acc[dt][4 * gq + 1] * mul);
+                   q.z = vc_f32_bits(acc[dt][4 * gq + 2] * mul); q.w = vc_f32_bits(acc[dt][4 * gq + 3] * mul); }
             *reinterpret_cast<vc_u32x4*>(w + dt * 32 + 8 * gq) = q;
         }
     vc_wave_barrier();
@@ -106,15 +114,15 @@ VC_DEV void ax_store_rows(float* stage, float* g, long ld, const vc_f32x16 (&acc
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
-template <bool DROP>
+template <bool DROP, bool PK>
 VC_KERNEL __launch_bounds__(128, 2) void attn_vit_fwd2_x3_kernel(AttnParams p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AX_TILE];          // Q hi, Q lo (then V hi, V lo) ; K hi, K lo (then the store staging)
     const int tid = threadIdx.x, lane = tid & 63, t = vc_uniform(tid >> 6);
     const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
     const int T = p.Tq;
     const long rowq = n * T;
-    ax_stage_nt<128>(tiles[0], tiles[1], (const float*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
-    ax_stage_nt<128>(tiles[2], tiles[3], (const float*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
+    ax_stage_nt<128, PK>(tiles[0], tiles[1], (const float*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
+    ax_stage_nt<128, PK>(tiles[2], tiles[3], (const float*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
     // V is requested NOW (into registers) and parked in Q's tiles once S is done: one memory round trip per workgroup instead of two
     constexpr int NV = AM_T * 8 / 128;
     vc_u32x4 vreg[NV][2];
@@ -139,7 +147,7 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_fwd2_x3_kernel(AttnParams p) {
     for (int it = 0; it < NV; ++it) {
         const int c = tid + 128 * it, row = c >> 3, col = (c & 7) * 8;
         vc_u32x2 h0, l0, h1, l1;
-        gemm_split4(vreg[it][0], h0, l0); gemm_split4(vreg[it][1], h1, l1);
+        ax_split4<PK>(vreg[it][0], h0, l0); ax_split4<PK>(vreg[it][1], h1, l1);
         vc_u32x4 wh, wl;
         wh.x = h0.x; wh.y = h0.y; wh.z = h1.x; wh.w = h1.y; wl.x = l0.x; wl.y = l0.y; wl.z = l1.x; wl.w = l1.y;
         if (row >= T) { wh.x = wh.y = wh.z = wh.w = 0u; wl.x = wl.y = wl.z = wl.w = 0u; }
@@ -175,11 +183,11 @@ VC_KERNEL __launch_bounds__(128, 2) void attn_vit_fwd2_x3_kernel(AttnParams p) {
     vc_f32x16 o[2];
     am_zero1(o);
     ax_mm_tok1<false>(o, st, tiles[0], tiles[1], lane, 0u, 1.0f);        // O[query][d] = sum_key P[query][key] V[key][d]
-    ax_store_rows(reinterpret_cast<float*>(tiles[2]) + t * AX_STAGE_FLOATS, (float*)p.o + rowq * p.ldo + h * AM_D, p.ldo, o, t, T, lane, 1.0f);   // (K is dead since the second barrier)
+    ax_store_rows<PK>(reinterpret_cast<float*>(tiles[2]) + t * AX_STAGE_FLOATS, (float*)p.o + rowq * p.ldo + h * AM_D, p.ldo, o, t, T, lane, 1.0f);   // (K is dead since the second barrier)
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
-template <bool DROP>
+template <bool DROP, bool PK>
 VC_KERNEL __launch_bounds__(256, 2) void attn_vit_bwd4_x3_kernel(AttnParams p) {
     VC_DYN_SHARED(vc_bf16, tiles);                                            // Q, K, V, dO: hi and lo plane each (8 planes) + lse / D_i
     float* lse_s = reinterpret_cast<float*>(tiles + 8 * AX_TILE);
@@ -190,10 +198,10 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_vit_bwd4_x3_kernel(AttnParams p) {
     const long rowq = n * T;
     vc_bf16 *Qh = tiles, *Ql = tiles + AX_TILE, *Kh = tiles + 2 * AX_TILE, *Kl = tiles + 3 * AX_TILE;
     vc_bf16 *Vh = tiles + 4 * AX_TILE, *Vl = tiles + 5 * AX_TILE, *Oh = tiles + 6 * AX_TILE, *Ol = tiles + 7 * AX_TILE;
-    ax_stage_nt<256>(Qh, Ql, (const float*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
-    ax_stage_nt<256>(Kh, Kl, (const float*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
-    ax_stage_nt<256>(Vh, Vl, (const float*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, tid);
-    ax_stage_nt<256>(Oh, Ol, (const float*)p.dout + rowq * p.lddo + h * AM_D, p.lddo, T, tid);
+    ax_stage_nt<256, PK>(Qh, Ql, (const float*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
+    ax_stage_nt<256, PK>(Kh, Kl, (const float*)p.k + rowq * p.ldk + h * AM_D, p.ldk, T, tid);
+    ax_stage_nt<256, PK>(Vh, Vl, (const float*)p.v + rowq * p.ldv + h * AM_D, p.ldv, T, tid);
+    ax_stage_nt<256, PK>(Oh, Ol, (const float*)p.dout + rowq * p.lddo + h * AM_D, p.lddo, T, tid);
     if (tid < AM_T) lse_s[tid] = (tid < T) ? p.lse[(n * p.H + h) * T + tid] : 0.f;
     vc_sync();
     const uint32_t dbase0 = (uint32_t)((n * p.H + h) * T) * (uint32_t)T;
@@ -229,7 +237,7 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_vit_bwd4_x3_kernel(AttnParams p) {
         vc_f32x16 dq[2];
         am_zero1(dq);
         ax_mm_tok1<false>(dq, st, Kh, Kl, lane, 0u, 1.0f);              // dQ[query][d] = sum_key dS[query][key] K[key][d]
-        ax_store_rows(reinterpret_cast<float*>(Vh) + t * AX_STAGE_FLOATS, (float*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, t, T, lane, p.scale);
+        ax_store_rows<PK>(reinterpret_cast<float*>(Vh) + t * AX_STAGE_FLOATS, (float*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, t, T, lane, p.scale);
     } else {           // ---------------- lane = key of tile t:  dV, dK
         uint32_t keep = 0;
         if (DROP) keep = am_keep_bits1<false>(p.drop, dbase0, T, t, lane);
@@ -252,7 +260,7 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_vit_bwd4_x3_kernel(AttnParams p) {
         ax_mm_nt1(dp, Oh, Ol, Vh, Vl, t, lane);      // dP'[query][key]
         vc_sync();                           // D_i from the query waves; nobody reads V / dO any more: dO's planes become the store staging
         float* stage = reinterpret_cast<float*>(Oh) + t * AX_STAGE_FLOATS;
-        ax_store_rows(stage, (float*)p.dv + rowq * p.lddv + h * AM_D, p.lddv, dv, t, T, lane, 1.0f);
+        ax_store_rows<PK>(stage, (float*)p.dv + rowq * p.lddv + h * AM_D, p.lddv, dv, t, T, lane, 1.0f);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -264,7 +272,7 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_vit_bwd4_x3_kernel(AttnParams p) {
         vc_f32x16 dk[2];
         am_zero1(dk);
         ax_mm_tok1<false>(dk, dp, Qh, Ql, lane, 0u, 1.0f);              // dK[key][d] = sum_query dS[query][key] Q[query][d]
-        ax_store_rows(stage, (float*)p.dk + rowq * p.lddk + h * AM_D, p.lddk, dk, t, T, lane, p.scale);
+        ax_store_rows<PK>(stage, (float*)p.dk + rowq * p.lddk + h * AM_D, p.lddk, dk, t, T, lane, p.scale);
     }
 }
 constexpr size_t ax_bwd_lds_bytes() { return (size_t)8 * AX_TILE * 2 + 2 * AM_T * sizeof(float); }

@@ -74,6 +74,7 @@ int vcad_op_attention_fwd(int t, int D, const void* q, const void* k, const void
     p.q = q; p.k = k; p.v = v; p.o = o; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lse = lse;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.window = window; p.causal = causal; p.scale = scale;
     if (t == VC_X3) { p.x3 = 1; t = VC_F32; }          // fp32 tensors, bf16x3 arithmetic where a kernel has that form (attn_x3.h)
+    else if (t == VC_PK) { p.x3 = 2; t = VC_F32; }     // ... and every tensor as pre-split hi | lo words
     return vc_attn_fwd(t, D, p, (vc_stream_t)stream);
 }
 
@@ -86,6 +87,7 @@ int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void
     p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.window = window; p.causal = causal; p.scale = scale;
     if (t == VC_X3) { p.x3 = 1; t = VC_F32; }          // fp32 tensors, bf16x3 arithmetic where a kernel has that form (attn_x3.h)
+    else if (t == VC_PK) { p.x3 = 2; t = VC_F32; }     // ... and every tensor as pre-split hi | lo words
     return vc_attn_bwd(t, D, p, (vc_stream_t)stream);
 }
 
@@ -99,6 +101,7 @@ int vcad_op_attention_bwd_o(int t, int D, const void* q, const void* k, const vo
     p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk; p.window = window; p.causal = causal; p.scale = scale;
     if (t == VC_X3) { p.x3 = 1; t = VC_F32; }          // fp32 tensors, bf16x3 arithmetic where a kernel has that form (attn_x3.h)
+    else if (t == VC_PK) { p.x3 = 2; t = VC_F32; }     // ... and every tensor as pre-split hi | lo words
     return vc_attn_bwd(t, D, p, (vc_stream_t)stream);
 }
 

@@ -337,6 +337,11 @@ struct Ctx {
     float* Gf(long off) const { return e->G + off; }
     Mat A32(const float* p, long ld) const { return Mat{p, VC_F32, ld}; }
     Mat AT(const void* p, long ld) const { return Mat{p, e->dt, ld}; }
+    // bf16x3 mode (r04): tensors of the ViTs that only feed GEMMs / the x3 attention kernels are stored PRE-SPLIT (hi | lo words, VC_PK: same 4 bytes
+    // per element as fp32) by their producers, so the consuming GEMMs unpack their tiles instead of splitting them (needs the pre-split weight shadow)
+    bool pk_acts() const { return e->ct == VC_X3 && e->Spk != nullptr; }
+    int vt(bool pk) const { return pk ? VC_PK : e->dt; }
+    Mat VT(const void* p, long ld, bool pk) const { return Mat{p, vt(pk), ld}; }
 
     // dropout site ids: (module << 16) | (layer << 8) | kind; module 1 = frame ViT, 2 = CAD ViT, 3 = decoder
     enum { K_EMB = 1, K_ATTN = 2, K_OUT = 3, K_MLP_ACT = 4, K_MLP_OUT = 5, K_SA = 6, K_SA_OUT = 7, K_CA = 8, K_CA_OUT = 9, K_FF_ACT = 10, K_FF_OUT = 11 };
@@ -346,11 +351,11 @@ struct Ctx {
         return d;
     }
     // masked copy of a residual-stream gradient: du = dx * mask (type T, compact [rows, cols]); returns the matrix to feed wgrad / dgrad
-    int masked(const float* dx, long ldx, long rows, int cols, vc_drop d, Mat* out, void* dst = nullptr) const {
-        if (!d.key) { *out = A32(dx, ldx); return 0; }
+    int masked(const float* dx, long ldx, long rows, int cols, vc_drop d, Mat* out, void* dst = nullptr, bool pk = false) const {
+        if (!d.key && !pk) { *out = A32(dx, ldx); return 0; }
         if (!dst) dst = L().t_dum;
-        *out = AT(dst, cols);
-        return vc_dropout_mul(e->dt, dx, ldx, dst, cols, rows, cols, d, s);
+        *out = VT(dst, cols, pk);                     // (pk: the pre-split copy is made even without a mask — it is what the consuming GEMMs take)
+        return vc_dropout_mul(vt(pk), dx, ldx, dst, cols, rows, cols, d, s);
     }
     int gemm(Mat A, int tra, Mat B, int trb, Mat C, int M, int N, int K, const Epi& ep, int role = 0) const {
         GemmCall c; memset(&c, 0, sizeof(c));
@@ -408,28 +413,29 @@ struct Ctx {
         if (need > L().scr_colsum_bytes) { vc_set_error("colsum scratch too small (%zu)", need); return VC_ERR_WORKSPACE; }
         return vc_colsum(X.dt, X.p, X.ld, rows, cols, out, accumulate, batch, bsx, bso, L().scr_colsum, s);
     }
-    int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C) const {
+    int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C, bool pk = false) const {
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = x; p.ldx = ldx; p.gamma = Pf(wo); p.beta = Pf(bo); p.y32 = y32; p.ldy32 = ldy32; p.yt = yt; p.ldyt = ldyt;
         p.stats = stats; p.rows = rows; p.eps = 1e-5f;
-        return vc_ln_fwd(tx, e->dt, C, 0, p, s);
+        return vc_ln_fwd(tx, vt(pk), C, 0, p, s);
     }
     // dx32 (+T copy) = add_in + LNbwd(dy);  dgamma/dbeta written to the grad buffer
     // `du` (optional): also emit the masked copy du = T(dx * mask(site d)) that masked() would produce from dx32 in a second pass
     int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
                const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C,
-               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr, float* defer_partial = nullptr) const {
+               vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr, float* defer_partial = nullptr,
+               bool du_pk = false) const {
         LnBwdParams p; memset(&p, 0, sizeof(p));
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
         if (du) {
-            if (d.key) { void* dst = du_dst ? du_dst : L().t_dum; p.dxt = dst; p.lddxt = C; p.drop = d; *du = AT(dst, C); }
+            if (d.key || du_pk) { void* dst = du_dst ? du_dst : L().t_dum; p.dxt = dst; p.lddxt = C; p.drop = d; *du = VT(dst, C, du_pk); }   // (du_pk: pre-split copy even without a mask)
             else *du = A32(dx32, lddx);
         }
         // du_colsum: the bias gradient of the Linear that consumes du, reduced by this kernel instead of a column-sum pass over du
         // defer_partial: the dgamma / dbeta partial rows are left in that buffer (the caller reduces them later, in a grouped column sum)
-        if (defer_partial) return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, defer_partial, nullptr, nullptr, L().scr_colsum, s, nullptr);
-        return vc_ln_bwd(td, VC_F32, e->dt, C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s, du ? du_colsum : nullptr);
+        if (defer_partial) return vc_ln_bwd(td, VC_F32, vt(du_pk), C, 0, p, defer_partial, nullptr, nullptr, L().scr_colsum, s, nullptr);
+        return vc_ln_bwd(td, VC_F32, vt(du_pk), C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s, du ? du_colsum : nullptr);
     }
 };
 
@@ -468,34 +474,35 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
         // Only the cls token of the LAST layer is consumed (pool='cls'): its Q projection, attention output, out-proj and
         // MLP are computed for the cls row only; K/V still need every token.  Same numbers, ~60 % less work in that layer.
         const bool cls_only = (L == c.vit_depth - 1);
+        const bool pk = cx.pk_acts() && !cls_only;          // bf16x3: this layer's GEMM-only tensors (h_a, qkv, ao, h_f, z, g) are stored pre-split
         const float scale = 1.0f / sqrtf((float)c.vit_dim_head);
         const char* q = (const char*)l.qkv;
-        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D));
+        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D, pk));
         AttnParams ap; memset(&ap, 0, sizeof(ap));
         ap.q = q; ap.k = q + (size_t)inner * e->esz; ap.v = q + (size_t)2 * inner * e->esz; ap.o = l.ao;
         ap.ldq = ap.ldk = ap.ldv = 3 * inner; ap.ldo = inner; ap.lse = l.lse;
         ap.B = (int)N; ap.H = c.vit_heads; ap.Tq = ap.Tk = P + 1; ap.window = P + 1; ap.causal = 0; ap.scale = scale;
-        ap.drop = cx.site(v + 1, L, Ctx::K_ATTN); ap.x3 = e->ct == VC_X3;
+        ap.drop = cx.site(v + 1, L, Ctx::K_ATTN); ap.x3 = pk ? 2 : (e->ct == VC_X3 ? 1 : 0);
         const vc_drop d_out = cx.site(v + 1, L, Ctx::K_OUT), d_act = cx.site(v + 1, L, Ctx::K_MLP_ACT), d_mlp = cx.site(v + 1, L, Ctx::K_MLP_OUT);
         if (!cls_only) {
             const bool q8 = e->fp8 && e->dt == VC_BF16;       // VCAD_FP8: these four Linears on the block-scaled fp8 matrix cores
             if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_a, D), wl.qkv, cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
-            else CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
+            else CK(cx.lin_fwd(cx.VT(l.h_a, D, pk), cx.W(wl.qkv, D), cx.VT(l.qkv, 3 * inner, pk), (int)R, 3 * inner, D, Epi()));
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
             { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; ep.drop = d_out;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.ao, inner), wl.ow, cx.A32(l.xm, D), (int)R, D, inner, ep));
-              else CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
-            CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D));
+              else CK(cx.lin_fwd(cx.VT(l.ao, inner, pk), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
+            CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D, pk));
             if (!q8 && e->dt == VC_BF16 && g_split_gelu) {     // bf16: plain GEMM (persistent kernel) -> z, then the activation pass (norm.h: act_fwd_bf16_kernel)
                 { Epi ep; ep.bias = cx.Pf(wl.b1); CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.z, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
                 CK(vc_act_fwd_bf16(l.z, l.g, R, c.vit_mlp, VC_ACT_GELU, d_act, cx.s));
             } else {
               Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_f, D), wl.w1, cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep));
-              else CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
+              else CK(cx.lin_fwd(cx.VT(l.h_f, D, pk), cx.W(wl.w1, D), cx.VT(l.g, c.vit_mlp, pk), (int)R, c.vit_mlp, D, ep)); }     // (pk: the pre-activation side output z is pre-split too — it has the output's type)
             { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.g, c.vit_mlp), wl.w4, cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep));
-              else CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
+              else CK(cx.lin_fwd(cx.VT(l.g, c.vit_mlp, pk), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
         } else {
             CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv + (long)inner * D, D), cx.AT(q + (size_t)inner * e->esz, 3 * inner), (int)R, 2 * inner, D, Epi()));   // K, V: all tokens
             CK(cx.lin_fwd(cx.AT(l.h_a, TD), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * TI), (int)N, inner, D, Epi()));                                       // Q: cls rows
@@ -539,28 +546,29 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         const bool cls_only = (L == c.vit_depth - 1);          // see vit_forward: dx is non-zero on cls rows only here
         const long Rm = cls_only ? N : R;                       // rows the MLP / out-proj backward runs over
         const long ldx = cls_only ? TD : D, ldao = cls_only ? TI : inner;
+        const bool pk = cx.pk_acts() && !cls_only;              // bf16x3: this layer's saved tensors and GEMM-only gradients (du, dz, dao, dqkv) are pre-split (vit_forward)
         // MLP (x' = xm + drop(W4 drop(gelu(z)) + b4)): the gradient entering W4 is dx * mask_out
-        if (!have_du) CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du));     // else: emitted by the layer above's LayerNorm backward
+        if (!have_du) CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du, nullptr, pk));     // else: emitted by the layer above's LayerNorm backward
         const bool have_db4 = have_du;
         have_du = false;
-        CK(cx.lin_wgrad(du, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, have_db4 ? nullptr : cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));   // (b4's gradient: from the LayerNorm backward that emitted du)
+        CK(cx.lin_wgrad(du, cx.VT(l.g, c.vit_mlp, pk), cx.Gf(wl.w4), c.vit_mlp, have_db4 ? nullptr : cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));   // (b4's gradient: from the LayerNorm backward that emitted du)
         bool have_db1 = false;
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
           const bool split = e->dt == VC_BF16 && g_split_gelu && !cls_only;      // bf16: plain dgrad, then the activation-derivative pass
           const Epi epg = split ? Epi() : ep;
           if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
-          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
+          else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.VT(cx.L().t_dz, c.vit_mlp, pk), (int)Rm, D, c.vit_mlp, epg));
           // (the activation-derivative pass also reduces its output over rows: b1's gradient without a column-sum pass over dz)
           if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), cx.L().scr_lnpart, cx.L().scr_lnpart_bytes, cx.L().scr_colsum));
           have_db1 = split; }
-        CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, have_db1 ? nullptr : cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
+        CK(cx.lin_wgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.VT(l.h_f, D, pk), cx.Gf(wl.w1), D, have_db1 ? nullptr : cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
         if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
-        else CK(cx.lin_dgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
+        else CK(cx.lin_dgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         // attention block (xm = x + drop(Wo ao + bo)): the LayerNorm backward also emits du = dx * mask_out
-        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, nullptr, cx.Gf(wl.ob)));
-        CK(cx.lin_wgrad(du, cx.AT(l.ao, ldao), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, nullptr, cx.Gf(wl.ob), nullptr, pk));
+        CK(cx.lin_wgrad(du, cx.VT(l.ao, ldao, pk), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
         if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
-        else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
+        else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.VT(cx.L().t_dao, inner, pk), (int)Rm, D, inner, Epi()));
         {
             AttnParams p; memset(&p, 0, sizeof(p));
             const char* q = (const char*)l.qkv; char* dq = (char*)cx.L().t_dqkv;
@@ -569,17 +577,18 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             p.dout = cx.L().t_dao; p.lddo = inner; p.dq = dq; p.dk = dq + (size_t)inner * e->esz; p.dv = dq + (size_t)2 * inner * e->esz;
             p.lddq = p.lddk = p.lddv = 3 * inner;
             p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
-            p.drop = cx.site(v + 1, L, Ctx::K_ATTN); p.x3 = e->ct == VC_X3;
+            p.drop = cx.site(v + 1, L, Ctx::K_ATTN); p.x3 = pk ? 2 : (e->ct == VC_X3 ? 1 : 0);
             if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero
                 CK(vc_memset_async(cx.L().t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
                 p.Tq = 1; p.ldq = 3 * TI; p.lddq = 3 * TI;
             }
             CK(vc_attn_bwd(e->dt, c.vit_dim_head, p, cx.s));
         }
-        CK(cx.lin_wgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.AT(l.h_a, D), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
+        CK(cx.lin_wgrad(cx.VT(cx.L().t_dqkv, 3 * inner, pk), cx.VT(l.h_a, D, pk), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
         if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
-        else CK(cx.lin_dgrad(cx.AT(cx.L().t_dqkv, 3 * inner), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
-        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4))); have_du = true; }
+        else CK(cx.lin_dgrad(cx.VT(cx.L().t_dqkv, 3 * inner, pk), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
+        // (the layer below is never the cls-only one: the du it receives is pre-split whenever the mode stores pre-split tensors)
+        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), nullptr, cx.pk_acts())); have_du = true; }
         else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
     }
     if (part != 1) {

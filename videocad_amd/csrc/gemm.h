@@ -156,6 +156,11 @@ template <> VC_DEV void quad_ld<vc_bf16>(const vc_bf16* p, float* v) {
     const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p);
     v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u);
 }
+template <> VC_DEV void quad_ld<vc_pk>(const vc_pk* p, float* v) {          // hi + lo of each pre-split word
+    const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p);
+    v[0] = vc_bits_f32(q.x & 0xFFFF0000u) + vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.y & 0xFFFF0000u) + vc_bits_f32(q.y << 16);
+    v[2] = vc_bits_f32(q.z & 0xFFFF0000u) + vc_bits_f32(q.z << 16); v[3] = vc_bits_f32(q.w & 0xFFFF0000u) + vc_bits_f32(q.w << 16);
+}
 template <typename T> VC_DEV void quad_st(T* p, const float* v);
 template <> VC_DEV void quad_st<float>(float* p, const float* v) {
     vc_u32x4 q; q.x = vc_f32_bits(v[0]); q.y = vc_f32_bits(v[1]); q.z = vc_f32_bits(v[2]); q.w = vc_f32_bits(v[3]);
@@ -164,6 +169,13 @@ template <> VC_DEV void quad_st<float>(float* p, const float* v) {
 template <> VC_DEV void quad_st<vc_bf16>(vc_bf16* p, const float* v) {
     vc_u32x2 q; q.x = vc_pack_bf16x2(v[0], v[1]); q.y = vc_pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<vc_u32x2*>(p) = q;
+}
+// bf16x3 GEMM output consumed only by other bf16x3 GEMMs / attention kernels: written PRE-SPLIT (hi | lo words, vc_rt.h vc_pk_pack — exactly the
+// two values a consumer's staging split would produce), so the consumers unpack (4 byte-permutes per quad) instead of splitting (10 VALU per quad)
+// every time a tile of it is staged — N / BN times per element for an A operand (r04)
+template <> VC_DEV void quad_st<vc_pk>(vc_pk* p, const float* v) {
+    vc_u32x4 q; q.x = vc_pk_pack(v[0]); q.y = vc_pk_pack(v[1]); q.z = vc_pk_pack(v[2]); q.w = vc_pk_pack(v[3]);
+    *reinterpret_cast<vc_u32x4*>(p) = q;
 }
 
 // The fused epilogue on four consecutive columns n..n+3 of row m (16-byte / 8-byte accesses): alpha, bias, row-broadcast add,

@@ -16,6 +16,11 @@ template <> VC_DEV void quad_load<vc_bf16>(const vc_bf16* p, float* v) {
     const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p);
     v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u);
 }
+template <> VC_DEV void quad_load<vc_pk>(const vc_pk* p, float* v) {
+    const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p);
+    v[0] = vc_bits_f32(q.x & 0xFFFF0000u) + vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.y & 0xFFFF0000u) + vc_bits_f32(q.y << 16);
+    v[2] = vc_bits_f32(q.z & 0xFFFF0000u) + vc_bits_f32(q.z << 16); v[3] = vc_bits_f32(q.w & 0xFFFF0000u) + vc_bits_f32(q.w << 16);
+}
 template <typename T> VC_DEV void quad_store(T* p, const float* v);
 template <> VC_DEV void quad_store<float>(float* p, const float* v) {
     vc_u32x4 q; q.x = vc_f32_bits(v[0]); q.y = vc_f32_bits(v[1]); q.z = vc_f32_bits(v[2]); q.w = vc_f32_bits(v[3]);
@@ -24,6 +29,10 @@ template <> VC_DEV void quad_store<float>(float* p, const float* v) {
 template <> VC_DEV void quad_store<vc_bf16>(vc_bf16* p, const float* v) {
     vc_u32x2 q; q.x = vc_pack_bf16x2(v[0], v[1]); q.y = vc_pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<vc_u32x2*>(p) = q;
+}
+template <> VC_DEV void quad_store<vc_pk>(vc_pk* p, const float* v) {           // pre-split bf16x3 operand words (gemm.h): the GEMM that consumes the tensor unpacks
+    vc_u32x4 q; q.x = vc_pk_pack(v[0]); q.y = vc_pk_pack(v[1]); q.z = vc_pk_pack(v[2]); q.w = vc_pk_pack(v[3]);
+    *reinterpret_cast<vc_u32x4*>(p) = q;
 }
 template <typename T, int VPL>
 VC_DEV void row_load(const T* p, float (&v)[VPL], int lane) {

@@ -114,11 +114,13 @@ int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s) {
         VC_LAUNCH(attn_fwd_single_query_bf16_kernel, dim3((unsigned)VC_CEIL_DIV((long)p.B * p.H, 4)), dim3(256), 0, s, p);
         return VC_OK;
     }
-    if (x3_ok(t, D, p, false)) {                                   // bf16x3 mode: split operands on the bf16 matrix cores
-        if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_x3_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
-        else VC_LAUNCH((attn_vit_fwd2_x3_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
+    if (x3_ok(t, D, p, false)) {                                   // bf16x3 mode: split operands on the bf16 matrix cores (x3 == 2: pre-split tensors in and out)
+        const dim3 g((unsigned)((long)p.B * p.H));
+        if (p.x3 == 2) { if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_x3_kernel<true, true>), g, dim3(128), 0, s, p); else VC_LAUNCH((attn_vit_fwd2_x3_kernel<false, true>), g, dim3(128), 0, s, p); }
+        else           { if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_x3_kernel<true, false>), g, dim3(128), 0, s, p); else VC_LAUNCH((attn_vit_fwd2_x3_kernel<false, false>), g, dim3(128), 0, s, p); }
         return VC_OK;
     }
+    if (p.x3 == 2) { vc_set_error("attention: pre-split tensors (x3 = 2) have no kernel for this shape (D=%d Tq=%d Tk=%d causal=%d)", D, p.Tq, p.Tk, p.causal); return VC_ERR_UNSUPPORTED; }
     if (mfma_ok(t, D, p, false) && g_vit_bwd_variant == 0) {      // two waves per (frame, head)
         if (p.drop.key) VC_LAUNCH((attn_vit_fwd2_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
         else VC_LAUNCH((attn_vit_fwd2_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(128), 0, s, p);
@@ -194,14 +196,18 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     if (x3_ok(t, D, p, true)) {                                    // bf16x3 mode
         static unsigned attr = 0;
         if (!(attr & vc_device_bit())) {
-            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<true>, ax_bwd_lds_bytes())) return rc;
-            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<false>, ax_bwd_lds_bytes())) return rc;
+            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<true, false>, ax_bwd_lds_bytes())) return rc;
+            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<false, false>, ax_bwd_lds_bytes())) return rc;
+            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<true, true>, ax_bwd_lds_bytes())) return rc;
+            if (int rc = set_dyn_lds(attn_vit_bwd4_x3_kernel<false, true>, ax_bwd_lds_bytes())) return rc;
             attr |= vc_device_bit();
         }
-        if (p.drop.key) VC_LAUNCH((attn_vit_bwd4_x3_kernel<true>), dim3((unsigned)((long)p.B * p.H)), dim3(256), ax_bwd_lds_bytes(), s, p);
-        else VC_LAUNCH((attn_vit_bwd4_x3_kernel<false>), dim3((unsigned)((long)p.B * p.H)), dim3(256), ax_bwd_lds_bytes(), s, p);
+        const dim3 g((unsigned)((long)p.B * p.H));
+        if (p.x3 == 2) { if (p.drop.key) VC_LAUNCH((attn_vit_bwd4_x3_kernel<true, true>), g, dim3(256), ax_bwd_lds_bytes(), s, p); else VC_LAUNCH((attn_vit_bwd4_x3_kernel<false, true>), g, dim3(256), ax_bwd_lds_bytes(), s, p); }
+        else           { if (p.drop.key) VC_LAUNCH((attn_vit_bwd4_x3_kernel<true, false>), g, dim3(256), ax_bwd_lds_bytes(), s, p); else VC_LAUNCH((attn_vit_bwd4_x3_kernel<false, false>), g, dim3(256), ax_bwd_lds_bytes(), s, p); }
         return VC_OK;
     }
+    if (p.x3 == 2) { vc_set_error("attention backward: pre-split tensors (x3 = 2) have no kernel for this shape (D=%d Tq=%d Tk=%d causal=%d)", D, p.Tq, p.Tk, p.causal); return VC_ERR_UNSUPPORTED; }
     if (mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {       // four waves per (frame, head)
         if (p.drop.key) VC_LAUNCH(attn_vit_bwd4_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);
         else VC_LAUNCH(attn_vit_bwd4_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);

@@ -65,8 +65,9 @@ static size_t dsize(int t) { return t == VC_BF16 ? 2 : 4; }
 int vc_gemm_prepare(GemmCall& c) {
     GemmParams& p = c.p;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) { vc_set_error("vc_gemm: empty problem %d %d %d", p.M, p.N, p.K); return VC_ERR_ARG; }
-    if (c.sb == VC_PK && c.ct != VC_X3) { vc_set_error("vc_gemm: pre-split operands feed the bf16x3 GEMM only"); return VC_ERR_UNSUPPORTED; }
-    if ((c.ct == VC_F32 || c.ct == VC_X3) && (c.sa != VC_F32 || (c.sb != VC_F32 && c.sb != VC_PK) || c.to != VC_F32)) { vc_set_error("vc_gemm: f32 / bf16x3 compute needs f32 operands"); return VC_ERR_UNSUPPORTED; }
+    if ((c.sa == VC_PK || c.sb == VC_PK || c.to == VC_PK) && c.ct != VC_X3) { vc_set_error("vc_gemm: pre-split operands / outputs belong to the bf16x3 GEMM only"); return VC_ERR_UNSUPPORTED; }
+    { auto f32ish = [](int t) { return t == VC_F32 || t == VC_PK; };
+      if ((c.ct == VC_F32 || c.ct == VC_X3) && !(f32ish(c.sa) && f32ish(c.sb) && f32ish(c.to))) { vc_set_error("vc_gemm: f32 / bf16x3 compute needs f32 (or pre-split) operands"); return VC_ERR_UNSUPPORTED; } }
     p.debug_skip = VC_AB(skip, 0);
     if (c.ct == VC_BF16) {          // bf16 mode: cheap erf (gemm.h) in both GEMM kernels, so results do not depend on the kernel choice
         if (p.act == VC_ACT_GELU) p.act = VC_ACT_GELU_FAST;

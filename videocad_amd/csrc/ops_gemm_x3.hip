@@ -1,7 +1,12 @@
-// ops_gemm_x3.hip — bf16x3 (VCAD_BF16X3: fp32 tensors, hi/lo-split bf16 MFMAs) instantiations of the register-staged GEMM
+// ops_gemm_x3.hip — bf16x3 (VCAD_BF16X3: fp32 tensors, hi/lo-split bf16 MFMAs) instantiations of the register-staged GEMM: fp32 activations
+// (split while staging) against fp32 or pre-split weights.  The all-pre-split forms live in ops_gemm_x3b.hip (own translation unit: they compile in parallel).
 #include "gemm_launch.h"
 
+int vc_gemm_launch_x3_pk(GemmCall c, int nsplit, int lay, vc_stream_t s);      // sa == VC_PK (ops_gemm_x3b.hip)
+
 int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s) {
+    if (c.sa == VC_PK) return vc_gemm_launch_x3_pk(c, nsplit, lay, s);
+    if (c.to != VC_F32) { vc_set_error("vc_gemm: bf16x3 with fp32 activations writes fp32"); return VC_ERR_UNSUPPORTED; }
     if (c.sb == VC_PK) {          // pre-split weights (forward / dgrad layouts)
         if (lay == 0) return gemm_launch<vc_x3, float, vc_pk, float, false, false>(c, nsplit, s);
         if (lay == 1) return gemm_launch<vc_x3, float, vc_pk, float, false, true>(c, nsplit, s);

@@ -22,6 +22,7 @@ int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s) {
     if (tx == VC_F32 && ty == VC_F32) return ln_fwd_m<float, float>(C, mode, p, s);
     if (tx == VC_F32 && ty == VC_BF16) return ln_fwd_m<float, vc_bf16>(C, mode, p, s);
     if (tx == VC_BF16 && ty == VC_BF16) return ln_fwd_m<vc_bf16, vc_bf16>(C, mode, p, s);
+    if (tx == VC_F32 && ty == VC_PK) return ln_fwd_m<float, vc_pk>(C, mode, p, s);          // bf16x3 mode: the typed output is a GEMM operand, written pre-split
     vc_set_error("ln_fwd: dtype combo %d %d", tx, ty); return VC_ERR_UNSUPPORTED;
 }
 
@@ -53,6 +54,7 @@ int vc_ln_bwd(int td, int tx, int ty, int C, int mode, LnBwdParams p, float* par
     if (td == VC_F32 && tx == VC_F32 && ty == VC_F32) rc = ln_bwd_m<float, float, float>(C, mode, p, nblk, s);
     else if (td == VC_BF16 && tx == VC_F32 && ty == VC_BF16) rc = ln_bwd_m<vc_bf16, float, vc_bf16>(C, mode, p, nblk, s);
     else if (td == VC_F32 && tx == VC_F32 && ty == VC_BF16) rc = ln_bwd_m<float, float, vc_bf16>(C, mode, p, nblk, s);
+    else if (td == VC_F32 && tx == VC_F32 && ty == VC_PK) rc = ln_bwd_m<float, float, vc_pk>(C, mode, p, nblk, s);
     else { vc_set_error("ln_bwd: dtype combo %d %d %d", td, tx, ty); return VC_ERR_UNSUPPORTED; }
     if (rc) return rc;
     if (partial_ws && dgamma) {        // partial is [nblk][2][C]: column-sum it into dgamma (first C) / dbeta (next C); dgamma == null: the caller reduces the rows later
@@ -91,6 +93,7 @@ int vc_colsum(int tx, const void* x, long ld, long rows, int cols, float* out, i
         p.out = dst; p.ld_out_rows = last ? 0 : cols; p.batch_stride_out = last ? bstride_out : nblk * cols; p.accumulate = last ? accumulate : 0;
         dim3 g(VC_CEIL_DIV(cols, 64), (unsigned)nblk, batch);
         if (cur_t == VC_F32) VC_LAUNCH((colsum_pass_kernel<float>), g, dim3(256), 0, s, p);
+        else if (cur_t == VC_PK) VC_LAUNCH((colsum_pass_kernel<vc_pk>), g, dim3(256), 0, s, p);          // pre-split words: hi + lo
         else VC_LAUNCH((colsum_pass_kernel<vc_bf16>), g, dim3(256), 0, s, p);
         if (last) break;
         cur = dst; cur_ld = cols; cur_rows = nblk; cur_bs = nblk * cols; cur_t = VC_F32; useA = !useA;
@@ -104,6 +107,7 @@ int vc_dropout_mul(int ty, const float* in, long ld_in, void* out, long ld_out, 
     ProfScope ps(VC_CAT_OTHER, 0, (double)rows * cols * (4 + (ty == VC_BF16 ? 2 : 4)), s);
     dim3 g((unsigned)VC_CEIL_DIV(rows * cols / 4, 256));
     if (ty == VC_BF16) VC_LAUNCH((dropout_mul_kernel<vc_bf16>), g, dim3(256), 0, s, in, ld_in, (vc_bf16*)out, ld_out, rows, cols, d);
+    else if (ty == VC_PK) VC_LAUNCH((dropout_mul_kernel<vc_pk>), g, dim3(256), 0, s, in, ld_in, (vc_pk*)out, ld_out, rows, cols, d);
     else VC_LAUNCH((dropout_mul_kernel<float>), g, dim3(256), 0, s, in, ld_in, (float*)out, ld_out, rows, cols, d);
     return VC_OK;
 }

@@ -271,6 +271,8 @@ template <> struct vc_cvt<vc_bf16> {
     VC_HD static float to_f32(vc_bf16 v) { return vc_bf16_to_f32(v); }
     VC_HD static vc_bf16 from_f32(float v) { return vc_f32_to_bf16(v); }
 };
+VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 // pre-split bf16x3 operand word (gemm.h): hi bf16 in the upper half, lo = bf16(x - hi) in the lower
 struct vc_pk { uint32_t w; };
 VC_HD uint32_t vc_pk_pack(float x) {
@@ -278,6 +280,11 @@ VC_HD uint32_t vc_pk_pack(float x) {
     const vc_bf16 l = vc_f32_to_bf16(x - vc_bf16_to_f32(h));
     return ((uint32_t)h.bits << 16) | (uint32_t)l.bits;
 }
+// (as a storage type: reads give hi + lo — the 16-bit-mantissa value the bf16x3 products see — writes split)
+template <> struct vc_cvt<vc_pk> {
+    VC_HD static float to_f32(vc_pk v) { return vc_bits_f32(v.w & 0xFFFF0000u) + vc_bits_f32(v.w << 16); }
+    VC_HD static vc_pk from_f32(float v) { vc_pk r; r.w = vc_pk_pack(v); return r; }
+};
 template <typename T> VC_HD float vc_ld(const T* p) { return vc_cvt<T>::to_f32(*p); }
 template <typename T> VC_HD void vc_st(T* p, float v) { *p = vc_cvt<T>::from_f32(v); }
 
@@ -293,8 +300,6 @@ VC_DEV float vc_wave_max(float v) {
 struct alignas(16) vc_u32x4 { uint32_t x, y, z, w; };   // 16-byte POD for vector copies
 struct alignas(8) vc_u32x2 { uint32_t x, y; };
 VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
-VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
-VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
 // ---- OCP fp8 e4m3 (no infinities, NaN = 0x7f / 0xff, max 448) — software codec for the emulator build and the host
 VC_HD float vc_e4m3_to_f32(uint8_t v) {
