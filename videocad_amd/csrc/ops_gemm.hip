@@ -69,7 +69,10 @@ int vc_gemm_prepare(GemmCall& c) {
     { auto f32ish = [](int t) { return t == VC_F32 || t == VC_PK; };
       if ((c.ct == VC_F32 || c.ct == VC_X3) && !(f32ish(c.sa) && f32ish(c.sb) && f32ish(c.to))) { vc_set_error("vc_gemm: f32 / bf16x3 compute needs f32 (or pre-split) operands"); return VC_ERR_UNSUPPORTED; } }
     p.debug_skip = VC_AB(skip, 0);
-    if (c.ct == VC_BF16) {          // bf16 mode: cheap erf (gemm.h) in both GEMM kernels, so results do not depend on the kernel choice
+    // bf16 mode: cheap erf (gemm.h) in both GEMM kernels, so results do not depend on the kernel choice.  bf16x3 (r04): the same — its absolute error
+    // (<= 1.5e-7) sits a decade under the mode's own ~5e-6 per GEMM, and libm's erff made the two GELU epilogues of a ViT layer the slowest
+    // launches per FLOP of the mode (302 / 357 us for 54 GFLOP, profiles/r04_x3_kernel_shapes.txt).  The exact-fp32 parity mode keeps erff.
+    if (c.ct == VC_BF16 || c.ct == VC_X3) {
         if (p.act == VC_ACT_GELU) p.act = VC_ACT_GELU_FAST;
         if (p.dact_kind == VC_ACT_GELU) p.dact_kind = VC_ACT_GELU_FAST;
     }
@@ -169,10 +172,21 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     long tiles = (long)VC_CEIL_DIV(p.M, BT) * VC_CEIL_DIV(p.N, BT);
     int nsplit = 1;
     if (scratch && tiles < 256 && p.K >= 8 * BK) {
-        nsplit = (int)VC_CEIL_DIV(512, tiles);
-        int maxs = p.K / (4 * BK); if (nsplit > maxs) nsplit = maxs;
-        size_t per = (size_t)p.M * p.N * sizeof(float);
-        if ((size_t)nsplit * per > scratch_bytes) nsplit = (int)(scratch_bytes / per);
+        // k-slices: two workgroups are co-resident per CU (512 slots).  r01-r03 took ceil(512 / tiles) slices — for 96 tiles (the ViT's QKV weight
+        // gradient in the fp32 / bf16x3 modes) that is 6 slices = 576 workgroups: a full round plus a 64-workgroup tail, i.e. two rounds of K / 6 each
+        // (1 373 us per call in the bf16x3 mode, profiles/r04_x3_kernel_shapes.txt).  Now: the slice count that minimises rounds x slice length.
+        const int maxs0 = p.K / (4 * BK);
+        const size_t per = (size_t)p.M * p.N * sizeof(float);
+        int maxs = maxs0 < 64 ? maxs0 : 64;
+        if ((size_t)maxs * per > scratch_bytes) maxs = (int)(scratch_bytes / per);
+        // cost in units of "one workgroup walking the whole K": rounds(ns) / ns for the k-loop + ns slab round trips (write + read of the fp32 tile
+        // grid at ~5 TB/s against ~0.3 us per k-tile of a workgroup)
+        const double t_full = (double)(p.K / BK) * 0.3, slab = (double)p.M * p.N * 8.0 / 5.0e6 / (t_full > 1e-9 ? t_full : 1e-9);
+        double best = 1e30;
+        for (int ns = 1; ns <= maxs; ++ns) {
+            const double cost = (double)VC_CEIL_DIV(tiles * ns, 512) / ns + slab * ns;
+            if (cost < best - 1e-12) { best = cost; nsplit = ns; }
+        }
         if (nsplit < 1) nsplit = 1;
     }
     int kps = VC_CEIL_DIV(p.K, nsplit); kps = VC_CEIL_DIV(kps, BK) * BK;
