@@ -1,7 +1,9 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for one round on the GPU box.  Usage: tools/collect_profiles.sh <tag>   (writes gpurun_out/<tag>/)
+# Collect the rocprofv3 evidence for one round on the GPU box.  Usage: VCAD_COMMIT=<sha> tools/collect_profiles.sh <tag>   (writes gpurun_out/<tag>/)
 # 1) kernel trace + stats of the DEFAULT bench command; 2) separate PMC passes (HBM read / write bytes; matrix-core busy cycles IN THE
-# MODEL) of a short bench run.  Every pass runs under its own `timeout`: a counter set the tool rejects aborts that pass, not the call.
+# MODEL) of a short bench run; 3) kernel-trace stats of the two other quoted shapes / modes (seq_len 186 at 16 clips; bf16x3 at C2).
+# Every pass runs under its own `timeout`: a counter set the tool rejects aborts that pass, not the call.  PMC passes never carry trace
+# domains other than --kernel-trace.
 TAG=${1:-r01}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
@@ -16,6 +18,11 @@ done
 # matrix-core occupancy per kernel inside the train step (r02 had it for isolated launches only): SQ_VALU_MFMA_BUSY_CYCLES against the
 # kernel's own GRBM_GUI_ACTIVE (summed over the 8 XCDs) x 256 CUs x 4 SIMDs / 8
 timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_MFMA -o pmc -- python $R/bench.py --steps 1 --warmup 1 --profile-only > $OUT/pmc_MFMA.json 2> $OUT/pmc_MFMA.err
+# the other quoted shapes / modes: per-kernel stats only
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_t186 -o t186 -- python $R/bench.py --profile-only --batch 16 --seq 186 --steps 6 --warmup 2 > $OUT/bench_t186.json 2> $OUT/bench_t186.err
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x3 -o x3 -- python $R/bench.py --profile-only --dtype bf16x3 --steps 3 --warmup 1 > $OUT/bench_x3.json 2> $OUT/bench_x3.err
 cd $R
 python tools/summarize_profiles.py $TAG > $OUT/summary.md 2> $OUT/summary.err
+python tools/kernel_stats_table.py $OUT/trace_t186/t186_kernel_stats.csv "seq_len 186, 16 clips (BASELINE configs[3] per-GPU shape), bf16" > $OUT/t186_kernel_stats.txt 2>> $OUT/summary.err
+python tools/kernel_stats_table.py $OUT/trace_x3/x3_kernel_stats.csv "C2 (32 clips x 64 steps), bf16x3" > $OUT/x3_kernel_stats.txt 2>> $OUT/summary.err
 tail -1 $OUT/bench_default.json | cut -c1-400

@@ -53,7 +53,7 @@ def run(name):
     for vn, v in res.items():
         ts = sorted(t for t, _ in v[1:])
         med = ts[len(ts) // 2]
-        print(f"  {vn:11s} {v[0][1]:8s} {med:8.1f} us   {gf / med * 1e3 / 1e3 if med == med else 0:7.1f} TF/s")
+        print(f"  {vn:11s} {v[0][1]:8s} {med:8.1f} us   {gf / med * 1e3 if med == med else 0:7.1f} TF/s")
 
 
 for n in (sys.argv[1:] or SHAPES):

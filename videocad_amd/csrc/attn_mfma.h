@@ -648,7 +648,9 @@ VC_KERNEL __launch_bounds__(128, ATTN_BWD_DROP_WAVES) void attn_vit_bwd_mfma_ker
 // chunks that are re-staged through the same small LDS tiles: the score grids accumulate over the chunks, the outputs are
 // produced one chunk at a time from the probability / dS grids that stay in registers.  The mask is the reference's
 // (causal + window band, model/autoregressive_transformer.py:180-188): key j visible to query i iff i - window < j <= i.
-// The wave-per-row kernels in attn.h remain the path for T > 64 and for fp32 mode.
+// The wave-per-row kernels in attn.h remain the path for fp32 mode beyond 64 steps.  Softmax exponentials are v_exp_f32 (vc_expf_fast, r04; r01-r03: libm
+// expf, ~20 instructions each — 64 per lane and block pair): exp(0) = 1 exactly either way, which is all the single-visible-key rule needs, and
+// the forward's lse and the backward's recompute use the same function.
 // ====================================================================================================================
 VC_DEV bool am_visible(int query, int key, int T, int window) { return key < T && key <= query && key > query - window; }
 
@@ -691,7 +693,7 @@ VC_KERNEL __launch_bounds__(64) void attn_dec_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
+            for (int r = 0; r < 16; ++r) { const float e = vc_expf_fast(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
         l += vc_shfl_xor(l, 32);
         const float inv = 1.0f / l;
 #pragma unroll
@@ -760,7 +762,7 @@ VC_KERNEL __launch_bounds__(64 * NCH) void attn_dec_fwd_cw_kernel(AttnParams p) 
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
+            for (int r = 0; r < 16; ++r) { const float e = vc_expf_fast(st[kt][qt][r] - m); st[kt][qt][r] = e; l += e; }
         l += vc_shfl_xor(l, 32);
         const float inv = 1.0f / l;
 #pragma unroll
@@ -823,7 +825,7 @@ VC_KERNEL __launch_bounds__(128, 1) void attn_dec_bwd_mfma_kernel(AttnParams p) 
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 32 + am_row(r, lane);
                     const bool ok = query < T && am_visible(query, key, T, p.window);
-                    const float pr = ok ? expf(sg[kt][qt][r] * p.scale - lse) : 0.f;
+                    const float pr = ok ? vc_expf_fast(sg[kt][qt][r] * p.scale - lse) : 0.f;
                     if (DROP) dg[kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);                    // dP = dP' * mask
                     sg[kt][qt][r] = pr; dsum += pr * dg[kt][qt][r];
                 }
@@ -844,7 +846,7 @@ VC_KERNEL __launch_bounds__(128, 1) void attn_dec_bwd_mfma_kernel(AttnParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int query = qt * 32 + am_row(r, lane);
-                    sg[qt][kt][r] = (query < T && am_visible(query, key, T, p.window)) ? expf(sg[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
+                    sg[qt][kt][r] = (query < T && am_visible(query, key, T, p.window)) ? vc_expf_fast(sg[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
                 }
         }
     }
@@ -964,7 +966,7 @@ VC_KERNEL __launch_bounds__(256, 1) void attn_dec_bwd_cw_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 32 + am_row(r, lane);
                     const bool ok = query < T && am_visible(query, key, T, p.window);
-                    const float pr = ok ? expf(sg[kt][qt][r] * p.scale - lse) : 0.f;
+                    const float pr = ok ? vc_expf_fast(sg[kt][qt][r] * p.scale - lse) : 0.f;
                     if (DROP) dg[kt][qt][r] *= am_keep(keep, kt, qt, r, p.drop.scale);                    // dP = dP' * mask
                     sg[kt][qt][r] = pr; dsum += pr * dg[kt][qt][r];
                 }
@@ -985,7 +987,7 @@ VC_KERNEL __launch_bounds__(256, 1) void attn_dec_bwd_cw_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int query = qt * 32 + am_row(r, lane);
-                    sg[qt][kt][r] = (query < T && am_visible(query, key, T, p.window)) ? expf(sg[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
+                    sg[qt][kt][r] = (query < T && am_visible(query, key, T, p.window)) ? vc_expf_fast(sg[qt][kt][r] * p.scale - lse_s[query]) : 0.f;   // P
                 }
         }
     }
@@ -1124,12 +1126,12 @@ VC_KERNEL __launch_bounds__(64 * NCH, 1) void attn_dec_fwd_blk_kernel(AttnParams
             m = fmaxf(m, vc_shfl_xor(m, 32));
             const float m_new = fmaxf(m_run[qt], m);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;             // a query that sees no key of the blocks so far: everything stays 0
-            const float alpha = expf(m_run[qt] - m_use);
+            const float alpha = vc_expf_fast(m_run[qt] - m_use);
             float l = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float e = expf(st[kt][qt][r] - m_use); st[kt][qt][r] = e; l += e; }
+                for (int r = 0; r < 16; ++r) { const float e = vc_expf_fast(st[kt][qt][r] - m_use); st[kt][qt][r] = e; l += e; }
             l += vc_shfl_xor(l, 32);
             l_run[qt] = l_run[qt] * alpha + l; m_run[qt] = m_new;
 #pragma unroll
@@ -1199,7 +1201,7 @@ VC_KERNEL __launch_bounds__(64 * NCH, 1) void attn_dec_bwd_q_blk_kernel(AttnPara
                     for (int r = 0; r < 16; ++r) {
                         const int key = k0 + kt * 32 + am_row(r, lane);
                         const bool ok = qok && am_visible(q0 + ql, key, T, p.window);
-                        const float pr = ok ? expf(sg[kt][qt][r] * p.scale - ls[qt]) : 0.f;
+                        const float pr = ok ? vc_expf_fast(sg[kt][qt][r] * p.scale - ls[qt]) : 0.f;
                         const float dpm = dg[kt][qt][r] * (DROP ? am_keep(keep, kt, qt, r, p.drop.scale) : 1.0f);      // dP = dP' * mask
                         if (pass == 0) dsum[qt] += pr * dpm;
                         else sg[kt][qt][r] = pr * (dpm - dsum[qt]);                                                       // dS^T (scale folded into the store)
@@ -1274,7 +1276,7 @@ VC_KERNEL __launch_bounds__(64 * NCH, 1) void attn_dec_bwd_kv_blk_kernel(AttnPar
                 for (int r = 0; r < 16; ++r) {
                     const int ql = qt * 32 + am_row(r, lane);
                     const bool ok = ql < tq && am_visible(q0 + ql, key, T, p.window);
-                    const float pr = ok ? expf(sg[qt][r] * p.scale - lse_s[ql]) : 0.f;
+                    const float pr = ok ? vc_expf_fast(sg[qt][r] * p.scale - lse_s[ql]) : 0.f;
                     const float ms = DROP ? am_keep(keep, qt, kt, r, p.drop.scale) : 1.0f;
                     dg[qt][r] = pr * (dg[qt][r] * ms - del_s[ql]);                                                        // dS
                     sg[qt][r] = pr;                                                                                       // P (the mask is applied while packing)
