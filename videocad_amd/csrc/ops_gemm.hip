@@ -167,16 +167,10 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     long tiles128 = (long)VC_CEIL_DIV(p.M, 128) * VC_CEIL_DIV(p.N, 128);
     // (not for the long token reductions of wgrad: halving the tile doubles operand traffic per FLOP there; those split K instead)
     // (wgrad layout: up to 512 tiles — the heads' 6000x1024 gradient over 2 080 tokens runs 256 -> 153 us on the small tile)
-    bool small = g_force_tile ? (g_force_tile == 64) : (tiles128 < (lay == 3 ? 512 : 256) && p.K <= 4096);
-    if (!g_force_tile && small && lay != 3) {
-        // ... unless the small tile's grid spills into a mostly empty extra round: two workgroups are co-resident per CU (512 slots) and a launch
-        // this small costs about one dependent latency chain per round.  At the maximum horizon (B = 16, T = 186: 2 976 rows) the decoder's
-        // 1024-wide Linears are 752 small tiles = two rounds (71 us per fp32-output dgrad in the model against 22 us for the 512 tiles of 2 048 rows,
-        // profiles/r04_t186_kernel_stats.txt); 192 big tiles are one round of ~1.6x the per-tile time (tools/shape_ab.py: 25 vs 16-18 us at 2 048 rows).
-        const long tiles64 = (long)VC_CEIL_DIV(p.M, 64) * VC_CEIL_DIV(p.N, 64);
-        const double cost64 = (double)VC_CEIL_DIV(tiles64, 512), cost128 = 1.6 * (double)VC_CEIL_DIV(tiles128, 512);
-        if (cost128 < cost64) small = false;
-    }
+    // (r04, measured and not kept: taking the big tile whenever the small tile's grid spills into a second, mostly empty round of the 512 co-resident
+    // slots — 752 small tiles for the decoder's 1024-wide Linears at 2 976 rows — made the T = 186 step slower: dgrad family 9.46 -> 10.10 ms,
+    // profiles/r04_tile_rounds_ab.txt; the 64 x 64 tile's second round is cheaper than 192 big tiles on 256 CUs)
+    const bool small = g_force_tile ? (g_force_tile == 64) : (tiles128 < (lay == 3 ? 512 : 256) && p.K <= 4096);
     const int BT = small ? 64 : 128;
     long tiles = (long)VC_CEIL_DIV(p.M, BT) * VC_CEIL_DIV(p.N, BT);
     int nsplit = 1;
