@@ -225,3 +225,15 @@ def test_layernorm_pre_split_outputs(emu):
                                              rows, U.ptr(scratch), scratch.numel() * 4, st), "ln_bwd pk")
     L.check(emu, emu.vcad_op_pack_x3(U.ptr(dx), U.ptr(want), dx.numel(), st), "pack")
     assert torch.equal(dxp.cpu(), want.cpu())
+
+
+@pytest.mark.parametrize("ct", [F32, U.X3, BF16])
+@pytest.mark.parametrize("trb", [0, 1])
+def test_gemm_ragged_rows_with_aligned_operands(emu, ct, trb):
+    """r04: a tile that is ragged in the row dimension only, on 16-byte-aligned operands with whole k-tiles, stages through vector loads on clamped
+    row indices (A rows past M, B rows past N) and takes the row-wise epilogue with a row bound — the decoder's 2 976-row Linears at the maximum
+    horizon (46.5 tiles of 64 rows).  Both tile sizes, fused epilogue, bf16 and fp32 outputs; nothing may be written outside [M, N]."""
+    for flags in (L.GEMM_TILE64 | L.GEMM_DMA_NEVER | L.GEMM_MID_NEVER, L.GEMM_TILE128 | L.GEMM_DMA_NEVER | L.GEMM_MID_NEVER):
+        U.check_gemm(emu, "cpu", 200, 136 if not trb else 192, 128, ct, trb=trb, bias=True, act=2, residual=True, splitk=False, flags=flags, pack_b=(ct == U.X3))
+        if ct == BF16:
+            U.check_gemm(emu, "cpu", 75, 128, 192, ct, to=F32, sa=F32, trb=trb, residual=True, splitk=False, flags=flags)      # fp32 activations, fp32 output (the decoder's residual-stream Linears)

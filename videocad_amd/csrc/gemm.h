@@ -337,6 +337,28 @@ struct GemmStager {
             }
         }
     }
+    // tile that is ragged in the ROW dimension only (whole k-tile, 16-byte-aligned operand, k contiguous in memory): load_fast's vector loads on a
+    // row index clamped to the last valid row.  The rows past R then hold a copy of row R - 1: they feed accumulator rows (A) / columns (B) that no
+    // epilogue path stores.  (r04: with the element-wise path below, the last 64-row tile of the decoder's 2 976-row Linears at the maximum horizon
+    // — 16 of 752 workgroups — set the duration of the whole launch: 45-71 us against 14-22 us at 2 048 rows, profiles/r04_t186_kernel_stats.txt.)
+    VC_DEV void load_fast_rows(const ST* base, long ld, int r0, int k0, int R, int tid) {
+        static_assert(!TR, "row clamping needs the k-contiguous layout");
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int c = tid + GEMM_THREADS * i;
+            int row = r0 + c / (BK / CH); row = row < R ? row : R - 1;
+            const ST* p = base + (long)row * ld + (k0 + (c % (BK / CH)) * CH);
+            if constexpr (X3) {
+                regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
+            } else if constexpr (sizeof(ST) == sizeof(CT)) {
+                regs[i] = *reinterpret_cast<const vc_u32x4*>(p);
+            } else {   // fp32 source feeding bf16 MFMA
+                const vc_u32x4 lo = reinterpret_cast<const vc_u32x4*>(p)[0], hi = reinterpret_cast<const vc_u32x4*>(p)[1];
+                regs[i].x = vc_pack_bf16x2(vc_bits_f32(lo.x), vc_bits_f32(lo.y)); regs[i].y = vc_pack_bf16x2(vc_bits_f32(lo.z), vc_bits_f32(lo.w));
+                regs[i].z = vc_pack_bf16x2(vc_bits_f32(hi.x), vc_bits_f32(hi.y)); regs[i].w = vc_pack_bf16x2(vc_bits_f32(hi.z), vc_bits_f32(hi.w));
+            }
+        }
+    }
     // edge tiles / unaligned operands: per-element bounds-checked loads, zero fill.
     // R = extent of the row dimension (M or N), Kend = end of this block's k-range
     VC_DEV void load(const ST* base, long ld, int r0, int k0, int R, int Kend, int tid) {
@@ -504,8 +526,12 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
             sa.load_fast(Ag, p.lda, m0, k1, tid); sb.load_fast(Bg, p.ldb, n0, k1, tid);
         } else {
             const bool kfull = k1 + BK <= kend;
-            if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid); else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
-            if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid); else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
+            if (rowsA && kfull) sa.load_fast(Ag, p.lda, m0, k1, tid);
+            else if (!TRA && p.vecA && kfull) { if constexpr (!TRA) sa.load_fast_rows(Ag, p.lda, m0, k1, p.M, tid); }     // ragged last row tile: clamped vector loads
+            else sa.load(Ag, p.lda, m0, k1, p.M, kend, tid);
+            if (rowsB && kfull) sb.load_fast(Bg, p.ldb, n0, k1, tid);
+            else if (!TRB && p.vecB && kfull) { if constexpr (!TRB) sb.load_fast_rows(Bg, p.ldb, n0, k1, p.N, tid); }
+            else sb.load(Bg, p.ldb, n0, k1, p.N, kend, tid);
         }
     };
     auto compute = [&](int cur) {
@@ -644,7 +670,7 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
     if (p.debug_skip & 8) { if (acc[0][0][0] == 12345.678f) ((float*)p.C)[0] = 1.f; return; }   // ablation: no epilogue
 #endif
     // epilogue: D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (!p.partial && p.vecC && m0 + GEMM_BM <= p.M && n0 + GEMM_BN <= p.N) {
+    if (!p.partial && p.vecC && n0 + GEMM_BN <= p.N) {      // (a tile ragged in M only takes this path too, rows past M skipped: r04)
         // Interior block: stage the fp32 tile through LDS (free after the last barrier) and run the epilogue on whole
         // rows — residual / activation-source loads and the final stores are coalesced 16-byte (fp32) or 8-byte (bf16)
         // accesses of 512/256-byte row segments instead of 64 strided scalars per lane.
@@ -666,6 +692,7 @@ VC_DEV void gemm_tile_program(const GemmParams& p, const int bid, const int nx, 
 #pragma unroll 4
         for (int pass = 0; pass < GEMM_BM / RPP; ++pass) {
             const int row = pass * RPP + tid / TPR, m = m0 + row;
+            if (m >= p.M) break;                                     // ragged last row tile (rows only grow with `pass`)
             float v[4];
             quad_ld_f32(et + row * ES + c4, v);
             gemm_epilogue_quad<TO>(p, m, n, v, b4);
