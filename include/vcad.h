@@ -92,8 +92,9 @@ int vcad_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int
  * frames: fp32, frame (b,t) at frames + b*frame_bstride + t*S*S  (so batch['frames'][:, :-1] needs no copy)
  * actions_norm: fp32 [B,T,7] already normalised (reference trainer.py:800-804); cad: fp32 [B,1,S,S]
  * cmds_out fp32 [B,T,num_classes], params_out fp32 [B,T,num_params*num_params_values]
- * Limits: 1 <= T <= 192 (the decoder attention kernels hold at most three 64-key blocks; the dataset's maximum horizon is
- * 186, reference README.md:40 — max_ep_len = 1000 only sizes the timestep table) and B*T*50*3072 < 2^32 (dropout indices). */
+ * Limits: 1 <= T <= min(max_ep_len, 1024) (r04; the dataset's maximum horizon is 186, reference README.md:40, the reference's max_ep_len 1000:
+ * bf16 mode streams the decoder attention over 64-step blocks, the fp32 / bf16x3 modes walk up to sixteen 64-key pieces per query) and
+ * B*T*50*3072 < 2^32 (dropout indices). */
 int vcad_forward(vcad_engine* e, const float* frames, int64_t frame_bstride, const float* actions_norm, const float* cad,
                  int B, int T, float* cmds_out, float* params_out, void* stream);
 
@@ -237,7 +238,7 @@ int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void
                           int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
                           void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
                           int causal, float scale, void* stream);
-/* same, with the saved forward output o: the 64 < T <= 192 decoder kernels take D_i = rowsum(dO * O) from it */
+/* same, with the saved forward output o passed along (the kernels recompute D_i from P and dP; o is accepted for callers that hold it) */
 int vcad_op_attention_bwd_o(int t, int D, const void* q, const void* k, const void* v, const void* o, int64_t ldo, const void* dout,
                             int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
                             void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,

@@ -164,3 +164,31 @@ def test_full_size_fp8_forward_mode_c5_per_gpu_shape():
     eng.backward()
     g_train = float(eng.optimizer_step(lr=1e-5)[0])
     assert np.isfinite(float(loss_t[0])) and np.isfinite(g_train) and 0.3 * g_eval < g_train < 3.0 * g_eval, (g_eval, g_train)
+
+
+@pytest.mark.parametrize("dtype,tol", [(L.VCAD_F32, 1e-4), (L.VCAD_BF16X3, 1e-4), (L.VCAD_BF16, 6e-3)], ids=["f32", "bf16x3", "bf16"])
+def test_horizon_beyond_192_matches_oracle(dtype, tol):
+    """r04: horizons past the released dataset's maximum (186) up to the reference's `max_ep_len` (model/autoregressive_transformer.py:17,80) — here
+    T = 250 (four 64-step blocks: the block-streaming decoder attention in bf16 mode, sixteen-piece wave-per-row kernels in the fp32 modes;
+    timestep rows up to 249): two clips against the fp32 oracle — logits, arg-max (exact in f32 / bf16x3), loss, probed gradient norms."""
+    T = 250
+    ref = oracle_two_clips(T)
+    eng = build(dtype)
+    frames, actions, cad = tiled(ref["batch"], 1)
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    c, p = cmds.cpu(), pars.cpu()
+    rel = U.relerr(p, ref["pars"])
+    agree = float((p.argmax(-1) == ref["pars"].argmax(-1)).float().mean())
+    record(f"T250_{dtype}", rel_err=rel, argmax_agreement=agree)
+    assert rel < tol and U.relerr(c, ref["cmds"]) < tol, (rel, U.relerr(c, ref["cmds"]))
+    if dtype != L.VCAD_BF16:
+        assert torch.equal(p.argmax(-1), ref["pars"].argmax(-1)) and torch.equal(c.argmax(-1), ref["cmds"].argmax(-1))
+    else:
+        assert agree > 0.985, agree
+    loss, _ = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - ref["loss"]) < (2e-5 if dtype != L.VCAD_BF16 else 1.5e-3) * abs(ref["loss"])
+    eng.backward()
+    gt = 3e-3 if dtype != L.VCAD_BF16 else 6e-3
+    for n, want in ref["gn"].items():
+        got = float(eng.view(n, eng.grads).double().norm())
+        assert abs(got - want) <= gt * want + 1e-9, (n, got, want)

@@ -237,3 +237,9 @@ def test_gemm_ragged_rows_with_aligned_operands(emu, ct, trb):
         U.check_gemm(emu, "cpu", 200, 136 if not trb else 192, 128, ct, trb=trb, bias=True, act=2, residual=True, splitk=False, flags=flags, pack_b=(ct == U.X3))
         if ct == BF16:
             U.check_gemm(emu, "cpu", 75, 128, 192, ct, to=F32, sa=F32, trb=trb, residual=True, splitk=False, flags=flags)      # fp32 activations, fp32 output (the decoder's residual-stream Linears)
+
+
+@pytest.mark.parametrize("T,window,D", [(200, 200, 256), (333, 333, 128), (260, 10, 256)])
+def test_attention_f32_beyond_192_keys(emu, T, window, D):
+    """r04: the fp32 modes' wave-per-row kernels with up to sixteen 64-key pieces per query (horizons up to 1 024; the reference's max_ep_len is 1 000)"""
+    U.check_attention(emu, "cpu", 1, 2, T, D, window=window, causal=1, dt=F32)

@@ -252,7 +252,7 @@ class AutoRegressiveTransformer(nn.Module):
         was_training = self.training
         self.eval()
         try:
-            if cached and T <= 192:
+            if cached and T <= 1024:
                 return self._sequential_cached(ui_images, cad_image, action)
             cmds_out, pars_out = [], []
             actions = torch.zeros(B, 1, self.act_dim, device=device) if action else None

@@ -1058,9 +1058,9 @@ static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, con
                        float* cmds_out, float* pars_out, void* stream) {
     if (!e->P) { vc_set_error("vcad_forward: parameters not bound"); return VC_ERR_ARG; }
     if (B < 1 || T < 1 || T > e->c.max_ep_len) { vc_set_error("vcad_forward: bad B=%d T=%d", B, T); return VC_ERR_ARG; }
-    // bf16 mode: the block-streaming decoder attention (attn_mfma.h) takes any horizon up to max_ep_len; the fp32 / bf16x3 modes' wave-per-row
-    // kernels (attn.h) hold at most three 64-key pieces per query in registers
-    if (T > 192 && e->dt != VC_BF16) { vc_set_error("vcad_forward: T=%d exceeds the fp32 attention kernels' 192-key limit (bf16 mode has none)", T); return VC_ERR_UNSUPPORTED; }
+    // any horizon up to max_ep_len (reference: 1 000): bf16 mode on the block-streaming decoder attention (attn_mfma.h), the fp32 / bf16x3 modes on the
+    // wave-per-row kernels (attn.h: up to sixteen 64-key pieces per query)
+    if (T > 1024) { vc_set_error("vcad_forward: T=%d exceeds the attention kernels' 1024-key limit", T); return VC_ERR_UNSUPPORTED; }
     if ((double)B * T * 50.0 * 3072.0 >= 4294967296.0) { vc_set_error("vcad_forward: B*T=%d too large for 32-bit dropout indices", B * T); return VC_ERR_UNSUPPORTED; }
     if (!e->ws) { vc_set_error("vcad_forward: no workspace"); return VC_ERR_WORKSPACE; }
     if (B != e->B || T != e->T || e->planned_ws != e->ws) {     // same (B, T, workspace): pointers, deferred tables and W^T jobs stay valid
@@ -1206,7 +1206,7 @@ size_t vcad_infer_workspace_bytes(const vcad_engine* e, int B, int Tmax) {
 static int infer_begin_any(vcad_engine* e, const void* cad, int u8, int B, int Tmax, void* stream) {
     if (!e->P) { vc_set_error("vcad_infer_begin: parameters not bound"); return VC_ERR_ARG; }
     if (e->c.num_views > 0) { vc_set_error("vcad_infer_begin: incremental inference has no multiview input (nor has the reference's sequential_inference)"); return VC_ERR_UNSUPPORTED; }
-    if (B < 1 || Tmax < 1 || Tmax > 192 || Tmax > e->c.max_ep_len) { vc_set_error("vcad_infer_begin: bad B=%d Tmax=%d (1 <= Tmax <= 192)", B, Tmax); return VC_ERR_ARG; }
+    if (B < 1 || Tmax < 1 || Tmax > 1024 || Tmax > e->c.max_ep_len) { vc_set_error("vcad_infer_begin: bad B=%d Tmax=%d (1 <= Tmax <= min(1024, max_ep_len))", B, Tmax); return VC_ERR_ARG; }
     if (!e->ws) { vc_set_error("vcad_infer_begin: no workspace"); return VC_ERR_WORKSPACE; }
     { vcad_engine tmp = *e; const size_t need = infer_plan(&tmp, B, Tmax, nullptr);
       if (need > e->ws_bytes) { vc_set_error("vcad_infer_begin: workspace %zu < %zu bytes", e->ws_bytes, need); return VC_ERR_WORKSPACE; } }

@@ -19,6 +19,10 @@ static int attn_fwd_t(int D, AttnParams p, vc_stream_t s) {
     else if (D == 256 && np == 1) VC_LAUNCH((attn_fwd_kernel<T, 4, 1>), g, dim3(256), 0, s, p);
     else if (D == 256 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 4, 3>), g, dim3(256), 0, s, p);
     else if (D == 64 && np <= 3) VC_LAUNCH((attn_fwd_kernel<T, 1, 3>), g, dim3(256), 0, s, p);
+    // up to 1 024 visible keys (the reference's max_ep_len is 1 000): long causal horizons of the fp32 modes and of the cached inference (r04)
+    else if (D == 256 && np <= 16) VC_LAUNCH((attn_fwd_kernel<T, 4, 16>), g, dim3(256), 0, s, p);
+    else if (D == 128 && np <= 16) VC_LAUNCH((attn_fwd_kernel<T, 2, 16>), g, dim3(256), 0, s, p);
+    else if (D == 64 && np <= 16) VC_LAUNCH((attn_fwd_kernel<T, 1, 16>), g, dim3(256), 0, s, p);
     else { vc_set_error("attn_fwd: D=%d keys=%d unsupported", D, max_keys(p)); return VC_ERR_UNSUPPORTED; }
     return VC_OK;
 }
@@ -32,6 +36,9 @@ static int attn_bwd_t(int D, AttnParams p, vc_stream_t s) {
     else if (D == 256 && npk == 1) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 1>), gq, dim3(256), 0, s, p);
     else if (D == 256 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 3>), gq, dim3(256), 0, s, p);
     else if (D == 64 && npk <= 3) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 3>), gq, dim3(256), 0, s, p);
+    else if (D == 256 && npk <= 16) VC_LAUNCH((attn_bwd_q_kernel<T, 4, 16>), gq, dim3(256), 0, s, p);
+    else if (D == 128 && npk <= 16) VC_LAUNCH((attn_bwd_q_kernel<T, 2, 16>), gq, dim3(256), 0, s, p);
+    else if (D == 64 && npk <= 16) VC_LAUNCH((attn_bwd_q_kernel<T, 1, 16>), gq, dim3(256), 0, s, p);
     else { vc_set_error("attn_bwd_q: D=%d keys=%d unsupported", D, max_keys(p)); return VC_ERR_UNSUPPORTED; }
     if (D == 128 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 2, 1>), gk, dim3(256), 0, s, p);
     else if (D == 128 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 2, 3>), gk, dim3(256), 0, s, p);
@@ -39,6 +46,9 @@ static int attn_bwd_t(int D, AttnParams p, vc_stream_t s) {
     else if (D == 256 && npq == 1) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 1>), gk, dim3(256), 0, s, p);
     else if (D == 256 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 3>), gk, dim3(256), 0, s, p);
     else if (D == 64 && npq <= 3) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 3>), gk, dim3(256), 0, s, p);
+    else if (D == 256 && npq <= 16) VC_LAUNCH((attn_bwd_kv_kernel<T, 4, 16>), gk, dim3(256), 0, s, p);
+    else if (D == 128 && npq <= 16) VC_LAUNCH((attn_bwd_kv_kernel<T, 2, 16>), gk, dim3(256), 0, s, p);
+    else if (D == 64 && npq <= 16) VC_LAUNCH((attn_bwd_kv_kernel<T, 1, 16>), gk, dim3(256), 0, s, p);
     else { vc_set_error("attn_bwd_kv: D=%d queries=%d unsupported", D, max_queries(p)); return VC_ERR_UNSUPPORTED; }
     return VC_OK;
 }
