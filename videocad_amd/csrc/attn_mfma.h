@@ -74,6 +74,16 @@ VC_DEV vc_s16x8 am_pack_keep(const vc_f32x16& a, int s, uint64_t keep, int ti, i
 }
 VC_DEV int am_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }   // row inside a 32x32 D tile
 
+// Workgroup -> (image n, head h) of the ViT kernels, XCD-aware (r04): hardware deals workgroups round-robin to the 8 XCDs (block b runs on XCD b % 8), so
+// with the plain b -> (b / H, b % H) order the 16 heads of one frame — sixteen adjacent 128-byte pieces of the same q / k / v rows — were fetched by eight different L2s,
+// each pulling single cache lines out of every 6 KiB row.  Here XCD x takes whole frames (frames 8 j + x): its L2 sees every row as three contiguous 2 KiB runs.
+// The frames past the last multiple of 8 keep the plain order.  (Pure placement: no effect on results.)
+VC_DEV void am_block_to_frame_head(int b, int B, int H, long& n, int& h) {
+    const int full = (B >> 3) << 3;                       // frames covered by whole groups of 8
+    if (b < full * H) { const int xcd = b & 7, idx = b >> 3; n = (long)(idx / H) * 8 + xcd; h = idx % H; }
+    else { n = b / H; h = b % H; }
+}
+
 VC_DEV void am_zero(vc_f32x16 (&a)[2][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -481,7 +491,7 @@ VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
     VC_SHARED float lse_s[AM_T];
     VC_SHARED float del_s[AM_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
-    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    int h; long n; am_block_to_frame_head((int)blockIdx.x, p.B, p.H, n, h);
     const int T = p.Tq;
     const long rowq = n * T;
     am_stage_nt<256>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
@@ -570,7 +580,7 @@ template <bool DROP>
 VC_KERNEL __launch_bounds__(128, 4) void attn_vit_fwd2_kernel(AttnParams p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[2][AM_T * AM_S];      // Q then V, K
     const int tid = threadIdx.x, lane = tid & 63, t = vc_uniform(tid >> 6);
-    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    int h; long n; am_block_to_frame_head((int)blockIdx.x, p.B, p.H, n, h);
     const int T = p.Tq;
     const long rowq = n * T;
     am_stage_nt<128>(tiles[0], (const vc_bf16*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);

@@ -118,7 +118,7 @@ template <bool DROP, bool PK>
 VC_KERNEL __launch_bounds__(128, 2) void attn_vit_fwd2_x3_kernel(AttnParams p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AX_TILE];          // Q hi, Q lo (then V hi, V lo) ; K hi, K lo (then the store staging)
     const int tid = threadIdx.x, lane = tid & 63, t = vc_uniform(tid >> 6);
-    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    int h; long n; am_block_to_frame_head((int)blockIdx.x, p.B, p.H, n, h);
     const int T = p.Tq;
     const long rowq = n * T;
     ax_stage_nt<128, PK>(tiles[0], tiles[1], (const float*)p.q + rowq * p.ldq + h * AM_D, p.ldq, T, tid);
@@ -193,7 +193,7 @@ VC_KERNEL __launch_bounds__(256, 2) void attn_vit_bwd4_x3_kernel(AttnParams p) {
     float* lse_s = reinterpret_cast<float*>(tiles + 8 * AX_TILE);
     float* del_s = lse_s + AM_T;
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
-    const int h = blockIdx.x % p.H; const long n = blockIdx.x / p.H;
+    int h; long n; am_block_to_frame_head((int)blockIdx.x, p.B, p.H, n, h);
     const int T = p.Tq;
     const long rowq = n * T;
     vc_bf16 *Qh = tiles, *Ql = tiles + AX_TILE, *Kh = tiles + 2 * AX_TILE, *Kl = tiles + 3 * AX_TILE;
