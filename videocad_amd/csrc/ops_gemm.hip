@@ -119,7 +119,11 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if (pass == 0 && lay == 1) continue;                        // (no 256-wide instantiation of the tr-read B layout: the hot dgrads go through W^T)
         const long tiles = (long)VC_CEIL_DIV(p.M, GD_BM) * (p.N / BN);
         const int ktiles = p.K / GD_BK;
-        const double kt_us = BN == 256 ? 0.42 : 0.25;               // one k-tile of one item, microseconds
+        // one k-tile of one item, microseconds.  Token-reduction wgrads (both operands streamed from HBM along k, nothing to re-use in L2) run at the
+        // pace of the ring's round trips, not of the matrix cores: ~2 us per k-tile in the model (QKV wgrad: 160 k-tiles in 355 us; the 512 x 512 MLP
+        // wgrads: 64 k-tiles in 127 us, profiles/r04_kernel_shapes_c2.txt).  With the r01 constants (0.42 / 0.25) the slab term outweighed the k-loop and
+        // the MLP wgrads ran as 25 slices on 200 of the 256 CUs; priced at what a k-tile costs they take 32 slices = one full round (r04).
+        const double kt_us = lay == 3 ? (BN == 256 ? 2.2 : 2.0) : (BN == 256 ? 0.42 : 0.25);
         // k-slices: model time as (rounds over the 256 CUs) x (k-tiles per item) + the fp32 slab round trip of a split
         int best = 1; double bestc = 1e30;
         const size_t per = (size_t)p.M * p.N * sizeof(float);
