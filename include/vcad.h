@@ -137,6 +137,15 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
    HIP-event profiler recording) the stage runs on the caller's stream in line and vcad_join_side is a no-op: a communication stream must
    then wait for the caller's stream itself (videocad_amd/trainer.py: GradSync does both). */
 int vcad_side_stage(const vcad_engine* e);
+/* Data parallelism for a binder WITHOUT PyTorch (r04): a per-bucket hook of the single-call backward.  vcad_backward calls fn(user, bucket, grads, count,
+ * stream) right after it has enqueued the last launch that writes bucket `bucket` (grads = device pointer to its `count` fp32 gradients inside the bound
+ * buffer, stream = the hipStream_t those launches are on — the caller's stream, or the library's side stream for the CAD ViT's bucket and, in train mode,
+ * for bucket 0 whose deferred weight gradients run there).  The hook must not block: record an event on `stream`, make its communication stream wait for it
+ * and enqueue ncclAllReduce(grads, grads, count, ncclFloat, ncclSum, comm, comm_stream) (RCCL); before vcad_optimizer_step the caller makes ITS stream
+ * wait for the communication stream and passes grad_scale = 1 / world.  The library never touches a bucket again after its hook ran.  NULL = off.
+ * (The reference's DDP wrap at experiment.py:104-109; the Python trainer does the same through vcad_backward_stage + torch.distributed.) */
+typedef int (*vcad_bucket_ready_fn)(void* user, int bucket, float* grads, int64_t count, void* stream);
+int vcad_set_bucket_callback(vcad_engine* e, vcad_bucket_ready_fn fn, void* user);
 int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
 int vcad_join_side(vcad_engine* e, void* stream);
 

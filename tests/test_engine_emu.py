@@ -337,3 +337,39 @@ def test_engine_other_wirings_match_oracle(emu, pa, ps, tse):
     eng.optimizer_step(lr=1e-5)
     for k in weights:
         assert float((eng.view(k) - ot.P[k].detach()).abs().max()) < 2e-6, k
+
+
+def test_bucket_callback_of_the_single_call_backward(emu):
+    """include/vcad.h vcad_set_bucket_callback (r04): the data-parallel hook for binders without PyTorch.  The whole backward calls it once per gradient
+    bucket, in stage order, with that bucket's range of the bound gradient buffer; a hook that doubles the range in place (= an all-reduce(SUM) over two
+    identical ranks) followed by an optimiser step with grad_scale = 1/2 must reproduce the plain step's weights."""
+    import ctypes as C
+    cfg = small_cfg(vit_depth=2, num_decoder_layers=1)
+    batch = synth.make_batch(1, 2, seed=12)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+
+    def step(hook):
+        eng, _ = build(cfg, L.VCAD_F32, emu)
+        seen = []
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_void_p)
+
+        def cb(user, bucket, grads, count, stream):
+            lo, hi = eng.buckets[bucket]
+            assert count == hi - lo and C.addressof(grads.contents) == eng.grads.data_ptr() + 4 * lo
+            seen.append(bucket)
+            eng.grads[lo:hi].mul_(2.0)                       # "all-reduce(SUM)" over two identical ranks
+            return 0
+        keep = CB(cb)
+        if hook:
+            L.check(eng.lib, eng.lib.vcad_set_bucket_callback(eng.h, C.cast(keep, C.c_void_p), None), "set_bucket_callback")
+        eng.set_dropout(0.1, seed=3)
+        cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+        eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+        eng.backward()
+        eng.optimizer_step(lr=1e-4, grad_scale=0.5 if hook else 1.0)
+        return eng.params.clone(), seen
+
+    p_plain, _ = step(False)
+    p_hook, seen = step(True)
+    assert seen == [0, 1, 2, 3, 4]
+    assert torch.equal(p_plain, p_hook)                       # (x2 then x0.5 is exact in fp32)

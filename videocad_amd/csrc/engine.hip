@@ -87,6 +87,7 @@ struct vcad_engine {
     float *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
     void *t_df1, *t_dq, *t_dkv, *t_dao_d, *t_dqkv_d;
     Lane lane[2];                 // scratch + ViT-backward temporaries per stream (see Lane)
+    vcad_bucket_ready_fn bucket_cb = nullptr; void* bucket_cb_user = nullptr;      // vcad_set_bucket_callback: per-bucket hook of the whole backward
     vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false, bwd_side = false, side_pending = false;
     float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
@@ -1159,21 +1160,34 @@ int vcad_join_side(vcad_engine* e, void* stream) {
 // Whole backward: after stages 0-1 (heads + decoder, stem) the CAD ViT's backward (stage 2) is independent of the frame ViT's
 // (stages 3-4), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
 // soon as its stage returns) keeps everything on the caller's stream.
+int vcad_set_bucket_callback(vcad_engine* e, vcad_bucket_ready_fn fn, void* user) { e->bucket_cb = fn; e->bucket_cb_user = user; return 0; }
+
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
     vc_stream_t s = (vc_stream_t)stream;
     const bool fork = e->c.enable_past_states && ensure_side(e);
+    // per-bucket hook (vcad_set_bucket_callback): called right after the launches that finalise a bucket have been enqueued, with the stream they are on
+    auto ready = [&](int b, vc_stream_t on) -> int {
+        if (!e->bucket_cb) return 0;
+        const long lo = e->buckets[b].first, hi = e->buckets[b].second;
+        const int rc = e->bucket_cb(e->bucket_cb_user, b, e->G + lo, (int64_t)(hi - lo), (void*)on);
+        if (rc) { vc_set_error("vcad_backward: bucket callback returned %d for bucket %d", rc, b); return VC_ERR_ARG; }
+        return 0;
+    };
     e->bwd_side = fork;
     int rc0 = vcad_backward_stage(e, 0, dcmds, dpars, stream);
     e->bwd_side = false;
     if (rc0) return rc0;
+    CK(ready(0, fork && e->drop_p > 0.f ? e->side : s));       // (train mode: the deferred decoder weight gradients were enqueued on the side stream, behind stage 0)
     CK(vcad_backward_stage(e, 1, dcmds, dpars, stream));
+    CK(ready(1, s));
     if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
     e->bwd_fork = fork;
     int rc = vcad_backward_stage(e, CAD_STAGE, dcmds, dpars, stream);
     e->bwd_fork = false;
     if (rc) return rc;
+    CK(ready(CAD_STAGE, fork ? e->side : s));
     if (fork) CK(vc_event_record(e->ev_join, e->side));
-    for (int st = CAD_STAGE + 1; st < NB_BUCKETS; ++st) CK(vcad_backward_stage(e, st, dcmds, dpars, stream));
+    for (int st = CAD_STAGE + 1; st < NB_BUCKETS; ++st) { CK(vcad_backward_stage(e, st, dcmds, dpars, stream)); CK(ready(st, s)); }
     if (fork) CK(vc_stream_wait_event(s, e->ev_join));
     return 0;
 }

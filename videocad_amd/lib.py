@@ -69,6 +69,7 @@ PROTOTYPES = {
     "vcad_backward_stage": (_i, [_vp, _i, _vp, _vp, _vp]),
     "vcad_backward_stage_side": (_i, [_vp, _i, _vp, _vp, _vp]),
     "vcad_side_stage": (_i, [_vp]),
+    "vcad_set_bucket_callback": (_i, [_vp, _vp, _vp]),
     "vcad_join_side": (_i, [_vp, _vp]),
     "vcad_optimizer_step": (_i, [_vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "vcad_optimizer_step_groups": (_i, [_vp, C.POINTER(_f), _f, _f, _f, _f, _i, _f, _vp, _vp]),
