@@ -475,3 +475,48 @@ def test_bf16_train_mode_other_wirings(pa, ps, tse):
     assert np.isfinite(l1) and bool(torch.isfinite(g1).all()) and float(g1.abs().sum()) > 0
     assert l1 == l2 and bool(torch.equal(g1, g2)), "train step is not deterministic"
     assert bool(torch.equal(g1, g3)), float((g1 - g3).abs().max())
+
+
+def test_bucket_callback_orders_the_exchange_behind_the_right_stream():
+    """vcad_set_bucket_callback on the device: the hook gets, per bucket, the stream its finalising launches are on (the caller's, or the library's side stream
+    for the CAD ViT's bucket and — train mode — for bucket 0's deferred weight gradients); an "exchange" enqueued on a third stream behind an event recorded
+    there (here: doubling the range, = all-reduce(SUM) over two identical ranks) followed by grad_scale = 1/2 must give bitwise the plain step."""
+    import ctypes as C
+    B, T = 2, 8
+    batch = synth.make_batch_torch(B, T, 11, DEV, None)
+    fr, ac, cad = batch["frames"], batch["actions"], batch["cad_image"]
+
+    def step(hook):
+        eng = build(L.VCAD_BF16)
+        comm = torch.cuda.Stream(device=DEV)
+        seen = []
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int64, C.c_void_p)
+
+        def cb(user, bucket, grads, count, stream):
+            lo, hi = eng.buckets[bucket]
+            src = torch.cuda.ExternalStream(stream, device=DEV) if stream else torch.cuda.current_stream(DEV)
+            ev = torch.cuda.Event(); ev.record(src)
+            comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                eng.grads[lo:hi].mul_(2.0)
+            seen.append((bucket, int(stream or 0)))
+            return 0
+        keep = CB(cb)
+        if hook:
+            L.check(eng.lib, eng.lib.vcad_set_bucket_callback(eng.h, C.cast(keep, C.c_void_p), None), "set_bucket_callback")
+        eng.set_dropout(0.1, seed=5)
+        cmds, pars = eng.forward(fr[:, :-1], O.normalize_actions(ac[:, :-1]), cad)
+        eng.loss(cmds, pars, ac[:, 1:], U.LABEL_W)
+        eng.backward()
+        torch.cuda.current_stream(DEV).wait_stream(comm)
+        eng.optimizer_step(lr=1e-4, grad_scale=0.5 if hook else 1.0)
+        torch.cuda.synchronize()
+        return eng.params.clone(), seen
+
+    p_plain, _ = step(False)
+    p_hook, seen = step(True)
+    assert [b for b, _ in seen] == [0, 1, 2, 3, 4]
+    cur = torch.cuda.current_stream(DEV).cuda_stream
+    assert seen[1][1] == cur and seen[3][1] == cur and seen[4][1] == cur
+    assert seen[0][1] == seen[2][1] and seen[0][1] != cur            # bucket 0 (deferred wgrads) and the CAD ViT's bucket are final on the side stream
+    assert bool(torch.equal(p_plain, p_hook)), float((p_plain - p_hook).abs().max())
