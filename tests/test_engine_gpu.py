@@ -93,7 +93,7 @@ def test_f32_step_matches_reference_goldens(golden_dir, case):
 
 @pytest.mark.parametrize("case", ["c1_full", "c1_ragged"])
 def test_bf16x3_step_in_tolerance_of_reference_goldens(golden_dir, case):
-    """VCAD_BF16X3 — fp32 tensors, every Linear as three hi/lo-split bf16 MFMAs, attention on the f32 matrix cores — against the goldens
+    """VCAD_BF16X3 — fp32 tensors, every Linear and the ViT attention as three hi/lo-split bf16 MFMAs on pre-split tensors (r04), decoder attention on the f32 matrix cores — against the goldens
     of the imported reference: north_star's gate (logits within 1e-3 relative, arg-max bit-exact) with a decade to spare, and the whole
     step (loss, metrics, 309 gradient norms, clip norm, post-Adam weights) at the split's accuracy."""
     meta = json.load(open(os.path.join(golden_dir, "meta.json")))["cases"][case]

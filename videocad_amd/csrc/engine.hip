@@ -1138,8 +1138,9 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
 }
 int vcad_side_stage(const vcad_engine*) { return CAD_STAGE; }
 // Data-parallel callers: the CAD ViT's backward (stage vcad_side_stage()) launched on the side stream; its bucket may be all-reduced only after
-// vcad_join_side() has made the waiting stream wait for it.  *forked (optional) reports whether the side stream was used: when it was not
-// (enable_past_states off, side stream disabled, profiler recording, stream creation failed) the stage ran on the caller's stream in line.
+// vcad_join_side() has made the waiting stream wait for it.  When the side stream is not used (enable_past_states off, side stream disabled, profiler
+// recording, stream creation failed) the stage runs on the caller's stream in line and vcad_join_side() is a no-op: a communication stream must then be ordered
+// behind the caller's stream itself (videocad_amd/trainer.py: GradSync.reduce_range waits for both).
 int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dpars, void* stream) {
     if (stage != CAD_STAGE) { vc_set_error("vcad_backward_stage_side: only stage %d (CAD ViT) can run on the side stream", CAD_STAGE); return VC_ERR_ARG; }
     vc_stream_t s = (vc_stream_t)stream;
