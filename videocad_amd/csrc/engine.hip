@@ -579,8 +579,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             p.lddq = p.lddk = p.lddv = 3 * inner;
             p.B = (int)N; p.H = c.vit_heads; p.Tq = p.Tk = P + 1; p.window = P + 1; p.causal = 0; p.scale = 1.0f / sqrtf((float)c.vit_dim_head);
             p.drop = cx.site(v + 1, L, Ctx::K_ATTN); p.x3 = pk ? 2 : (e->ct == VC_X3 ? 1 : 0);
-            if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero
-                CK(vc_memset_async(cx.L().t_dqkv, 0, (size_t)R * 3 * inner * e->esz, cx.s));
+            if (cls_only) {       // one query (the cls row) per frame; dQ of every other token is zero — the Q third of every row (dK / dV are written for all tokens)
+                CK(vc_zero_cols(cx.L().t_dqkv, (long)3 * inner * e->esz, R, (long)inner * e->esz, cx.s));
                 p.Tq = 1; p.ldq = 3 * TI; p.lddq = 3 * TI;
             }
             CK(vc_attn_bwd(e->dt, c.vit_dim_head, p, cx.s));

@@ -304,6 +304,15 @@ VC_KERNEL __launch_bounds__(256) void dropout_mul_kernel(const float* in, long l
     quad_store<TY>(out + r * ld_out + c, v);
 }
 
+// zero the first `width_bytes` (a multiple of 16) of each of `rows` rows spaced `ld_bytes` apart (16-byte stores; a strided memset)
+VC_KERNEL __launch_bounds__(256) void zero_cols_kernel(char* p, long ld_bytes, long rows, int width_bytes) {
+    const int per_row = width_bytes / 16;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    vc_u32x4 z; z.x = z.y = z.z = z.w = 0u;
+    *reinterpret_cast<vc_u32x4*>(p + (i / per_row) * ld_bytes + (i % per_row) * 16) = z;
+}
+
 // ---- act = tanh(a W^T + b + ts[t])  with K = act_dim (7): too skinny for MFMA, one thread per output
 // (reference model/autoregressive_transformer.py:112,176-178)
 template <typename TY>

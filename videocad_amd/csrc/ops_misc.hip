@@ -111,6 +111,13 @@ int vc_dropout_mul(int ty, const float* in, long ld_in, void* out, long ld_out, 
     else VC_LAUNCH((dropout_mul_kernel<float>), g, dim3(256), 0, s, in, ld_in, (float*)out, ld_out, rows, cols, d);
     return VC_OK;
 }
+int vc_zero_cols(void* p, long ld_bytes, long rows, long width_bytes, vc_stream_t s) {
+    if (rows <= 0 || width_bytes <= 0) return VC_OK;
+    if (((uintptr_t)p | (uintptr_t)ld_bytes | (uintptr_t)width_bytes) & 15) { vc_set_error("vc_zero_cols: 16-byte alignment"); return VC_ERR_ARG; }
+    ProfScope ps(VC_CAT_OTHER, 0, (double)rows * width_bytes, s);
+    VC_LAUNCH(zero_cols_kernel, dim3((unsigned)VC_CEIL_DIV(rows * (width_bytes / 16), 256)), dim3(256), 0, s, (char*)p, ld_bytes, rows, (int)width_bytes);
+    return VC_OK;
+}
 int vc_dtanh(int ty, const float* d, const float* y, float* out32, void* outt, long n, vc_stream_t s) {
     dim3 g((unsigned)VC_CEIL_DIV(n, 256));
     if (ty == VC_BF16) VC_LAUNCH((dtanh_kernel<vc_bf16>), g, dim3(256), 0, s, d, y, out32, (vc_bf16*)outt, n);
