@@ -398,9 +398,6 @@ VC_DEV uint32_t am_keep_bits1(const vc_drop& d, uint32_t base, int T, int tj, in
         for (int j = 0; j < 8; ++j) {
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti) {
-                // register pair (2j, 2j + 1) of tile ti walks rows ti*32 + (2j & 3) + 8 (2j >> 2) (+ 4 in the upper half-wave) and the next one: when even the
-                // smallest of them is a padding row (>= T: 14 of the 64 rows for the ViT's 50 tokens) nothing reads these bits — no hash (r04; wave-uniform test)
-                if (ti * 32 + ((2 * j) & 3) + 8 * ((2 * j) >> 2) >= T) continue;
                 uint32_t b0, b1;
                 if (QCOL) {
                     const int key = ti * 32 + am_row(2 * j, lane);
