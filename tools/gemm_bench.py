@@ -164,6 +164,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "abl":
                 run(f"{name} [{'no epilogue' if sk else 'full'} #{rnd}]", *dims, **kw)
     lib.vcad_debug_gemm_skip(0)
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "spread":
+    # the residual epilogue of the 128-wide tile: full / no epilogue (64) / no epilogue but its loads and stores spread over the main loop (256)
+    lib.vcad_debug_gemm_dma(1)
+    for name, dims, kw in [("out fwd +res f32", (R, 512, 1024), dict(to=F32, bias=True, res=True)), ("mlp2 fwd +res f32", (R, 512, 512), dict(to=F32, bias=True, res=True)),
+                           ("out fwd +res f32 102400", (102400, 512, 1024), dict(to=F32, bias=True, res=True)), ("mlp2 fwd +res f32 102400", (102400, 512, 512), dict(to=F32, bias=True, res=True))]:
+        for rnd in range(3):
+            for sk, tag in ((0, "full"), (64, "no epilogue"), (256, "spread traffic, no epilogue")):
+                lib.vcad_debug_gemm_skip(sk)
+                run(f"{name} [{tag} #{rnd}]", *dims, **kw)
+    lib.vcad_debug_gemm_skip(0)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "wr":
     # is the epilogue's cost the HBM write stream?  full / no epilogue (64) / the same stores aimed at 256 rows of C that stay in L2 (128)
     lib.vcad_debug_gemm_dma(1)
