@@ -27,8 +27,9 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seq", type=int, default=64)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"],
-                    help="bf16 = throughput mode (headline); bf16x3 = in-tolerance mode (fp32 tensors, hi/lo-split bf16 MFMAs); f32 = exact fp32 MFMA")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "bf16x3"],
+                    help="bf16 = throughput mode (headline, BASELINE's dtype); f16 = the same kernels on fp16 storage (libvcad_hip_f16.so: in tolerance); "
+                         "bf16x3 = fp32 tensors, hi/lo-split bf16 MFMAs (in tolerance); f32 = exact fp32 MFMA")
     ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout probability (reference default 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-seq186", action="store_true", help="skip the extra seq_len=186 measurement reported beside the headline config")

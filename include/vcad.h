@@ -27,7 +27,13 @@
 extern "C" {
 #endif
 
-enum { VCAD_F32 = 0, VCAD_BF16 = 1, VCAD_BF16X3 = 2 };
+enum { VCAD_F32 = 0, VCAD_BF16 = 1, VCAD_BF16X3 = 2, VCAD_F16 = 3 };
+
+/* The 16-bit storage format is a build-time property of the kernel library: libvcad_hip.so stores bf16 (VCAD_BF16, VCAD_BF16X3, VCAD_F32 engines),
+ * libvcad_hip_f16.so — the same sources compiled with -DVC_H16, the same entry points — stores IEEE fp16 (VCAD_F16, VCAD_F32 engines): the kernels,
+ * tensors and MFMA rate of VCAD_BF16 with 10 mantissa bits instead of 7 (logits within 1e-3 of the fp32 reference), and a gradient scale that
+ * keeps the backward inside fp16's exponent range (vcad_set_grad_scale).  Each library rejects the other's dtypes.  "bf16" / "f16": */
+const char* vcad_storage_format(void);
 
 typedef struct vcad_config {
     /* AutoRegressiveTransformer.__init__ kwargs (reference model/autoregressive_transformer.py:11-35) */
@@ -35,7 +41,7 @@ typedef struct vcad_config {
     int num_classes, num_params, num_params_values, max_ep_len;
     /* vit_pytorch.ViT(...) constructor call at reference model/trajectory_model.py:54-65 */
     int vit_dim, vit_depth, vit_heads, vit_dim_head, vit_mlp, image_size, patch_size;
-    int dtype;                     /* VCAD_F32 | VCAD_BF16 | VCAD_BF16X3 */
+    int dtype;                     /* VCAD_F32 | VCAD_BF16 | VCAD_BF16X3 (libvcad_hip.so) | VCAD_F16 (libvcad_hip_f16.so) */
     /* wiring flags of forward (reference model/autoregressive_transformer.py:149-213) */
     int enable_past_actions, enable_past_states, enable_timestep_embedding;
     int num_views;          /* multiview branch (reference model/autoregressive_transformer.py:72-74,167-170): 0 = off (every final_experiments.json entry) */
@@ -76,6 +82,14 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * attention / to_out / feed-forward dropouts, TransformerDecoderLayer dropout, dropout1-3 and attention dropout).
  * p = 0 disables (model.eval()).  Masks are a stateless hash of (seed, site, element index): set a fresh seed before every
  * training forward; the backward of that forward regenerates the same masks.  No mask tensors are stored. */
+/* Gradient scale of the backward (VCAD_F16 engines: default 4096; every other engine: 1 = off).  A power of two in [1, 2^24]: vcad_backward* multiplies the
+ * incoming dlogits by it (into a private copy) and divides each gradient bucket by it — exactly — when the bucket is complete, before the bucket callback:
+ * the gradient buffer, the callback and vcad_optimizer_step* only ever see true gradients.  A gradient that overflows fp16 anyway shows up as a non-finite
+ * gradient norm: vcad_optimizer_step* then leaves weights and moments untouched (norm_out[0] is inf / NaN); halve the scale and go on.
+ * Changes the workspace plan: call before the next forward. */
+int vcad_set_grad_scale(vcad_engine* e, float scale);
+float vcad_grad_scale(const vcad_engine* e);
+
 /* VCAD_FP8 forward mode (bf16 engines): the four Linear layers of every full ViT layer run on the block-scaled fp8 matrix cores
  * (MXFP8: e4m3 elements, one E8M0 scale per 32 k-values, fp32 accumulate); weights are re-quantised from the fp32 master after every
  * optimiser step, activations right before each GEMM; the backward pass is the bf16 one.  Re-plans the workspace (query
@@ -150,7 +164,8 @@ int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, cons
 int vcad_join_side(vcad_engine* e, void* stream);
 
 /* ---- clip_grad_norm_(max_norm) + Adam.step (reference trainer.py:493-494); step = 1-based Adam step count;
- * grad_scale multiplies gradients first (1/world_size after an all-reduce SUM); norm_out: fp32 [2] = |g|, clip coef */
+ * grad_scale multiplies gradients first (1/world_size after an all-reduce SUM); norm_out: fp32 [2] = |g|, clip coef.  A non-finite |g| skips the update
+ * (weights, moments and shadow stay as they are). */
 int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, float eps, float max_norm, int step,
                         float grad_scale, float* norm_out, void* stream);
 

@@ -12,34 +12,42 @@ from videocad_amd import lib as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_PATH = os.path.join(ROOT, "tests", "emu", "libvcad_emu.so")
+EMU_PATH_F16 = os.path.join(ROOT, "tests", "emu", "libvcad_emu_f16.so")
 X3 = "bf16x3"            # GEMM compute type of the VCAD_BF16X3 mode: fp32 tensors, hi/lo-split bf16 MFMAs
-TD = {torch.float32: L.VCAD_F32, torch.bfloat16: L.VCAD_BF16, X3: L.VCAD_BF16X3}
+TD = {torch.float32: L.VCAD_F32, torch.bfloat16: L.VCAD_BF16, X3: L.VCAD_BF16X3,
+      torch.float16: L.VCAD_BF16}      # op-level type code 1 = "the 16-bit storage type of the library": fp16 tensors go to libvcad_hip_f16.so (L.load("f16"))
+S16 = (torch.bfloat16, torch.float16)
+EPS16 = {torch.bfloat16: 1.0, torch.float16: 0.125}      # rounding step relative to bf16's (the 16-bit tolerances below are bf16's, scaled)
 
 
-def load_emu():
-    if not os.path.exists(EMU_PATH) or os.path.getmtime(EMU_PATH) < max(
+def load_emu(fmt="bf16"):
+    """the host-emulator build of the kernel sources (tests/emu/), in either 16-bit storage format; rebuilt when a source is newer"""
+    path = EMU_PATH if fmt == "bf16" else EMU_PATH_F16
+    if not os.path.exists(path) or os.path.getmtime(path) < max(
             os.path.getmtime(os.path.join(ROOT, "videocad_amd", "csrc", f)) for f in os.listdir(os.path.join(ROOT, "videocad_amd", "csrc"))
             if f.endswith((".h", ".hip"))):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "videocad_amd", "csrc"), "emu"])
-    return L.declare(C.CDLL(EMU_PATH))
+    lib = L.declare(C.CDLL(path))
+    assert lib.vcad_storage_format().decode() == fmt
+    return lib
 
 
-_EMU = None
+_EMU = {}
 
 
 @contextlib.contextmanager
-def emulated():
-    """Route `videocad_amd.lib.load()` to the host-emulator build for the duration (tests only — the product has no such
-    switch: it loads csrc/libvcad_hip.so or raises)."""
-    global _EMU
-    if _EMU is None:
-        _EMU = load_emu()
-    old = L._lib
-    L._lib = _EMU
+def emulated(fmt="bf16"):
+    """Route `videocad_amd.lib.load(fmt)` to the host-emulator build for the duration (tests only — the product has no such
+    switch: it loads csrc/libvcad_hip*.so or raises)."""
+    if fmt not in _EMU:
+        _EMU[fmt] = load_emu(fmt)
+    attr = "_lib" if fmt == "bf16" else "_lib_f16"
+    old = getattr(L, attr)
+    setattr(L, attr, _EMU[fmt])
     try:
-        yield _EMU
+        yield _EMU[fmt]
     finally:
-        L._lib = old
+        setattr(L, attr, old)
 
 
 LABEL_W = [0.04332685213392362, 0.02915898563179938, 0.267566828114559, 0.6005346809501417, 0.05941265316957628]
@@ -48,7 +56,7 @@ LABEL_W = [0.04332685213392362, 0.02915898563179938, 0.267566828114559, 0.600534
 
 def ensure_hip_lib():
     """the gfx950 product library is git-ignored: cross-compile it (hipcc works without a GPU) when a fresh checkout lacks it"""
-    if not os.path.exists(L.LIB_PATH):
+    if not os.path.exists(L.LIB_PATH) or not os.path.exists(L.LIB_PATH_F16):
         subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "videocad_amd", "csrc"), "all"])
     return L.LIB_PATH
 
@@ -89,8 +97,8 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
     sb = st if sb is None else sb
     A_log = rnd((M, K), "cpu", seed=seed + 1)
     B_log = rnd((N, K), "cpu", seed=seed + 2)
-    A_q = A_log.to(sa).float() if ct == torch.float32 or x3 else A_log.to(torch.bfloat16).float()
-    B_q = B_log.to(sb).float() if ct == torch.float32 or x3 else B_log.to(torch.bfloat16).float()
+    A_q = A_log.to(sa).float() if ct == torch.float32 or x3 else A_log.to(ct).float()
+    B_q = B_log.to(sb).float() if ct == torch.float32 or x3 else B_log.to(ct).float()
 
     def store(x_log, tr, dt):
         x = x_log.t().contiguous() if tr else x_log.contiguous()
@@ -151,8 +159,8 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
     out = Cbuf[:, :N].float().cpu()
     err = relerr(out, ref)
     if tol is None:
-        tol = 2e-6 if (ct == torch.float32) else (6e-3 if to == torch.bfloat16 else 2e-5)
-        if ct == torch.bfloat16 and to == torch.float32:
+        tol = 2e-6 if (ct == torch.float32) else (6e-3 * EPS16[to] if to in S16 else 2e-5)
+        if ct in S16 and to == torch.float32:
             tol = 1e-5
         if x3:
             tol = 1.5e-5          # three-term split: ~2^-17 per operand + the dropped lo*lo term, against the UNROUNDED fp32 operands
@@ -175,7 +183,7 @@ def check_layernorm(lib, device, rows, C_, dt, seed=0):
     xr = x.double().cpu().requires_grad_(True); gr = g.double().cpu().requires_grad_(True); br = b.double().cpu().requires_grad_(True)
     ref = torch.nn.functional.layer_norm(xr, (C_,), gr, br, 1e-5)
     assert relerr(y32, ref) < 2e-6, relerr(y32, ref)
-    assert relerr(yt, ref) < (2e-6 if dt == torch.float32 else 4e-3)
+    assert relerr(yt, ref) < (2e-6 if dt == torch.float32 else 4e-3 * EPS16[dt])
     dy = rnd((rows, C_), device, seed=seed + 3)
     dyt = dy.to(dt)
     add = rnd((rows, C_), device, seed=seed + 4)
@@ -218,7 +226,7 @@ def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=
     L.check(lib, rc, "attn_fwd")
     qr, kr, vr = (qkv[:, :, i].double().cpu().requires_grad_(True) for i in range(3))
     ref, lse_ref = attn_ref(qr, kr, vr, window, causal, scale)
-    tol = (2e-5 if x3 else 3e-6) if dt == torch.float32 else 6e-3
+    tol = (2e-5 if x3 else 3e-6) if dt == torch.float32 else 6e-3 * EPS16[dt]
     assert relerr(o, ref) < tol, ("attn fwd", relerr(o, ref))
     assert relerr(lse, lse_ref) < 1e-5
     do = rnd((B, T, H, D), device, dt, seed=seed + 1)
@@ -230,7 +238,7 @@ def check_attention(lib, device, B, H, T, D, window, causal, dt, seed=0, packed=
                                      C.c_void_p(db_ + 2 * H * D * es), ld, ld, ld, B, H, T, T, window, causal, scale, st)
     L.check(lib, rc, "attn_bwd")
     ref.backward(do.double().cpu())
-    tolb = (5e-5 if x3 else 1e-5) if dt == torch.float32 else 1.5e-2
+    tolb = (5e-5 if x3 else 1e-5) if dt == torch.float32 else 1.5e-2 * EPS16[dt]
     for i, g in enumerate((qr.grad, kr.grad, vr.grad)):
         assert relerr(dqkv[:, :, i], g) < tolb, ("attn bwd", i, relerr(dqkv[:, :, i], g))
     if x3:       # r04: the same kernels on pre-split tensors (what the bf16x3 engine hands them): outputs == pack(fp32-tensor outputs), word for word

@@ -34,6 +34,10 @@ def test_c_abi_exports_every_declared_symbol():
     assert not any(hasattr(lib, n) for n in ab_names), [n for n in ab_names if hasattr(lib, n)]
     assert declared and all(hasattr(lib, n) for n in declared), [n for n in declared if not hasattr(lib, n)]
     assert declared <= set(L.PROTOTYPES) | {"vcad_config", "vcad_engine"}, declared - set(L.PROTOTYPES)
+    # the fp16-storage build of the same sources: the same entry points, and it says which format it stores
+    lib16 = L.declare(ctypes.CDLL(L.LIB_PATH_F16))
+    assert all(hasattr(lib16, n) for n in declared) and not any(hasattr(lib16, n) for n in ab_names)
+    assert lib.vcad_storage_format() == b"bf16" and lib16.vcad_storage_format() == b"f16" and b"f16" in lib16.vcad_version()
 
 
 def test_state_dict_matches_appendix_b_and_factory_surface():

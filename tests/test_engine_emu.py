@@ -373,3 +373,59 @@ def test_bucket_callback_of_the_single_call_backward(emu):
     p_hook, seen = step(True)
     assert seen == [0, 1, 2, 3, 4]
     assert torch.equal(p_plain, p_hook)                       # (x2 then x0.5 is exact in fp32)
+
+
+# ------------------------------------------------------------------------------------------------ fp16-storage build (VCAD_F16, libvcad_hip_f16.so)
+@pytest.fixture
+def emu16():
+    with U.emulated("f16") as e:
+        yield e
+
+
+def _f16_grads(eng, batch, scale=None):
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    if scale is not None:
+        eng.set_grad_scale(scale)
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    eng.backward()
+    return cmds, pars, eng.grads.clone()
+
+
+def test_engine_f16_step_against_oracle_and_gradient_scale(emu16):
+    """The fp16 build of the engine sources (tests/emu/libvcad_emu_f16.so), train mode, three ViT layers: forward and every gradient against the oracle fed
+    the same masks, at an eighth of the bf16 tolerances; the gradient buffer holds TRUE gradients whatever the (power-of-two) gradient scale — the scale
+    only decides what underflows inside the backward; an overflowing scale leaves a non-finite norm and an untouched model."""
+    cfg = small_cfg(vit_depth=3, num_decoder_layers=1)
+    eng, weights = build(cfg, L.VCAD_F16, emu16)
+    assert eng.lib is emu16 and eng.shadow.dtype == torch.float16 and eng.grad_scale == 4096.0
+    eng.set_gemm_flags(L.GEMM_DMA_ALWAYS | L.GEMM_DYNAMIC)
+    B, T = 1, 2
+    eng.set_dropout(0.1, seed=77)
+    batch = synth.make_batch(B, T, seed=8)
+    ot = O.OracleTrainer(weights, cfg)
+    ot.masks = engine_masks(eng, cfg, B, T)
+    oloss, _, ocmds, opars = ot.loss_and_grads(batch)
+    cmds, pars, g4096 = _f16_grads(eng, batch)
+    assert U.relerr(pars, opars) < 4e-3 and U.relerr(cmds, ocmds) < 4e-3, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
+    errs = {}
+    for k in weights:
+        g = eng.view(k, eng.grads); og = ot.P[k].grad
+        if og is not None and float(og.norm()) > 0:
+            errs[k] = float((g - og).norm()) / float(og.norm())
+    assert sorted(errs.values())[len(errs) // 2] < 4e-3 and max(errs.values()) < 0.04, max(errs.items(), key=lambda kv: kv[1])
+    # another scale: same gradients up to what rounds differently inside the backward
+    _, _, g256 = _f16_grads(eng, batch, 256.0)
+    assert U.relerr(g256, g4096) < 2e-3, U.relerr(g256, g4096)
+    with pytest.raises(RuntimeError, match="power of two"):
+        eng.set_grad_scale(1000.0)
+    # 2^24 x dlogits of O(0.1) overflows fp16: non-finite gradients, the update is skipped, the host halves the scale
+    before = eng.params.clone()
+    _f16_grads(eng, batch, float(1 << 24))
+    norm = eng.optimizer_step(lr=1e-3)
+    assert not bool(torch.isfinite(norm[0])) and torch.equal(eng.params, before)
+    assert eng.check_grad_overflow(norm) and eng.grad_scale == float(1 << 23)
+    _f16_grads(eng, batch, 4096.0)
+    norm = eng.optimizer_step(lr=1e-3)
+    assert bool(torch.isfinite(norm[0])) and not torch.equal(eng.params, before) and not eng.check_grad_overflow(norm)
+    assert torch.equal(eng.shadow.float(), eng.params.to(torch.float16).float())          # the fp16 weight copy follows the update

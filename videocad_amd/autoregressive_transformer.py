@@ -101,9 +101,9 @@ class AutoRegressiveTransformer(nn.Module):
         self.state_embedding_model_size = self.cad_embedding_model_size = 512
         self.dropout_p = dropout
         self.compute_dtype = compute_dtype
-        if compute_dtype not in ("bf16", "f32", "fp32", "bf16x3"):
-            raise ValueError(f"compute_dtype={compute_dtype!r}: expected 'bf16', 'bf16x3' or 'f32'")
-        dt = {"bf16": L.VCAD_BF16, "bf16x3": L.VCAD_BF16X3}.get(compute_dtype, L.VCAD_F32)
+        if compute_dtype not in ("bf16", "f16", "fp16", "f32", "fp32", "bf16x3"):
+            raise ValueError(f"compute_dtype={compute_dtype!r}: expected 'bf16', 'f16', 'bf16x3' or 'f32'")
+        dt = {"bf16": L.VCAD_BF16, "bf16x3": L.VCAD_BF16X3, "f16": L.VCAD_F16, "fp16": L.VCAD_F16}.get(compute_dtype, L.VCAD_F32)
         cfg = make_config(hidden_size=hidden_size, nhead=nhead, num_decoder_layers=num_decoder_layers,
                           dim_feedforward=dim_feedforward, window_size=window_size, act_dim=act_dim, num_classes=num_classes,
                           num_params=num_params, num_params_values=num_params_values, max_ep_len=max_ep_len, dtype=dt,

@@ -34,7 +34,7 @@ CANONICAL_MODEL_CONFIG = {"model_name": "autoregressive", "state_dim": 1644, "ac
 CLASS_WEIGHTS = os.path.join(ROOT, "tests", "golden", "class_weights.json")     # verbatim copy of the reference's data file
 
 TRAIN_GF_PER_FRAME = {8: 6.25, 64: 5.70, 128: 5.68, 186: 5.68}     # fwd+bwd algorithmic GFLOP per frame
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}       # MI355X_MICROARCH.md dense MFMA peaks (bf16x3: three bf16 MFMAs per product)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}       # MI355X_MICROARCH.md dense MFMA peaks (bf16x3: three bf16 MFMAs per product)
 CATS = ["gemm_fwd", "gemm_dgrad", "gemm_wgrad", "attention", "layernorm", "loss", "optimizer", "other"]
 
 
@@ -365,10 +365,12 @@ def run(args):
     if rank == 0 and world == 1 and (B, T) == (32, 64) and args.dtype == "bf16" and not getattr(args, "no_modes", False):
         modes = {}
         # fp8: BASELINE configs[4] is seq_len 186 — its per-GPU shape (B=16, T=186), next to the bf16 leg at that shape above
-        for key, dt, f8, K3, B3, T3 in (("bf16x3", "bf16x3", False, 4, B, T), ("bf16x3_seq_len_186", "bf16x3", False, 3, 16, 186), ("f32", "f32", False, 2, B, T),
+        # f16 = the fp16-storage build of the library (libvcad_hip_f16.so, VCAD_F16): the bf16 mode's kernels with ten mantissa bits — in tolerance at its speed
+        for key, dt, f8, K3, B3, T3 in (("f16", "f16", False, 10, B, T), ("f16_seq_len_186", "f16", False, 6, 16, 186),
+                                        ("bf16x3", "bf16x3", False, 4, B, T), ("bf16x3_seq_len_186", "bf16x3", False, 3, 16, 186), ("f32", "f32", False, 2, B, T),
                                         ("bf16_fp8_forward", "bf16", True, 4, 16, 186)):
             try:
-                modes[key] = short_leg(dt, f8, B3, T3, K3, 1, device, rank, world, 2000, args.dropout, want_parity=(key != "bf16x3_seq_len_186"))
+                modes[key] = short_leg(dt, f8, B3, T3, K3, 3 if dt == "f16" else 1, device, rank, world, 2000, args.dropout, want_parity=not key.endswith("_seq_len_186"))
             except Exception as ex:               # a reporting leg never breaks the headline measurement
                 modes[key] = {"error": repr(ex)}
 
@@ -398,12 +400,18 @@ def run(args):
             out["seq_len_128_batch_64"] = extra_c3
         if modes:
             out["modes"] = modes
-            x3 = modes.get("bf16x3") or {}
-            if "value" in x3:        # the number to quote next to "matches the reference" (north_star: logits within 1e-3 rel, arg-max exact)
-                out["in_tolerance"] = {"dtype": "bf16x3", "workload": x3["workload"], "value": x3["value"], "unit": "frames/s", "ms_per_step": x3["ms_per_step"],
-                                       "rel_err": x3.get("parity", {}).get("rel_err"), "argmax_agreement": x3.get("parity", {}).get("argmax_agreement"),
-                                       "cmd_argmax_agreement": x3.get("parity", {}).get("cmd_argmax_agreement"),
-                                       "seq_len_186": {k: (modes.get("bf16x3_seq_len_186") or {}).get(k) for k in ("workload", "value", "ms_per_step")}}
+            # the number to quote next to "matches the reference" (north_star: logits within 1e-3 relative, arg-max exact): the fastest measured mode whose
+            # own parity block (fp32 goldens of the imported reference) says so
+            ok = lambda m: "value" in m and (m.get("parity") or {}).get("rel_err", 1.0) < 1e-3 and (m.get("parity") or {}).get("argmax_agreement") == 1.0 \
+                and (m.get("parity") or {}).get("cmd_argmax_agreement") == 1.0
+            cands = {k: modes[k] for k in ("f16", "bf16x3", "f32") if ok(modes.get(k) or {})}
+            if cands:
+                best = max(cands, key=lambda k: cands[k]["value"]); m = cands[best]
+                out["in_tolerance"] = {"dtype": best, "workload": m["workload"], "value": m["value"], "unit": "frames/s", "ms_per_step": m["ms_per_step"],
+                                       "rel_err": m["parity"]["rel_err"], "argmax_agreement": m["parity"]["argmax_agreement"],
+                                       "cmd_argmax_agreement": m["parity"]["cmd_argmax_agreement"],
+                                       "seq_len_186": {k: (modes.get(best + "_seq_len_186") or {}).get(k) for k in ("workload", "value", "ms_per_step")},
+                                       "candidates": {k: {"value": v["value"], "rel_err": v["parity"]["rel_err"]} for k, v in cands.items()}}
         if pcie:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:

@@ -45,8 +45,8 @@ template <> VC_DEV float attn_dot_chunk<float>(const vc_u32x4& c, const float* b
     return vc_bits_f32(c.x) * bc[0] + vc_bits_f32(c.y) * bc[1] + vc_bits_f32(c.z) * bc[2] + vc_bits_f32(c.w) * bc[3];
 }
 template <> VC_DEV float attn_dot_chunk<vc_bf16>(const vc_u32x4& c, const float* bc) {
-    return vc_bits_f32(c.x << 16) * bc[0] + vc_bits_f32(c.x & 0xFFFF0000u) * bc[1] + vc_bits_f32(c.y << 16) * bc[2] + vc_bits_f32(c.y & 0xFFFF0000u) * bc[3] +
-           vc_bits_f32(c.z << 16) * bc[4] + vc_bits_f32(c.z & 0xFFFF0000u) * bc[5] + vc_bits_f32(c.w << 16) * bc[6] + vc_bits_f32(c.w & 0xFFFF0000u) * bc[7];
+    return vc_lo16_f32(c.x) * bc[0] + vc_hi16_f32(c.x) * bc[1] + vc_lo16_f32(c.y) * bc[2] + vc_hi16_f32(c.y) * bc[3] +
+           vc_lo16_f32(c.z) * bc[4] + vc_hi16_f32(c.z) * bc[5] + vc_lo16_f32(c.w) * bc[6] + vc_hi16_f32(c.w) * bc[7];
 }
 template <typename T, int D>
 VC_DEV float attn_dot_row(const T* row, const float* bc) {
@@ -66,7 +66,7 @@ VC_DEV float attn_dot_row(const T* row, const float* bc) {
 // DPL consecutive elements of a row as floats (one vector load for DPL = 4)
 template <typename T, int DPL> VC_DEV void attn_row_ld(const T* p, float (&v)[DPL]) {
     if constexpr (DPL == 4 && sizeof(T) == 4) { const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p); v[0] = vc_bits_f32(q.x); v[1] = vc_bits_f32(q.y); v[2] = vc_bits_f32(q.z); v[3] = vc_bits_f32(q.w); }
-    else if constexpr (DPL == 4 && sizeof(T) == 2) { const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p); v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u); }
+    else if constexpr (DPL == 4 && sizeof(T) == 2) { const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p); v[0] = vc_lo16_f32(q.x); v[1] = vc_hi16_f32(q.x); v[2] = vc_lo16_f32(q.y); v[3] = vc_hi16_f32(q.y); }
     else {
 #pragma unroll
         for (int j = 0; j < DPL; ++j) v[j] = vc_ld(p + j);
@@ -295,7 +295,7 @@ VC_KERNEL __launch_bounds__(256) void attn_fwd_single_query_bf16_kernel(AttnPara
         const float w = r < p.Tk ? ps[wave][r] : 0.f;
         const uint32_t u[4] = {vv[it].x, vv[it].y, vv[it].z, vv[it].w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { acc[2 * k] += w * vc_bits_f32(u[k] << 16); acc[2 * k + 1] += w * vc_bits_f32(u[k] & 0xFFFF0000u); }
+        for (int k = 0; k < 4; ++k) { acc[2 * k] += w * vc_lo16_f32(u[k]); acc[2 * k + 1] += w * vc_hi16_f32(u[k]); }
     }
 #pragma unroll
     for (int off = 8; off < 64; off <<= 1)
@@ -367,7 +367,7 @@ VC_KERNEL __launch_bounds__(256) void attn_bwd_single_query_kernel(AttnParams p)
             const float dsj = live ? dss[wave][r] : 0.f, pj = live ? pss[wave][r] : 0.f;
             const uint32_t u[4] = {kk[it].x, kk[it].y, kk[it].z, kk[it].w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { acc[2 * k] += dsj * vc_bits_f32(u[k] << 16); acc[2 * k + 1] += dsj * vc_bits_f32(u[k] & 0xFFFF0000u); }
+            for (int k = 0; k < 4; ++k) { acc[2 * k] += dsj * vc_lo16_f32(u[k]); acc[2 * k + 1] += dsj * vc_hi16_f32(u[k]); }
             if (live) {
                 vc_u32x4 wk, wv;
                 wk.x = vc_pack_bf16x2(dsj * qv[0], dsj * qv[1]); wk.y = vc_pack_bf16x2(dsj * qv[2], dsj * qv[3]);

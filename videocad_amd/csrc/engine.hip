@@ -90,6 +90,9 @@ struct vcad_engine {
     vcad_bucket_ready_fn bucket_cb = nullptr; void* bucket_cb_user = nullptr;      // vcad_set_bucket_callback: per-bucket hook of the whole backward
     vc_stream_t side = nullptr; vc_event_t ev_fork = nullptr, ev_fork2 = nullptr, ev_join = nullptr; bool side_ok = false, no_side = false, bwd_fork = false, bwd_side = false, side_pending = false;
     float *loss_rows; int* loss_arg; float *loss_small; int* loss_metrics; float *dl_cmds, *dl_pars; float* norm_part; float* norm_out;
+    // fp16 build: the backward runs on gradients multiplied by grad_scale (a power of two: dlogits are scaled into dls_* on entry, every gradient bucket is
+    // divided again — exactly — by the launch that finalises it), so that activation gradients of 1e-6..1e-8 stay inside fp16's normal range.  1 = off.
+    float grad_scale = 1.0f; float *dls_cmds = nullptr, *dls_pars = nullptr;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
     float drop_p = 0.f; uint64_t drop_seed = 0;
@@ -293,6 +296,8 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     e->loss_small = b.take<float>(64 * 4); e->loss_metrics = b.take<int>(VC_NMETRIC * 4);
     const long nlog = (long)c.num_params * c.num_params_values;
     e->dl_cmds = b.take<float>(M * c.num_classes * 4); e->dl_pars = b.take<float>(M * nlog * 4);
+    e->dls_cmds = e->dls_pars = nullptr;
+    if (e->grad_scale != 1.0f) { e->dls_cmds = b.take<float>(M * c.num_classes * 4); e->dls_pars = b.take<float>(M * nlog * 4); }
     e->norm_part = b.take<float>(1024 * 4); e->norm_out = b.take<float>(8 * 4);
     e->wT = nullptr; e->wT_jobs.clear(); e->wT_fresh = false;
     if (e->dt == VC_BF16 && c.enable_past_states) {
@@ -802,6 +807,13 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
     return 0;
 }
 
+// fp16 build: bucket b is complete on `on` — divide the gradient scale out again (exact: a power of two)
+int unscale_bucket(vcad_engine* e, int b, vc_stream_t on) {
+    if (e->grad_scale == 1.0f) return 0;
+    const long lo = e->buckets[b].first, hi = e->buckets[b].second;
+    return vc_scale(e->G + lo, e->G + lo, hi - lo, 1.0f / e->grad_scale, on);
+}
+
 int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_stream_t s) {
     Ctx cx{e, s}; const vcad_config& c = e->c;
     const int B = e->B, T = e->T, H = c.hidden_size, D = c.vit_dim, ff = c.dim_feedforward; const long M = (long)B * T;
@@ -812,6 +824,10 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     const bool pa = c.enable_past_actions, ps = c.enable_past_states, tsE = c.enable_timestep_embedding;
     const float* tgt0 = pa ? e->act : (ps ? e->ui : e->mem);
     const int sa_window = pa ? T : c.window_size;
+    if (e->grad_scale != 1.0f) {
+        CK(vc_scale(dcmds, e->dls_cmds, M * n5, e->grad_scale, s)); CK(vc_scale(dpars, e->dls_pars, M * n6, e->grad_scale, s));
+        dcmds = e->dls_cmds; dpars = e->dls_pars;
+    }
     CK(cx.lin_wgrad(cx.A32(dcmds, n5), cx.A32(xf, H), cx.Gf(e->o_h5_w), H, cx.Gf(e->o_h5_b), (int)M, n5, H));
     CK(cx.lin_wgrad(cx.A32(dpars, n6), cx.A32(xf, H), cx.Gf(e->o_h6_w), H, cx.Gf(e->o_h6_b), (int)M, n6, H));
     CK(cx.lin_dgrad(cx.A32(dpars, n6), cx.W(e->o_h6_w, H), cx.A32(dx, H), (int)M, n6, H, Epi()));
@@ -864,8 +880,10 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         for (int g = 0; g < 2; ++g)
             CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], gs));
         CK(vc_colsum_grouped(df.d_cs, (int)df.cs.size(), df.cs_strips, df.cs_chunks, df.cs_partial, gs));
+        CK(unscale_bucket(e, 0, gs));
+        return 0;
     }
-    return 0;
+    return unscale_bucket(e, 0, s);
 }
 
 // stage 1: stem (bucket 1; reference model/autoregressive_transformer.py:144-178).  dx = gradient of the decoder's tgt input (left in t_dcur by stage 0).
@@ -938,12 +956,30 @@ const char* vcad_last_error(void) { return vc_get_error(); }
 #ifdef VC_EMU
 const char* vcad_version(void) { return "videocad_amd 0.2 (host emulator build: tests only)"; }
 #else
-const char* vcad_version(void) { return "videocad_amd 0.2 (gfx950)"; }
+const char* vcad_version(void) { return "videocad_amd 0.2 (gfx950, " VC_S16_NAME " storage)"; }
 #endif
+
+const char* vcad_storage_format(void) { return VC_S16_NAME; }
+// Gradient scale (fp16 engines; a power of two, 1 = off): the backward multiplies the incoming dlogits by it and divides every gradient bucket by it again when
+// the bucket is complete, so the gradient buffer always holds true gradients.  Changes the workspace plan: call before the next forward.
+int vcad_set_grad_scale(vcad_engine* e, float scale) {
+    int ex = 0;
+    if (!(scale >= 1.0f) || frexpf(scale, &ex) != 0.5f || scale > 16777216.0f) { vc_set_error("vcad_set_grad_scale: %g is not a power of two in [1, 2^24]", (double)scale); return VC_ERR_ARG; }
+    if (scale != e->grad_scale) { e->grad_scale = scale; e->planned_ws = nullptr; e->B = e->T = 0; e->fwd_valid = false; e->infer_T = 0; }
+    return 0;
+}
+float vcad_grad_scale(const vcad_engine* e) { return e->grad_scale; }
 
 int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (!cfg || !out) { vc_set_error("null argument"); return VC_ERR_ARG; }
+#ifdef VC_H16
+    if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_F16) { vc_set_error("dtype %d: this build of the library stores fp16 (VCAD_F16, VCAD_F32); the bf16 modes are in libvcad_hip.so", cfg->dtype); return VC_ERR_ARG; }
+    const bool s16 = cfg->dtype == VCAD_F16;
+#else
+    if (cfg->dtype == VCAD_F16) { vc_set_error("VCAD_F16: this build of the library stores bf16; the fp16 build is libvcad_hip_f16.so"); return VC_ERR_ARG; }
     if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_BF16 && cfg->dtype != VCAD_BF16X3) { vc_set_error("bad dtype %d", cfg->dtype); return VC_ERR_ARG; }
+    const bool s16 = cfg->dtype == VCAD_BF16;
+#endif
     if (cfg->hidden_size % cfg->nhead) { vc_set_error("hidden_size %% nhead != 0"); return VC_ERR_ARG; }
     const int hd = cfg->hidden_size / cfg->nhead;
     if ((hd != 256 && hd != 128 && hd != 64) || cfg->vit_dim_head != 64) { vc_set_error("head dims (%d, %d) unsupported (decoder 64/128/256, ViT 64)", hd, cfg->vit_dim_head); return VC_ERR_UNSUPPORTED; }
@@ -959,7 +995,10 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (cfg->num_classes != 5 || cfg->num_params != 6 || cfg->num_params_values != 1000) { vc_set_error("heads must be 5 + 6x1000 (reference model/autoregressive_transformer.py:218)"); return VC_ERR_UNSUPPORTED; }
     if (cfg->dim_feedforward % 8 || cfg->vit_mlp % 8) { vc_set_error("dim_feedforward / vit_mlp must be multiples of 8 (16-byte bf16 rows)"); return VC_ERR_UNSUPPORTED; }
     vcad_engine* e = new vcad_engine();
-    e->c = *cfg; e->dt = cfg->dtype == VCAD_BF16 ? VC_BF16 : VC_F32; e->ct = cfg->dtype == VCAD_BF16X3 ? VC_X3 : e->dt; e->esz = cfg->dtype == VCAD_BF16 ? 2 : 4;
+    e->c = *cfg; e->dt = s16 ? VC_BF16 : VC_F32; e->ct = cfg->dtype == VCAD_BF16X3 ? VC_X3 : e->dt; e->esz = s16 ? 2 : 4;
+#ifdef VC_H16
+    if (s16) e->grad_scale = 4096.0f;          // default gradient scale of fp16 engines (vcad_set_grad_scale)
+#endif
     if (cfg->vit_depth < 1 || cfg->num_decoder_layers < 1) { vc_set_error("vit_depth / num_decoder_layers must be >= 1"); delete e; return VC_ERR_ARG; }
     build_params(e);
     if ((int)e->buckets.size() != NB_BUCKETS) { vc_set_error("internal: %d buckets", (int)e->buckets.size()); delete e; return VC_ERR_ARG; }
@@ -1010,6 +1049,9 @@ int vcad_set_workspace(vcad_engine* e, void* ws, size_t bytes) { e->ws = (char*)
 // VCAD_FP8 forward mode: the ViT's Linear layers on the block-scaled fp8 matrix cores (bf16 engines only; backward unchanged).  Changes the
 // workspace plan: call before the next forward.
 int vcad_set_fp8(vcad_engine* e, int on) {
+#ifdef VC_H16
+    if (on) { vc_set_error("vcad_set_fp8: the fp8 forward mode exists in the bf16 build only"); return VC_ERR_UNSUPPORTED; }
+#endif
     if (on && e->dt != VC_BF16) { vc_set_error("vcad_set_fp8: fp8 forward GEMMs need a bf16 engine"); return VC_ERR_UNSUPPORTED; }
     if (on && (e->c.vit_dim % 128 || (e->c.vit_heads * e->c.vit_dim_head) % 128 || e->c.vit_mlp % 128)) { vc_set_error("vcad_set_fp8: ViT widths must be multiples of 128"); return VC_ERR_UNSUPPORTED; }
     e->fp8 = on != 0; e->planned_ws = nullptr; e->B = e->T = 0; e->fwd_valid = false; e->infer_T = 0;
@@ -1133,6 +1175,7 @@ int vcad_backward_stage(vcad_engine* e, int stage, const float* dcmds, const flo
         default: vc_set_error("vcad_backward_stage: stage %d out of range", stage); return VC_ERR_ARG;
     }
     if (rc) return rc;
+    if (stage > 0) CK(unscale_bucket(e, stage, stage == CAD_STAGE && e->bwd_fork ? e->side : s));       // (stage 0 does its own: its last launches may be on the side stream)
     if (vc_last_launch_error()) { vc_set_error("vcad_backward: kernel launch failed"); return VC_ERR_LAUNCH; }
     return 0;
 }
@@ -1350,7 +1393,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
         AdamParams a; memset(&a, 0, sizeof(a));
         a.p = e->P + lo; a.g = e->G + lo; a.m = e->Mm + lo; a.v = e->Vv + lo; a.n = hi - lo; a.lr = lr_bucket[b0]; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
         a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
-        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr; a.shadow_pk = e->Spk ? e->Spk + lo : nullptr;
+        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.finite = e->norm_out + 2; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr; a.shadow_pk = e->Spk ? e->Spk + lo : nullptr;
         CK(vc_adam(a, s));
         b0 = b1i + 1;
     }

@@ -154,7 +154,7 @@ template <typename T> VC_DEV void quad_ld(const T* p, float* v);
 template <> VC_DEV void quad_ld<float>(const float* p, float* v) { quad_ld_f32(p, v); }
 template <> VC_DEV void quad_ld<vc_bf16>(const vc_bf16* p, float* v) {
     const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p);
-    v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u);
+    v[0] = vc_lo16_f32(q.x); v[1] = vc_hi16_f32(q.x); v[2] = vc_lo16_f32(q.y); v[3] = vc_hi16_f32(q.y);
 }
 template <> VC_DEV void quad_ld<vc_pk>(const vc_pk* p, float* v) {          // hi + lo of each pre-split word
     const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p);

@@ -166,8 +166,8 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
     if (p.dact_src) {
         float s4[4];
         if constexpr (sizeof(TO) == 2) {
-            s4[0] = vc_bits_f32(side.x << 16); s4[1] = vc_bits_f32(side.x & 0xffff0000u);
-            s4[2] = vc_bits_f32(side.y << 16); s4[3] = vc_bits_f32(side.y & 0xffff0000u);
+            s4[0] = vc_lo16_f32(side.x); s4[1] = vc_hi16_f32(side.x);
+            s4[2] = vc_lo16_f32(side.y); s4[3] = vc_hi16_f32(side.y);
         } else {
             s4[0] = vc_bits_f32(side.x); s4[1] = vc_bits_f32(side.y); s4[2] = vc_bits_f32(side.z); s4[3] = vc_bits_f32(side.w);
         }
@@ -584,7 +584,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                             }
                             if (p.dact_src) {
                                 float s0, s1;
-                                if constexpr (sizeof(TO) == 2) { s0 = vc_bits_f32(sd[i][r].x << 16); s1 = vc_bits_f32(sd[i][r].x & 0xffff0000u); }
+                                if constexpr (sizeof(TO) == 2) { s0 = vc_lo16_f32(sd[i][r].x); s1 = vc_hi16_f32(sd[i][r].x); }
                                 else { s0 = vc_bits_f32(sd[i][r].x); s1 = vc_bits_f32(sd[i][r].y); }
                                 v[0] = vc_apply_dact(v[0], s0, p.dact_kind); v[1] = vc_apply_dact(v[1], s1, p.dact_kind);
                             }

@@ -14,7 +14,7 @@ template <> VC_DEV void quad_load<float>(const float* p, float* v) {
 }
 template <> VC_DEV void quad_load<vc_bf16>(const vc_bf16* p, float* v) {
     const vc_u32x2 q = *reinterpret_cast<const vc_u32x2*>(p);
-    v[0] = vc_bits_f32(q.x << 16); v[1] = vc_bits_f32(q.x & 0xFFFF0000u); v[2] = vc_bits_f32(q.y << 16); v[3] = vc_bits_f32(q.y & 0xFFFF0000u);
+    v[0] = vc_lo16_f32(q.x); v[1] = vc_hi16_f32(q.x); v[2] = vc_lo16_f32(q.y); v[3] = vc_hi16_f32(q.y);
 }
 template <> VC_DEV void quad_load<vc_pk>(const vc_pk* p, float* v) {
     const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(p);
@@ -340,6 +340,18 @@ VC_KERNEL __launch_bounds__(256) void add_inplace_kernel(float* a, const float* 
     if (i < n) a[i] += b[i];
 }
 
+// y = alpha * x (y may be x): the gradient scale of the fp16 build (engine.hip: grad_scale) — 16 bytes per thread, grid-stride
+VC_KERNEL __launch_bounds__(256) void scale_kernel(const float* x, float* y, long n, float alpha) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4]; quad_load<float>(x + 4 * i, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= alpha;
+        quad_store<float>(y + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = alpha * x[(n4 << 2) + threadIdx.x];
+}
+
 // ---- fp32 -> T cast (weight shadows) and generic fill
 template <typename TY>
 VC_KERNEL __launch_bounds__(256) void cast_kernel(const float* x, TY* y, long n) {
@@ -354,7 +366,7 @@ VC_KERNEL __launch_bounds__(256) void cast_kernel(const float* x, TY* y, long n)
 VC_DEV void vc_unpack8(const vc_u32x4& q, float (&v)[8]) {
     const uint32_t u[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[2 * k] = vc_bits_f32(u[k] << 16); v[2 * k + 1] = vc_bits_f32(u[k] & 0xFFFF0000u); }
+    for (int k = 0; k < 4; ++k) { v[2 * k] = vc_lo16_f32(u[k]); v[2 * k + 1] = vc_hi16_f32(u[k]); }
 }
 VC_DEV vc_u32x4 vc_pack8(const float (&v)[8]) {
     vc_u32x4 q; q.x = vc_pack_bf16x2(v[0], v[1]); q.y = vc_pack_bf16x2(v[2], v[3]); q.z = vc_pack_bf16x2(v[4], v[5]); q.w = vc_pack_bf16x2(v[6], v[7]);

@@ -141,6 +141,13 @@ int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s) {
     VC_LAUNCH(add_inplace_kernel, dim3((unsigned)VC_CEIL_DIV(n, 256)), dim3(256), 0, s, a, b, n);
     return VC_OK;
 }
+int vc_scale(const float* x, float* y, long n, float alpha, vc_stream_t s) {
+    if (n <= 0) return VC_OK;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) { vc_set_error("vc_scale: pointers must be 16-byte aligned"); return VC_ERR_ARG; }
+    long nb = VC_CEIL_DIV(n / 4 + 1, 256); if (nb > 4096) nb = 4096;
+    VC_LAUNCH(scale_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, y, n, alpha);
+    return VC_OK;
+}
 VC_KERNEL __launch_bounds__(256) void pack_x3_kernel(const float* x, uint32_t* y, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = vc_pk_pack(x[i]);
 }

@@ -32,6 +32,7 @@ VC_KERNEL __launch_bounds__(256) void sumsq_stage2_kernel(const float* partial, 
         float nrm = (float)sqrt(red[0]) * gscale;      // norm of the averaged gradient (gscale = 1/world)
         float coef = max_norm / (nrm + 1e-6f);
         norm_out[0] = nrm; norm_out[1] = coef < 1.0f ? coef : 1.0f;
+        norm_out[2] = (nrm == nrm && nrm <= 3.0e38f) ? 1.0f : 0.0f;      // finite?  (an overflowed fp16 backward: the update is skipped, adam_kernel)
     }
 }
 
@@ -40,10 +41,12 @@ struct AdamParams {
     float lr, beta1, beta2, eps, bc1, bc2;      // bc = 1 - beta^t
     const float* clip;                          // device scalar (norm_out + 1) or null
     float gscale;                               // extra gradient scale (1/world for DDP sum -> mean)
+    const float* finite;                        // device scalar (norm_out + 2): 0 = the gradient norm is inf / NaN -> leave p, m, v alone
     vc_bf16* shadow;                            // optional bf16 copy of p (same flat offsets)
     uint32_t* shadow_pk;                        // optional pre-split (hi | lo bf16) copy of p for the bf16x3 GEMMs (gemm.h vc_pk)
 };
 VC_KERNEL __launch_bounds__(256) void adam_kernel(AdamParams a) {
+    if (a.finite && a.finite[0] == 0.0f) return;
     const float c = (a.clip ? a.clip[0] : 1.0f) * a.gscale;
     const float step = a.lr / a.bc1, rs2 = 1.0f / sqrtf(a.bc2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {

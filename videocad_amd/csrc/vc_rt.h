@@ -5,6 +5,16 @@
 // fiber-per-lane CPU emulator used ONLY by the `-m "not gpu"` tests to check kernel indexing logic
 // (it is test infrastructure, never shipped, never a fallback: the product library has no CPU path).
 #pragma once
+// 16-bit storage format of this build.  Default: bf16 (libvcad_hip.so).  -DVC_H16: IEEE half (libvcad_hip_f16.so) — the same kernels, the same 16-bit
+// tensors and MFMA rate, 10 mantissa bits instead of 7 (the precision class of the TF32 the reference allows itself, main.py:28) at the price of
+// fp16's exponent range, which the engine covers with a power-of-two gradient scale (engine.hip: grad_scale).  The type is renamed so that kernel
+// names in traces say which format ran.  bf16x3 and fp8 modes exist in the bf16 build only.
+#ifdef VC_H16
+#define vc_bf16 vc_f16
+#define VC_S16_NAME "f16"
+#else
+#define VC_S16_NAME "bf16"
+#endif
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
@@ -56,8 +66,14 @@ typedef __bf16 vc_bf16x8_hw __attribute__((ext_vector_type(8)));
 
 // D(32x32) += A(32x16) * B(16x32), bf16 in / f32 acc.  lane l: A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31];
 // D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)   (cdna_hip_programming.md §3)
+// (VC_H16: the 16-bit operands are IEEE halves — v_mfma_f32_32x32x16_f16, same shape, layout and rate)
 VC_DEV vc_f32x16 vc_mfma_32x32x16_bf16(vc_s16x8 a, vc_s16x8 b, vc_f32x16 c) {
+#ifdef VC_H16
+    typedef _Float16 vc_f16x8_hw __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vc_f16x8_hw, a), __builtin_bit_cast(vc_f16x8_hw, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vc_bf16x8_hw, a), __builtin_bit_cast(vc_bf16x8_hw, b), c, 0, 0, 0);
+#endif
 }
 // LDS transpose read (gfx950 ds_read_b64_tr_b16), semantics measured with tools/probe_tr16.hip: within each 16-lane
 // group lane i points at 4 consecutive 16-bit elements D_i[0..3]; lane i receives { D_{4j + i/4}[i%4] : j = 0..3 }.
@@ -241,8 +257,75 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #endif
 
 // ------------------------------------------------------------------------------------------ common
-struct vc_bf16 { uint16_t bits; };
+struct vc_bf16 { uint16_t bits; };          // one 16-bit storage element (bf16, or IEEE half under VC_H16)
+VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 
+#ifdef VC_H16
+// software codec (host side and the emulator build; the device uses v_cvt_f32_f16 / v_cvt_pk_f16_f32)
+VC_HD float vc_half_bits_to_f32(uint32_t h) {
+    const uint32_t sg = (h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    if (e == 0) return vc_bits_f32(vc_f32_bits((float)m * 5.9604644775390625e-8f) | sg);      // zero / subnormal: m * 2^-24
+    if (e == 31) return vc_bits_f32(sg | 0x7F800000u | (m << 13));
+    return vc_bits_f32(sg | ((e + 112u) << 23) | (m << 13));
+}
+VC_HD uint32_t vc_f32_to_half_bits(float f) {       // round-to-nearest-even; overflow -> inf; NaN stays NaN
+    uint32_t u = vc_f32_bits(f);
+    const uint32_t sg = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u > 0x7F800000u) return sg | 0x7E00u;
+    if (u >= 0x477FF000u) return sg | 0x7C00u;
+    if (u < 0x38800000u) {                                           // below 2^-14: subnormal half = RNE(|f| * 2^24)
+        const float r = vc_bits_f32(u) * 16777216.0f + 12582912.0f;  // (1.5 * 2^23: the integer lands in the low mantissa bits)
+        return sg | (vc_f32_bits(r) - 0x4B400000u);
+    }
+    const uint32_t r = u + 0xFFFu + ((u >> 13) & 1u);
+    return sg | ((r - 0x38000000u) >> 13);
+}
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 vc_h2_hw __attribute__((ext_vector_type(2)));
+typedef float vc_f2_hw __attribute__((ext_vector_type(2)));
+#endif
+VC_HD float vc_bf16_to_f32(vc_bf16 h) {
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(_Float16, h.bits);
+#else
+    return vc_half_bits_to_f32(h.bits);
+#endif
+}
+VC_HD vc_bf16 vc_f32_to_bf16(float f) {
+    vc_bf16 r;
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    r.bits = __builtin_bit_cast(uint16_t, (_Float16)f);
+#else
+    r.bits = (uint16_t)vc_f32_to_half_bits(f);
+#endif
+    return r;
+}
+// the two elements of a packed pair (element 0 in the low half) / packing two
+VC_HD float vc_lo16_f32(uint32_t u) {
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(vc_h2_hw, u).x;
+#else
+    return vc_half_bits_to_f32(u & 0xFFFFu);
+#endif
+}
+VC_HD float vc_hi16_f32(uint32_t u) {
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    return (float)__builtin_bit_cast(vc_h2_hw, u).y;
+#else
+    return vc_half_bits_to_f32(u >> 16);
+#endif
+}
+VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) {
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    const vc_f2_hw v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vc_h2_hw));               // v_cvt_pk_f16_f32
+#else
+    return vc_f32_to_half_bits(lo) | (vc_f32_to_half_bits(hi) << 16);
+#endif
+}
+#else
 VC_HD float vc_bf16_to_f32(vc_bf16 h) {
     uint32_t u = ((uint32_t)h.bits) << 16;
     float f;
@@ -261,6 +344,10 @@ VC_HD vc_bf16 vc_f32_to_bf16(float f) {     // round-to-nearest-even; NaN stays 
     r.bits = (uint16_t)(u >> 16);
     return r;
 }
+VC_HD float vc_lo16_f32(uint32_t u) { return vc_bits_f32(u << 16); }
+VC_HD float vc_hi16_f32(uint32_t u) { return vc_bits_f32(u & 0xFFFF0000u); }
+VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
+#endif
 
 template <typename T> struct vc_cvt;
 template <> struct vc_cvt<float> {
@@ -271,8 +358,6 @@ template <> struct vc_cvt<vc_bf16> {
     VC_HD static float to_f32(vc_bf16 v) { return vc_bf16_to_f32(v); }
     VC_HD static vc_bf16 from_f32(float v) { return vc_f32_to_bf16(v); }
 };
-VC_HD float vc_bits_f32(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
-VC_HD uint32_t vc_f32_bits(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 // pre-split bf16x3 operand word (gemm.h): hi bf16 in the upper half, lo = bf16(x - hi) in the lower
 struct vc_pk { uint32_t w; };
 VC_HD uint32_t vc_pk_pack(float x) {
@@ -299,7 +384,6 @@ VC_DEV float vc_wave_max(float v) {
 
 struct alignas(16) vc_u32x4 { uint32_t x, y, z, w; };   // 16-byte POD for vector copies
 struct alignas(8) vc_u32x2 { uint32_t x, y; };
-VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
 
 // ---- OCP fp8 e4m3 (no infinities, NaN = 0x7f / 0xff, max 448) — software codec for the emulator build and the host
 VC_HD float vc_e4m3_to_f32(uint8_t v) {

@@ -32,7 +32,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class NativeEngine:
     def __init__(self, cfg: L.Config, device):
-        self.lib = L.load()
+        self.lib = L.load(L.storage_format(cfg.dtype))
         self.cfg = cfg
         self.device = torch.device(device)
         h = C.c_void_p()
@@ -69,7 +69,7 @@ class NativeEngine:
         self.params = params.to(self.device) if params is not None else z()
         self.grads, self.m, self.v = z(), z(), z()
         # bf16: bf16 copy of the weights; bf16x3: the weights pre-split into hi | lo bf16 words (same 4 bytes per element); f32: none
-        self.shadow = z(torch.bfloat16) if self.cfg.dtype == L.VCAD_BF16 else (z(torch.int32) if self.cfg.dtype == L.VCAD_BF16X3 else None)
+        self.shadow = {L.VCAD_BF16: lambda: z(torch.bfloat16), L.VCAD_F16: lambda: z(torch.float16), L.VCAD_BF16X3: lambda: z(torch.int32)}.get(self.cfg.dtype, lambda: None)()
         self.ws = None
         self._bind()
 
@@ -100,6 +100,25 @@ class NativeEngine:
         only, backward unchanged.  The workspace is re-planned on the next forward."""
         L.check(self.lib, self.lib.vcad_set_fp8(self.h, 1 if on else 0), "set_fp8")
         self.fp8 = bool(on)
+
+    # ------------------------------------------------------------------ gradient scale (fp16 engines; include/vcad.h: vcad_set_grad_scale)
+    @property
+    def grad_scale(self) -> float:
+        return float(self.lib.vcad_grad_scale(self.h))
+
+    def set_grad_scale(self, scale: float):
+        """a power of two; the backward runs on scaled gradients, the gradient buffer holds true ones.  Re-plans the workspace on the next forward."""
+        L.check(self.lib, self.lib.vcad_set_grad_scale(self.h, float(scale)), "set_grad_scale")
+
+    def check_grad_overflow(self, norm: torch.Tensor) -> bool:
+        """fp16 engines: `norm` = what optimizer_step returned some steps ago.  A non-finite gradient norm means the scaled backward overflowed fp16 (the
+        library skipped that update): halve the scale.  Host sync on `norm` — call it every few dozen steps, not every step."""
+        if self.cfg.dtype != L.VCAD_F16 or norm is None:
+            return False
+        bad = not bool(torch.isfinite(norm[0]).item())
+        if bad and self.grad_scale > 1.0:
+            self.set_grad_scale(self.grad_scale / 2)
+        return bad
 
     def set_dropout(self, p: float, seed: int = 0):
         """p = 0 disables; call with a fresh seed before every training forward (masks = hash(seed, site, index))."""

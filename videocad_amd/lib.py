@@ -10,8 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvcad_hip.so")
+# the same sources built with fp16 as the 16-bit storage format (include/vcad.h: vcad_storage_format) — VCAD_F16 engines
+LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libvcad_hip_f16.so")
 
-VCAD_F32, VCAD_BF16, VCAD_BF16X3 = 0, 1, 2
+VCAD_F32, VCAD_BF16, VCAD_BF16X3, VCAD_F16 = 0, 1, 2, 3
 # kernel-selection flags (include/vcad.h VCAD_GEMM_*; tests only) and kernel families (vcad_kernel_launches / vcad_op_gemm kernel_out)
 GEMM_TILE64, GEMM_TILE128, GEMM_DMA_NEVER, GEMM_DMA_ALWAYS, GEMM_WIDE_NEVER, GEMM_WIDE_ALWAYS, GEMM_MID_NEVER, GEMM_MID_ALWAYS = 1, 2, 4, 8, 16, 32, 64, 128
 GEMM_DYNAMIC = 1 << 16
@@ -45,6 +47,9 @@ _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 PROTOTYPES = {
     "vcad_last_error": (C.c_char_p, []),
     "vcad_version": (C.c_char_p, []),
+    "vcad_storage_format": (C.c_char_p, []),
+    "vcad_set_grad_scale": (_i, [_vp, _f]),
+    "vcad_grad_scale": (_f, [_vp]),
     "vcad_engine_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
     "vcad_engine_destroy": (None, [_vp]),
     "vcad_param_total": (_i64, [_vp]),
@@ -115,18 +120,35 @@ def declare(lib):
 
 
 _lib = None
+_lib_f16 = None
 
 
-def load():
-    """Load the HIP library; fail loudly (no CPU fallback)."""
-    global _lib
-    if _lib is None:
+def load(fmt: str = "bf16"):
+    """Load the HIP library that stores `fmt` ("bf16": libvcad_hip.so, "f16": libvcad_hip_f16.so); fail loudly (no CPU fallback)."""
+    global _lib, _lib_f16
+    if fmt not in ("bf16", "f16"):
+        raise ValueError(f"storage format {fmt!r}: expected 'bf16' or 'f16'")
+    cur = _lib if fmt == "bf16" else _lib_f16
+    if cur is None:
         import torch  # noqa: F401  (first: the library must bind to the HIP runtime torch ships, not load a second one from /opt/rocm)
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C videocad_amd/csrc` "
+        path = LIB_PATH if fmt == "bf16" else LIB_PATH_F16
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `make -C videocad_amd/csrc` "
                                "(the VideoCAD MI355X path has no CPU fallback)")
-        _lib = declare(C.CDLL(LIB_PATH))
-    return _lib
+        cur = declare(C.CDLL(path))
+        got = cur.vcad_storage_format().decode()
+        if got != fmt:
+            raise RuntimeError(f"{path} stores {got!r}, expected {fmt!r}: rebuild with `make -C videocad_amd/csrc`")
+        if fmt == "bf16":
+            _lib = cur
+        else:
+            _lib_f16 = cur
+    return cur
+
+
+def storage_format(dtype: int) -> str:
+    """which build of the library an engine of this dtype runs on"""
+    return "f16" if dtype == VCAD_F16 else "bf16"
 
 
 def load_ab():

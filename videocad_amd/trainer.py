@@ -433,9 +433,16 @@ class BaseTrainer:
         cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"], inputs.get("multiview_images") if self.native.num_views > 0 else None)
         out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
         self.gradsync.backward()
-        eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
-                           grad_scale=1.0 / self.gradsync.world)
+        norm = eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
+                                  grad_scale=1.0 / self.gradsync.world)
         self.native.mark_shadow_fresh()
+        if eng.cfg.dtype == L.VCAD_F16:
+            # fp16 engines: an overflowed backward leaves a non-finite gradient norm (the library skipped that update).  Looked at 32 steps late, so the
+            # host never waits for the step it just enqueued; every rank sees the same all-reduced gradients, hence the same norms and the same scale.
+            self._norm_ring = getattr(self, "_norm_ring", [])
+            self._norm_ring.append(norm)
+            if len(self._norm_ring) > 32 and eng.check_grad_overflow(self._norm_ring.pop(0)):
+                self._norm_ring.clear()
         return out[0], met
 
     def _class_w(self):
