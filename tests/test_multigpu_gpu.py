@@ -113,7 +113,7 @@ def test_bench_gpus_2_starts_two_rccl_ranks():
     assert j["n_gpus"] == 2 and j["comm"]["rccl_ranks"] == 2 and j["config"]["global_batch"] == 4 and j["scaling"] == "weak"
 
 
-def _one_rank_main(port, tmp, q, no_side):
+def _one_rank_main(port, tmp, q, no_side, dtype="bf16"):
     import torch.distributed as dist
     from videocad_amd.model_factory import ModelFactory
     from videocad_amd.trainer import create_trainer
@@ -125,7 +125,7 @@ def _one_rank_main(port, tmp, q, no_side):
     try:
         out = {}
         for forced in (False, True):
-            model, mtype = ModelFactory().create_model("autoregressive", dict(CANON, compute_dtype="bf16"), dev)
+            model, mtype = ModelFactory().create_model("autoregressive", dict(CANON, compute_dtype=dtype), dev)
             model.load_state_dict({k: synth.make_param_torch(k, s, dev) for k, s in O.param_shapes().items()}, strict=True)
             model.train()
             pk = {"loader": [], "sampler": None}
@@ -152,15 +152,15 @@ def _one_rank_main(port, tmp, q, no_side):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("no_side", [False, True])
-def test_bucketed_exchange_on_a_one_rank_rccl_group_is_bitwise_the_plain_step(tmp_path, no_side):
+@pytest.mark.parametrize("no_side,dtype", [(False, "bf16"), (True, "bf16"), (False, "f16")])
+def test_bucketed_exchange_on_a_one_rank_rccl_group_is_bitwise_the_plain_step(tmp_path, no_side, dtype):
     """What a 1-GPU box can say about a17: the whole multi-stream choreography of GradSync (staged backward, side-stream stage, communication
     stream, per-bucket `ncclAllReduce` through RCCL — a one-rank group, so each collective is RCCL's local copy kernel) runs on the device and
     leaves exactly the gradients and weights of the plain single-call step; the per-collective issue / completion report is well formed."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_one_rank_main, args=(29800 + (os.getpid() % 1000) + int(no_side), str(tmp_path), q, no_side))
+    p = ctx.Process(target=_one_rank_main, args=(29800 + (os.getpid() % 1000) + int(no_side) + 2 * (dtype == "f16"), str(tmp_path), q, no_side, dtype))
     p.start(); p.join(timeout=600)
     assert p.exitcode == 0
     rep = q.get(timeout=5)

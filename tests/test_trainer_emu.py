@@ -358,3 +358,35 @@ def test_enable_profiling_writes_torch_profiler_traces(emu, tmp_path, monkeypatc
     tr.train(1)
     d = os.path.join("logs", "p", "profile_traces", "epoch0", "rank0")
     assert os.path.isdir(d) and any(f.endswith(".json") or f.endswith(".json.gz") for f in os.listdir(d)), os.listdir(d) if os.path.isdir(d) else d
+
+
+def test_f16_model_through_the_reference_surface(tmp_path, monkeypatch):
+    """compute_dtype='f16' (the fp16-storage build of the library) behind the same factory / trainer surface: the autograd bridge hands torch TRUE
+    gradients (the gradient scale never leaves the library), the native train step matches them, master weights and the state_dict stay fp32."""
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), "class_weights.json")
+    with U.emulated("f16") as emu16:
+        cfg, ocfg = small(compute_dtype="f16", vit_depth=2)
+        model, mtype, shapes = make_model(cfg, ocfg)
+        eng = model._engine
+        assert eng.lib is emu16 and eng.cfg.dtype == L.VCAD_F16 and eng.shadow.dtype == torch.float16 and eng.grad_scale == 4096.0
+        assert all(v.dtype == torch.float32 for v in model.state_dict().values())
+        model.eval()
+        nb, tb = tbatch(1, 2, 4)
+        pk = {"loader": [tb], "sampler": None}
+        tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t16"}, "cpu", mtype, rank=0)
+        ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in shapes.items()}, ocfg)
+        oloss, ometrics, ocmds, opars = ot.loss_and_grads(nb)
+        bd = tr.prepare_batch(tb)
+        preds = model(tr._prepare_model_inputs(bd, False))
+        assert U.relerr(preds[1], opars) < 4e-3
+        loss, _ = tr.compute_loss(preds, bd["actions"][:, 1:])
+        loss.backward()
+        errs = sorted(U.relerr(p.grad, ot.P[n].grad) for n, p in model.named_parameters() if float(ot.P[n].grad.norm()) > 0)
+        assert errs[len(errs) // 2] < 4e-3 and errs[-1] < 0.05, (errs[len(errs) // 2], errs[-1])
+        g_bridge = eng.grads.clone()
+        w0 = eng.params.clone()
+        loss2, _ = tr._process_batch(tb)                     # the fused native step on the same batch: same gradients, then Adam
+        assert abs(float(loss2) - float(oloss)) < 2e-3 * abs(float(oloss))
+        assert U.relerr(eng.grads, g_bridge) < 1e-6 and not torch.equal(eng.params, w0)
+        assert len(tr._norm_ring) == 1 and bool(torch.isfinite(tr._norm_ring[0][0]))

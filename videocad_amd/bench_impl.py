@@ -203,6 +203,11 @@ def short_leg(dtype, fp8, B, T, steps, warmup, device, rank, world, seed, dropou
            "ms_per_step_median": round(float(np.median(per)), 3), "steps": steps, "warmup": warmup, "loss": float(loss.item())}
     if parity is not None:
         out["parity"] = parity
+    if dtype == "f16" and rank == 0 and world == 1:          # the in-tolerance leg gets its own roofline block (same fields as the headline's, no PMC traffic)
+        try:
+            out["roofline"] = profile_step(tr, bd, dtype, B, T, B * T / (e / steps))[1]
+        except Exception as ex:
+            out["roofline"] = {"error": repr(ex)}
     del tr, model, bd
     torch.cuda.empty_cache()
     return out
