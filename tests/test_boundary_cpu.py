@@ -170,13 +170,15 @@ def _q_get(q, procs, timeout=900):
     raise AssertionError("workers timed out")
 
 
-def _ddp_worker(rank, world, port, tmp, q, wrap=False):
+def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32"):
     import torch.distributed as dist
     _cwd_with_class_weights(tmp)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         L._lib = U.load_emu()                        # this process only ever runs the emulator build
         cfg, ocfg = small_model(None)
+        if dtype == "f16":
+            L._lib_f16 = U.load_emu("f16"); cfg = dict(cfg, compute_dtype="f16")
         torch.manual_seed(1234 + rank)               # every rank draws DIFFERENT initial weights (the reference seeds nothing) ...
         model, mtype = ModelFactory().create_model("autoregressive", cfg, "cpu")
         shapes = O.param_shapes(ocfg)
@@ -214,7 +216,10 @@ def _ddp_worker(rank, world, port, tmp, q, wrap=False):
             assert all(p.grad is None for p in model.parameters())
             if rank == 0:                                                       # the summed gradient itself (Adam's first step hides a doubled gradient)
                 q.put({"__grads__": {n: eng.view(n, eng.grads).detach().clone().numpy() for n in shapes}})
-        if rank == 0:
+        if dtype == "f16" and rank == 0:
+            eng = native._engine
+            q.put({"__grads__": {n: eng.view(n, eng.grads).detach().clone().numpy() for n in shapes}, "scale": eng.grad_scale})
+        elif rank == 0:
             q.put({n: p.detach().clone().numpy() for n, p in native.named_parameters()})
         dist.barrier()
     finally:
@@ -293,3 +298,30 @@ def test_gloo_data_parallel_step_matches_mean_of_gradients(tmp_path, world):
             worst_noise = (n, float(diff[~sig].max()))
     assert worst_sig[1] < 2e-6, worst_sig
     assert worst_noise[1] <= 2.1e-5, worst_noise
+
+
+def test_gloo_data_parallel_step_on_the_fp16_build(tmp_path):
+    """two ranks over gloo, kernels of the fp16-storage build under the emulator: what the collectives sum is the TRUE gradient of each rank (every bucket is
+    divided by the gradient scale before it is handed over), so the flat buffer holds the sum of the two ranks' oracle gradients at fp16 accuracy"""
+    import torch.multiprocessing as mp
+    U.load_emu(); U.load_emu("f16")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 11
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q, False, "f16")) for r in range(world)]
+    [p.start() for p in procs]
+    got = _q_get(q, procs)
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got["scale"] == 4096.0
+    _, ocfg = small_model(None)
+    shapes = O.param_shapes(ocfg)
+    ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in shapes.items()}, ocfg)
+    gsum = None
+    for r in range(world):
+        ot.loss_and_grads(synth.make_batch(1, 2, seed=10 + r))
+        g = {k: p.grad.clone() for k, p in ot.P.items()}
+        gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
+    errs = sorted((U.relerr(torch.from_numpy(got["__grads__"][n]), gsum[n]), n) for n in gsum if float(gsum[n].norm()) > 1e-6)
+    assert errs[len(errs) // 2][0] < 4e-3 and errs[-1][0] < 0.05, (errs[len(errs) // 2], errs[-1])
