@@ -74,8 +74,9 @@ def test_reference_style_loop_through_autograd_f32(golden_dir, tmp_path):
     assert not torch.equal(p2, pars)
 
 
-def test_bf16_trainer_runs(tmp_path):
-    model, tr = make("bf16", tmp_path)
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_bf16_trainer_runs(tmp_path, dtype):
+    model, tr = make(dtype, tmp_path)
     model.train()           # dropout 0.1 active: the train loop of the reference
     batch = synth.make_batch_torch(2, 6, 5, "cpu")
     l0, _ = tr._process_batch(batch)
@@ -84,7 +85,7 @@ def test_bf16_trainer_runs(tmp_path):
     assert torch.isfinite(l1) and float(l1) < float(l0) + 1e-3          # lr 1e-5: loss must not blow up
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 3e-2), ("f16", 1e-3)])
 def test_cached_sequential_inference_matches_oracle_prefix_runs(tmp_path, dtype, tol):
     """f1 (reference model/autoregressive_transformer.py:222-275): step t of the cached run == last row of the ORACLE's forward
     on the prefix [0..t] — what the reference's O(T^2) loop computes — and the literal loop (cached=False) agrees too."""
@@ -98,11 +99,12 @@ def test_cached_sequential_inference_matches_oracle_prefix_runs(tmp_path, dtype,
     for t in range(T):
         with torch.no_grad():
             oc, op = O.model_forward(P, frames[:, : t + 1].cpu(), torch.zeros(B, t + 1, 7), cad.cpu())[:2]
-        assert U.relerr(pars[:, t], op[:, -1]) < tol and U.relerr(cmds[:, t], oc[:, -1]) < tol, (t, U.relerr(pars[:, t], op[:, -1]))
-        if dtype == "f32":
+        # (the command logits of one step are ten numbers: their norm-wise error scatters around the 12 000-element parameter logits' — 2.5x for fp16's gate)
+        assert U.relerr(pars[:, t], op[:, -1]) < tol and U.relerr(cmds[:, t], oc[:, -1]) < tol * (2.5 if dtype == "f16" else 1.0), (t, U.relerr(pars[:, t], op[:, -1]), U.relerr(cmds[:, t], oc[:, -1]))
+        if dtype != "bf16":
             assert torch.equal(pars[:, t].argmax(-1).cpu(), op[:, -1].argmax(-1))
     c0, p0 = model.sequential_inference(frames, cad, action=False, cached=False)
-    assert U.relerr(p0, pars) < (2e-5 if dtype == "f32" else 2e-2)
+    assert U.relerr(p0, pars) < {"f32": 2e-5, "bf16": 2e-2, "f16": 2.5e-3}[dtype]
     # action feedback: equals ONE teacher-forced oracle forward on the actions the run fed itself
     c2, p2 = model.sequential_inference(frames, cad, action=True)
     fed = [torch.zeros(B, 1, 7, device=DEV)]
@@ -110,7 +112,7 @@ def test_cached_sequential_inference_matches_oracle_prefix_runs(tmp_path, dtype,
         fed.append(model._next_action(c2[:, t:t + 1], p2[:, t:t + 1]))
     with torch.no_grad():
         oc, op = O.model_forward(P, frames.cpu(), torch.cat(fed, 1).cpu(), cad.cpu())[:2]
-    assert U.relerr(p2, op) < tol and U.relerr(c2, oc) < tol
+    assert U.relerr(p2, op) < tol and U.relerr(c2, oc) < tol * (2.5 if dtype == "f16" else 1.0)
 
 
 def test_uint8_input_path_is_bit_identical_and_staged_from_pinned_memory(tmp_path):
