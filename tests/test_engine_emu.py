@@ -429,3 +429,6 @@ def test_engine_f16_step_against_oracle_and_gradient_scale(emu16):
     norm = eng.optimizer_step(lr=1e-3)
     assert bool(torch.isfinite(norm[0])) and not torch.equal(eng.params, before) and not eng.check_grad_overflow(norm)
     assert torch.equal(eng.shadow.float(), eng.params.to(torch.float16).float())          # the fp16 weight copy follows the update
+    # a lowered scale climbs back to the default after 2 000 finite norms in a row (host logic; no kernels involved)
+    eng.set_grad_scale(1024.0); eng._good_norms = 1998
+    assert not eng.check_grad_overflow(norm) and eng.grad_scale == 1024.0 and not eng.check_grad_overflow(norm) and eng.grad_scale == 2048.0

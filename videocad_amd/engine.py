@@ -116,8 +116,15 @@ class NativeEngine:
         if self.cfg.dtype != L.VCAD_F16 or norm is None:
             return False
         bad = not bool(torch.isfinite(norm[0]).item())
-        if bad and self.grad_scale > 1.0:
-            self.set_grad_scale(self.grad_scale / 2)
+        if bad:
+            self._good_norms = 0
+            if self.grad_scale > 1.0:
+                self.set_grad_scale(self.grad_scale / 2)
+        else:
+            # 2 000 finite norms in a row: back up towards the default (a scale lowered by one outlier batch should not stay low for the rest of the run)
+            self._good_norms = getattr(self, "_good_norms", 0) + 1
+            if self._good_norms >= 2000 and self.grad_scale < 4096.0:
+                self.set_grad_scale(self.grad_scale * 2); self._good_norms = 0
         return bad
 
     def set_dropout(self, p: float, seed: int = 0):
