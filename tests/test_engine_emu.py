@@ -393,10 +393,10 @@ def _f16_grads(eng, batch, scale=None):
 
 
 def test_engine_f16_step_against_oracle_and_gradient_scale(emu16):
-    """The fp16 build of the engine sources (tests/emu/libvcad_emu_f16.so), train mode, three ViT layers: forward and every gradient against the oracle fed
+    """The fp16 build of the engine sources (tests/emu/libvcad_emu_f16.so), train mode, two ViT layers: forward and every gradient against the oracle fed
     the same masks, at an eighth of the bf16 tolerances; the gradient buffer holds TRUE gradients whatever the (power-of-two) gradient scale — the scale
     only decides what underflows inside the backward; an overflowing scale leaves a non-finite norm and an untouched model."""
-    cfg = small_cfg(vit_depth=3, num_decoder_layers=1)
+    cfg = small_cfg(vit_depth=2, num_decoder_layers=1)
     eng, weights = build(cfg, L.VCAD_F16, emu16)
     assert eng.lib is emu16 and eng.shadow.dtype == torch.float16 and eng.grad_scale == 4096.0
     eng.set_gemm_flags(L.GEMM_DMA_ALWAYS | L.GEMM_DYNAMIC)
