@@ -2,6 +2,10 @@
 // (split while staging) against fp32 or pre-split weights.  The all-pre-split forms live in ops_gemm_x3b.hip (own translation unit: they compile in parallel).
 #include "gemm_launch.h"
 
+#ifdef VC_H16     // bf16-only mode: the fp16-storage build (libvcad_hip_f16.so) carries the entry point, not the kernels
+int vc_gemm_launch_x3(GemmCall, int, int, vc_stream_t) { vc_set_error("vc_gemm: bf16x3 exists in the bf16 build only"); return VC_ERR_UNSUPPORTED; }
+#else
+
 int vc_gemm_launch_x3_pk(GemmCall c, int nsplit, int lay, vc_stream_t s);      // sa == VC_PK (ops_gemm_x3b.hip)
 
 int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s) {
@@ -19,3 +23,4 @@ int vc_gemm_launch_x3(GemmCall c, int nsplit, int lay, vc_stream_t s) {
         default: return gemm_launch<vc_x3, float, float, float, true, true>(c, nsplit, s);
     }
 }
+#endif

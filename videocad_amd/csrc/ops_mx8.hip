@@ -2,6 +2,11 @@
 #include "ops.h"
 #include "gemm_mx8.h"
 
+#ifdef VC_H16     // bf16-only mode: the fp16-storage build (libvcad_hip_f16.so) carries the entry point, not the kernels
+int vc_mx8_quant(int, const void*, long, uint8_t*, uint8_t*, long, int, vc_stream_t) { vc_set_error("vc_mx8_quant: the fp8 forward exists in the bf16 build only"); return VC_ERR_UNSUPPORTED; }
+int vc_gemm_mx8(Mx8Params, int, vc_stream_t) { vc_set_error("vc_gemm_mx8: the fp8 forward exists in the bf16 build only"); return VC_ERR_UNSUPPORTED; }
+#else
+
 int vc_mx8_quant(int tx, const void* x, long ld, uint8_t* q, uint8_t* sc, long rows, int cols, vc_stream_t s) {
     if (rows <= 0) return VC_OK;
     if (cols % 32) { vc_set_error("mx8_quant: cols %d is not a multiple of the 32-element block", cols); return VC_ERR_ARG; }
@@ -41,3 +46,4 @@ int vc_gemm_mx8(Mx8Params q, int to, vc_stream_t s) {
     ProfScope ps(VC_CAT_GEMM_FWD, 2.0 * p.M * p.N * p.K, (double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (to == VC_BF16 ? 2 : 4), s);
     return to == VC_BF16 ? mx8_launch<vc_bf16>(q, s) : mx8_launch<float>(q, s);
 }
+#endif
