@@ -346,7 +346,18 @@ VC_HD vc_bf16 vc_f32_to_bf16(float f) {     // round-to-nearest-even; NaN stays 
 }
 VC_HD float vc_lo16_f32(uint32_t u) { return vc_bits_f32(u << 16); }
 VC_HD float vc_hi16_f32(uint32_t u) { return vc_bits_f32(u & 0xFFFF0000u); }
-VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) { return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16); }
+VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) {
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+    // one v_cvt_pk_bf16_f32 on exactly this pair (two scalar conversions leave the pairing to the vectoriser: it packed (v0, v2) / (v1, v3) of the
+    // persistent GEMM's store quads and spent four more VALU per store re-sorting the halves)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 h2 __attribute__((ext_vector_type(2)));
+    const f2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
+#else
+    return (uint32_t)vc_f32_to_bf16(lo).bits | ((uint32_t)vc_f32_to_bf16(hi).bits << 16);
+#endif
+}
 #endif
 
 template <typename T> struct vc_cvt;
