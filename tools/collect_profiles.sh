@@ -21,8 +21,12 @@ timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYC
 # the other quoted shapes / modes: per-kernel stats only
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_t186 -o t186 -- python $R/bench.py --profile-only --batch 16 --seq 186 --steps 6 --warmup 2 > $OUT/bench_t186.json 2> $OUT/bench_t186.err
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x3 -o x3 -- python $R/bench.py --profile-only --dtype bf16x3 --steps 3 --warmup 1 > $OUT/bench_x3.json 2> $OUT/bench_x3.err
+# the fp16-storage build (libvcad_hip_f16.so): per-kernel stats + matrix-core occupancy of the same step
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_f16 -o f16 -- python $R/bench.py --profile-only --dtype f16 --steps 6 --warmup 2 > $OUT/bench_f16.json 2> $OUT/bench_f16.err
+timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_MFMA_f16 -o pmc -- python $R/bench.py --dtype f16 --steps 1 --warmup 1 --profile-only > $OUT/pmc_MFMA_f16.json 2> $OUT/pmc_MFMA_f16.err
 cd $R
 python tools/summarize_profiles.py $TAG > $OUT/summary.md 2> $OUT/summary.err
 python tools/kernel_stats_table.py $OUT/trace_t186/t186_kernel_stats.csv "seq_len 186, 16 clips (BASELINE configs[3] per-GPU shape), bf16" > $OUT/t186_kernel_stats.txt 2>> $OUT/summary.err
 python tools/kernel_stats_table.py $OUT/trace_x3/x3_kernel_stats.csv "C2 (32 clips x 64 steps), bf16x3" > $OUT/x3_kernel_stats.txt 2>> $OUT/summary.err
+python tools/kernel_stats_table.py $OUT/trace_f16/f16_kernel_stats.csv "C2 (32 clips x 64 steps), f16 (libvcad_hip_f16.so)" > $OUT/f16_kernel_stats.txt 2>> $OUT/summary.err
 tail -1 $OUT/bench_default.json | cut -c1-400

@@ -88,29 +88,34 @@ if pmc:
 
 
 # ---- matrix-core occupancy per kernel IN THE MODEL (pmc_MFMA pass): busy cycles of the MFMA pipes / (kernel-active cycles x 1024 SIMDs)
-path = os.path.join(base, "pmc_MFMA", "pmc_counter_collection.csv")
-if os.path.exists(path):
-    per = collections.defaultdict(lambda: collections.defaultdict(float))
-    calls = collections.Counter()
-    seen = set()
-    for row in csv.DictReader(open(path)):
-        k = short(row["Kernel_Name"])
-        if "at::native" in row["Kernel_Name"] or "rocclr" in row["Kernel_Name"]:
-            continue
-        per[k][row["Counter_Name"]] += float(row["Counter_Value"])
-        if (k, row["Dispatch_Id"]) not in seen:
-            seen.add((k, row["Dispatch_Id"])); calls[k] += 1
-    rows_ = []
-    for k, v in per.items():
-        act = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                      # summed over the 8 XCDs
-        if act <= 0 or v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
-            continue
-        rows_.append((act, k, v["SQ_VALU_MFMA_BUSY_CYCLES"] / (act * 256 * 4), calls[k]))
-    tot_act = sum(r[0] for r in rows_)
-    print("\n## matrix-core occupancy in the model (PMC pass over `bench.py --steps 1 --warmup 1 --profile-only`; SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))\n")
-    print("| kernel | launches in the pass | share of MFMA-kernel time | MFMA busy |\n|---|---|---|---|")
-    for act, k, u, n in sorted(rows_, reverse=True)[:16]:
-        print(f"| `{k}` | {n} | {100 * act / tot_act:.1f} % | {u:.3f} |")
-    dma = [r for r in rows_ if r[1].startswith("gemm_dma_kernel")]
-    if dma:
-        print(f"\n`gemm_dma_kernel` family, time-weighted: {sum(r[0] * r[2] for r in dma) / sum(r[0] for r in dma):.3f}")
+def mfma_table(dirname, what):
+  path = os.path.join(base, dirname, "pmc_counter_collection.csv")
+  if os.path.exists(path):
+      per = collections.defaultdict(lambda: collections.defaultdict(float))
+      calls = collections.Counter()
+      seen = set()
+      for row in csv.DictReader(open(path)):
+          k = short(row["Kernel_Name"])
+          if "at::native" in row["Kernel_Name"] or "rocclr" in row["Kernel_Name"]:
+              continue
+          per[k][row["Counter_Name"]] += float(row["Counter_Value"])
+          if (k, row["Dispatch_Id"]) not in seen:
+              seen.add((k, row["Dispatch_Id"])); calls[k] += 1
+      rows_ = []
+      for k, v in per.items():
+          act = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0                      # summed over the 8 XCDs
+          if act <= 0 or v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
+              continue
+          rows_.append((act, k, v["SQ_VALU_MFMA_BUSY_CYCLES"] / (act * 256 * 4), calls[k]))
+      tot_act = sum(r[0] for r in rows_)
+      print(f"\n## matrix-core occupancy in the model{what} (PMC pass over `bench.py --steps 1 --warmup 1 --profile-only`; SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))\n")
+      print("| kernel | launches in the pass | share of MFMA-kernel time | MFMA busy |\n|---|---|---|---|")
+      for act, k, u, n in sorted(rows_, reverse=True)[:16]:
+          print(f"| `{k}` | {n} | {100 * act / tot_act:.1f} % | {u:.3f} |")
+      dma = [r for r in rows_ if r[1].startswith("gemm_dma_kernel")]
+      if dma:
+          print(f"\n`gemm_dma_kernel` family, time-weighted: {sum(r[0] * r[2] for r in dma) / sum(r[0] for r in dma):.3f}")
+
+
+mfma_table("pmc_MFMA", "")
+mfma_table("pmc_MFMA_f16", ", fp16-storage build (--dtype f16)")
