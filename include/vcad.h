@@ -82,11 +82,13 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * attention / to_out / feed-forward dropouts, TransformerDecoderLayer dropout, dropout1-3 and attention dropout).
  * p = 0 disables (model.eval()).  Masks are a stateless hash of (seed, site, element index): set a fresh seed before every
  * training forward; the backward of that forward regenerates the same masks.  No mask tensors are stored. */
-/* Gradient scale of the backward (VCAD_F16 engines: default 4096; every other engine: 1 = off).  A power of two in [1, 2^24]: vcad_backward* multiplies the
- * incoming dlogits by it (into a private copy) and divides each gradient bucket by it — exactly — when the bucket is complete, before the bucket callback:
- * the gradient buffer, the callback and vcad_optimizer_step* only ever see true gradients.  A gradient that overflows fp16 anyway shows up as a non-finite
+/* Gradient scale of the backward.  VCAD_F16 engines start in AUTOMATIC mode (scale = 0): each plan sets the scale to 2 x the next power of two >= B * T (the loss
+ * is a mean over B * T rows, so the scaled dlogits have the magnitudes of a one-row batch whatever the batch size: 4096 at 32 x 64), floor 1024, cap 2^20.
+ * Every other engine: 1 = off.  A value names the scale: a power of two in [1, 2^24].  vcad_backward* multiplies the incoming dlogits by it (into a private
+ * copy) and divides each gradient bucket by it — exactly — when the bucket is complete, before the bucket callback: the gradient buffer, the callback and
+ * vcad_optimizer_step* only ever see true gradients.  A gradient that overflows fp16 anyway shows up as a non-finite
  * gradient norm: vcad_optimizer_step* then leaves weights and moments untouched (norm_out[0] is inf / NaN); halve the scale and go on.
- * Changes the workspace plan: call before the next forward. */
+ * Re-plans the workspace: call before the next forward.  vcad_grad_scale: the value in force (after a plan in automatic mode: that plan's). */
 int vcad_set_grad_scale(vcad_engine* e, float scale);
 float vcad_grad_scale(const vcad_engine* e);
 

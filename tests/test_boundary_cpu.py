@@ -314,7 +314,7 @@ def test_gloo_data_parallel_step_on_the_fp16_build(tmp_path):
     got = _q_get(q, procs)
     [p.join(timeout=300) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert got["scale"] == 4096.0
+    assert got["scale"] == 1024.0                       # automatic gradient scale: 2 x pow2ceil(B * T), floor 1024 (two rows here; 4096 at the benchmark's 2 048)
     _, ocfg = small_model(None)
     shapes = O.param_shapes(ocfg)
     ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in shapes.items()}, ocfg)

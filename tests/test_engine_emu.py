@@ -406,7 +406,7 @@ def test_engine_f16_step_against_oracle_and_gradient_scale(emu16):
     ot = O.OracleTrainer(weights, cfg)
     ot.masks = engine_masks(eng, cfg, B, T)
     oloss, _, ocmds, opars = ot.loss_and_grads(batch)
-    cmds, pars, g4096 = _f16_grads(eng, batch)
+    cmds, pars, g4096 = _f16_grads(eng, batch, 4096.0)
     assert U.relerr(pars, opars) < 4e-3 and U.relerr(cmds, ocmds) < 4e-3, (U.relerr(pars, opars), U.relerr(cmds, ocmds))
     errs = {}
     for k in weights:
@@ -414,9 +414,11 @@ def test_engine_f16_step_against_oracle_and_gradient_scale(emu16):
         if og is not None and float(og.norm()) > 0:
             errs[k] = float((g - og).norm()) / float(og.norm())
     assert sorted(errs.values())[len(errs) // 2] < 4e-3 and max(errs.values()) < 0.04, max(errs.items(), key=lambda kv: kv[1])
-    # another scale: same gradients up to what rounds differently inside the backward
+    # another scale: same gradients up to what rounds differently inside the backward; 0 = automatic: 2 x pow2ceil(B * T), floor 1024
     _, _, g256 = _f16_grads(eng, batch, 256.0)
     assert U.relerr(g256, g4096) < 2e-3, U.relerr(g256, g4096)
+    _, _, gauto = _f16_grads(eng, batch, 0.0)
+    assert eng.grad_scale == 1024.0 and U.relerr(gauto, g4096) < 2e-3
     with pytest.raises(RuntimeError, match="power of two"):
         eng.set_grad_scale(1000.0)
     # 2^24 x dlogits of O(0.1) overflows fp16: non-finite gradients, the update is skipped, the host halves the scale

@@ -103,6 +103,7 @@ def test_full_size_step_f16_in_tolerance_and_train_mode_sane(name, B, T):
     frames, actions, cad = FS.tiled(ref["batch"], K)
     an = O.normalize_actions(actions[:, :-1])
     cmds, pars = eng.forward(frames[:, :-1], an, cad)
+    assert eng.grad_scale == {"C2": 4096.0, "C4_per_gpu": 8192.0, "C3": 16384.0}[name]      # automatic: 2 x pow2ceil(B * T)
     p = pars[:2].cpu()
     rel, mae = U.relerr(p, ref["pars"]), float((p - ref["pars"]).abs().mean())
     rel_c = U.relerr(cmds[:2].cpu(), ref["cmds"])

@@ -93,6 +93,7 @@ struct vcad_engine {
     // fp16 build: the backward runs on gradients multiplied by grad_scale (a power of two: dlogits are scaled into dls_* on entry, every gradient bucket is
     // divided again — exactly — by the launch that finalises it), so that activation gradients of 1e-6..1e-8 stay inside fp16's normal range.  1 = off.
     float grad_scale = 1.0f; float *dls_cmds = nullptr, *dls_pars = nullptr;
+    bool grad_scale_auto = false;      // fp16 engines until vcad_set_grad_scale names a value: the scale follows the planned batch (plan())
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
     float drop_p = 0.f; uint64_t drop_seed = 0;
@@ -297,7 +298,13 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     const long nlog = (long)c.num_params * c.num_params_values;
     e->dl_cmds = b.take<float>(M * c.num_classes * 4); e->dl_pars = b.take<float>(M * nlog * 4);
     e->dls_cmds = e->dls_pars = nullptr;
-    if (e->grad_scale != 1.0f) { e->dls_cmds = b.take<float>(M * c.num_classes * 4); e->dls_pars = b.take<float>(M * nlog * 4); }
+    if (e->grad_scale_auto) {
+        // the loss is a mean over M = B * T rows: 2 * 2^ceil(log2 M) undoes that factor, so the scaled dlogits — and everything behind them — have the
+        // magnitudes of a one-row batch whatever the batch size (4096 at the benchmark's 2 048 rows); floor 1024 for small batches
+        float a = 2.0f; while (a < 2.0f * (float)M && a < 1048576.0f) a *= 2.0f;
+        e->grad_scale = a < 1024.0f ? 1024.0f : a;
+    }
+    if (e->grad_scale != 1.0f || e->grad_scale_auto) { e->dls_cmds = b.take<float>(M * c.num_classes * 4); e->dls_pars = b.take<float>(M * nlog * 4); }
     e->norm_part = b.take<float>(1024 * 4); e->norm_out = b.take<float>(8 * 4);
     e->wT = nullptr; e->wT_jobs.clear(); e->wT_fresh = false;
     if (e->dt == VC_BF16 && c.enable_past_states) {
@@ -964,8 +971,10 @@ const char* vcad_storage_format(void) { return VC_S16_NAME; }
 // the bucket is complete, so the gradient buffer always holds true gradients.  Changes the workspace plan: call before the next forward.
 int vcad_set_grad_scale(vcad_engine* e, float scale) {
     int ex = 0;
-    if (!(scale >= 1.0f) || frexpf(scale, &ex) != 0.5f || scale > 16777216.0f) { vc_set_error("vcad_set_grad_scale: %g is not a power of two in [1, 2^24]", (double)scale); return VC_ERR_ARG; }
-    if (scale != e->grad_scale) { e->grad_scale = scale; e->planned_ws = nullptr; e->B = e->T = 0; e->fwd_valid = false; e->infer_T = 0; }
+    if (scale != 0.0f && (!(scale >= 1.0f) || frexpf(scale, &ex) != 0.5f || scale > 16777216.0f)) { vc_set_error("vcad_set_grad_scale: %g is neither 0 (automatic) nor a power of two in [1, 2^24]", (double)scale); return VC_ERR_ARG; }
+    e->grad_scale_auto = scale == 0.0f;
+    if (scale != 0.0f) e->grad_scale = scale;
+    e->planned_ws = nullptr; e->B = e->T = 0; e->fwd_valid = false; e->infer_T = 0;          // (the plan holds the scaled dlogits copies and, in automatic mode, fixes the value)
     return 0;
 }
 float vcad_grad_scale(const vcad_engine* e) { return e->grad_scale; }
@@ -997,7 +1006,7 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     vcad_engine* e = new vcad_engine();
     e->c = *cfg; e->dt = s16 ? VC_BF16 : VC_F32; e->ct = cfg->dtype == VCAD_BF16X3 ? VC_X3 : e->dt; e->esz = s16 ? 2 : 4;
 #ifdef VC_H16
-    if (s16) e->grad_scale = 4096.0f;          // default gradient scale of fp16 engines (vcad_set_grad_scale)
+    if (s16) { e->grad_scale = 4096.0f; e->grad_scale_auto = true; }          // fp16 engines: automatic gradient scale (vcad_set_grad_scale), 4096 until the first plan
 #endif
     if (cfg->vit_depth < 1 || cfg->num_decoder_layers < 1) { vc_set_error("vit_depth / num_decoder_layers must be >= 1"); delete e; return VC_ERR_ARG; }
     build_params(e);

@@ -107,7 +107,8 @@ class NativeEngine:
         return float(self.lib.vcad_grad_scale(self.h))
 
     def set_grad_scale(self, scale: float):
-        """a power of two; the backward runs on scaled gradients, the gradient buffer holds true ones.  Re-plans the workspace on the next forward."""
+        """a power of two, or 0 = automatic (fp16 engines' default: follows the planned batch, 4096 at 32 x 64); the backward runs on scaled gradients, the
+        gradient buffer holds true ones.  Re-plans the workspace on the next forward."""
         L.check(self.lib, self.lib.vcad_set_grad_scale(self.h, float(scale)), "set_grad_scale")
 
     def check_grad_overflow(self, norm: torch.Tensor) -> bool:
@@ -118,12 +119,15 @@ class NativeEngine:
         bad = not bool(torch.isfinite(norm[0]).item())
         if bad:
             self._good_norms = 0
+            if getattr(self, "_scale_target", None) is None:
+                self._scale_target = self.grad_scale                 # (what the automatic rule chose for this batch shape)
             if self.grad_scale > 1.0:
-                self.set_grad_scale(self.grad_scale / 2)
+                self.set_grad_scale(self.grad_scale / 2)             # explicit from here on
         else:
-            # 2 000 finite norms in a row: back up towards the default (a scale lowered by one outlier batch should not stay low for the rest of the run)
+            # 2 000 finite norms in a row: back up towards where it started (a scale lowered by one outlier batch should not stay low for the rest of the run)
             self._good_norms = getattr(self, "_good_norms", 0) + 1
-            if self._good_norms >= 2000 and self.grad_scale < 4096.0:
+            target = getattr(self, "_scale_target", None) or 4096.0
+            if self._good_norms >= 2000 and self.grad_scale < target:
                 self.set_grad_scale(self.grad_scale * 2); self._good_norms = 0
         return bad
 
