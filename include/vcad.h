@@ -30,7 +30,7 @@ extern "C" {
 enum { VCAD_F32 = 0, VCAD_BF16 = 1, VCAD_BF16X3 = 2, VCAD_F16 = 3 };
 
 /* The 16-bit storage format is a build-time property of the kernel library: libvcad_hip.so stores bf16 (VCAD_BF16, VCAD_BF16X3, VCAD_F32 engines),
- * libvcad_hip_f16.so — the same sources compiled with -DVC_H16, the same entry points — stores IEEE fp16 (VCAD_F16, VCAD_F32 engines): the kernels,
+ * libvcad_hip_f16.so — the same sources compiled with -DVC_H16, the same entry points — stores IEEE fp16 (VCAD_F16 engines): the kernels,
  * tensors and MFMA rate of VCAD_BF16 with 10 mantissa bits instead of 7 (logits within 1e-3 of the fp32 reference), and a gradient scale that
  * keeps the backward inside fp16's exponent range (vcad_set_grad_scale).  Each library rejects the other's dtypes.  "bf16" / "f16": */
 const char* vcad_storage_format(void);

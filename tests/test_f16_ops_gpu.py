@@ -83,7 +83,7 @@ def test_bf16_only_modes_are_rejected(hip):
     import ctypes as C
     keys = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
             "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size")
-    for lib, bad in ((hip, L.VCAD_BF16), (hip, L.VCAD_BF16X3), (L.load("bf16"), L.VCAD_F16)):
+    for lib, bad in ((hip, L.VCAD_BF16), (hip, L.VCAD_BF16X3), (hip, L.VCAD_F32), (L.load("bf16"), L.VCAD_F16)):
         cfg = make_config(dtype=bad, **{k: O.CANONICAL_CONFIG[k] for k in keys})
         h = C.c_void_p()
         assert lib.vcad_engine_create(C.byref(cfg), C.byref(h)) != 0

@@ -982,7 +982,7 @@ float vcad_grad_scale(const vcad_engine* e) { return e->grad_scale; }
 int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (!cfg || !out) { vc_set_error("null argument"); return VC_ERR_ARG; }
 #ifdef VC_H16
-    if (cfg->dtype != VCAD_F32 && cfg->dtype != VCAD_F16) { vc_set_error("dtype %d: this build of the library stores fp16 (VCAD_F16, VCAD_F32); the bf16 modes are in libvcad_hip.so", cfg->dtype); return VC_ERR_ARG; }
+    if (cfg->dtype != VCAD_F16) { vc_set_error("dtype %d: this build of the library runs VCAD_F16 engines (fp16 storage); every other mode is in libvcad_hip.so", cfg->dtype); return VC_ERR_ARG; }
     const bool s16 = cfg->dtype == VCAD_F16;
 #else
     if (cfg->dtype == VCAD_F16) { vc_set_error("VCAD_F16: this build of the library stores bf16; the fp16 build is libvcad_hip_f16.so"); return VC_ERR_ARG; }
