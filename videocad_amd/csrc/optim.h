@@ -10,9 +10,17 @@
 VC_KERNEL __launch_bounds__(256) void sumsq_stage1_kernel(const float* g, long n, float* partial) {
     VC_SHARED float red[256];
     float s = 0.f;
+    // one 16-byte load per thread and trip (the per-element bound check of the first version made these four 4-byte loads at a 16-byte lane stride: 2.8 TB/s);
+    // same elements per thread in the same order, so the sum is bit-identical
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const vc_u32x4 q = *reinterpret_cast<const vc_u32x4*>(g + i);
+            const float v4[4] = {vc_bits_f32(q.x), vc_bits_f32(q.y), vc_bits_f32(q.z), vc_bits_f32(q.w)};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (i + j < n) { float v = g[i + j]; s += v * v; }
+            for (int j = 0; j < 4; ++j) { float v = v4[j]; s += v * v; }
+        } else {
+            for (int j = 0; j < 4; ++j) if (i + j < n) { float v = g[i + j]; s += v * v; }
+        }
     }
     red[threadIdx.x] = s;
     vc_sync();
