@@ -107,6 +107,25 @@ def test_bench_line_single_gpu_contract():
     assert j["kernel_breakdown"]["attention"]["GBps"] and j["parity"]["argmax_agreement"] >= 0.97 and j["parity"]["logit_mae"] < 1.1e-2 and j["parity"]["rel_err"] < 6e-3          # ~1.5x measured (7.2e-3, 3.9e-3; one near-tie of 96 arg-maxes may flip with the kernel mix)
 
 
+def test_bench_in_tolerance_block_is_the_fastest_mode_inside_the_gate():
+    """at the headline shape the line carries `in_tolerance`: the fastest measured mode whose own parity block meets north_star's gate (logits within 1e-3
+    of the reference's goldens, arg-max exact) — the fp16-storage build, at about the headline's speed; bf16x3 and f32 are the slower candidates"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-seq186", "--no-pcie"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    it = j["in_tolerance"]
+    assert it["dtype"] == "f16" and it["rel_err"] < 1e-3 and it["argmax_agreement"] == 1.0 and it["cmd_argmax_agreement"] == 1.0, it
+    assert it["value"] > 0.9 * j["value"] and j["dtype"] == "bf16" and j["parity"]["rel_err"] > 1e-3, (it["value"], j["value"])     # the headline stays BASELINE's dtype
+    assert set(it["candidates"]) >= {"f16", "bf16x3"} and it["candidates"]["bf16x3"]["value"] < it["value"]
+    assert j["modes"]["f16"]["roofline"]["bound"] == "mfma" and it["seq_len_186"]["value"] > 0
+
+
 @two_gpus
 def test_bench_gpus_2_starts_two_rccl_ranks():
     j = _bench(["--gpus", "2"])
