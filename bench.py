@@ -41,6 +41,8 @@ def main(argv=None):
     ap.add_argument("--uint8-frames", action="store_true", help="feed uint8 grayscale pixels (normalised inside the patchify kernel) instead of fp32 frames")
     ap.add_argument("--no-modes", action="store_true", help="skip the short bf16x3 / f32 / fp8 legs reported beside the headline (each with its parity block)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive (pinned host -> HBM staged) measurement reported beside the headline")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "half"], help="N > 1: gradient buckets on the wire in fp32 (reference) or in the library's 16-bit storage format")
+    ap.add_argument("--grad-exchange", default="all_reduce", choices=["all_reduce", "rs_ag", "auto"], help="N > 1: one all_reduce per bucket, or reduce_scatter + all_gather (auto: buckets >= 32 MB)")
     ap.add_argument("--profile-only", action="store_true", help="rocprofv3 runs: only the headline workload's train steps (no seq-186 / PCIe / parity / CPU-baseline legs)")
     args = ap.parse_args(argv)
     if args.profile_only:

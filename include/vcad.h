@@ -88,6 +88,7 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * copy) and divides each gradient bucket by it — exactly — when the bucket is complete, before the bucket callback: the gradient buffer, the callback and
  * vcad_optimizer_step* only ever see true gradients.  A gradient that overflows fp16 anyway shows up as a non-finite
  * gradient norm: vcad_optimizer_step* then leaves weights and moments untouched (norm_out[0] is inf / NaN); halve the scale and go on.
+ * External dlogits handed to vcad_backward* need 4-byte alignment only (a 16-byte aligned pointer takes the vector copy).
  * Re-plans the workspace: call before the next forward.  vcad_grad_scale: the value in force (after a plan in automatic mode: that plan's). */
 int vcad_set_grad_scale(vcad_engine* e, float scale);
 float vcad_grad_scale(const vcad_engine* e);
@@ -165,9 +166,25 @@ int vcad_set_bucket_callback(vcad_engine* e, vcad_bucket_ready_fn fn, void* user
 int vcad_backward_stage_side(vcad_engine* e, int stage, const float* dcmds, const float* dparams, void* stream);
 int vcad_join_side(vcad_engine* e, void* stream);
 
+/* ---- half-precision WIRE FORMAT for the gradient exchange (r05; optional — the reference's DDP buckets are fp32, experiment.py:104-109):
+ * a finished range [lo, hi) of the flat fp32 gradient buffer (lo % 4 == 0) is copied into a caller-owned buffer of 16-bit elements in THIS LIBRARY'S
+ * storage format (vcad_storage_format(): bf16, or IEEE half in libvcad_hip_f16.so), summed over ranks there (ncclAllReduce / ReduceScatter with
+ * ncclBfloat16 / ncclHalf) and copied back: half the xGMI bytes.  bf16 has fp32's exponent range: pass amax = NULL.  fp16 does not:
+ *   vcad_wire_amax   writes max |g| of the range to amax_out[0] (amax_out: DEVICE, 1 + 1024 floats — the rest is reduction scratch; a NaN
+ *                    gradient gives 3.4e38); the caller all-reduces that one float with MAX over the ranks;
+ *   vcad_wire_pack   multiplies by 2^floor(log2(32768 / (world * amax))) — the sum over `world` ranks cannot overflow — while converting;
+ *   vcad_wire_unpack divides by the same power of two (recomputed from the same device scalar) while converting back.
+ * Each rank's addend is rounded to 8 (bf16) / 11 (fp16) significant bits and the collective accumulates in that format: expect ~4e-3 / ~5e-4
+ * norm-wise on the summed bucket (tests/test_boundary_cpu.py bounds it).  All three only enqueue kernels on `stream`. */
+int vcad_wire_amax(vcad_engine* e, int64_t lo, int64_t hi, float* amax_out, void* stream);
+int vcad_wire_pack(vcad_engine* e, int64_t lo, int64_t hi, void* wire16, const float* amax, int world, void* stream);
+int vcad_wire_unpack(vcad_engine* e, int64_t lo, int64_t hi, const void* wire16, const float* amax, int world, void* stream);
+
 /* ---- clip_grad_norm_(max_norm) + Adam.step (reference trainer.py:493-494); step = 1-based Adam step count;
- * grad_scale multiplies gradients first (1/world_size after an all-reduce SUM); norm_out: fp32 [2] = |g|, clip coef.  A non-finite |g| skips the update
- * (weights, moments and shadow stay as they are). */
+ * grad_scale multiplies gradients first (1/world_size after an all-reduce SUM); norm_out: fp32 [2] = |g|, clip coef.  VCAD_F16 engines only: a non-finite |g|
+ * (the scaled backward overflowed fp16) skips the update — weights, moments and shadow stay as they are; the caller should then not count the
+ * step (pass the same `step` again next time) and lower the scale (vcad_set_grad_scale).  Every other dtype does what the reference's
+ * clip_grad_norm_ + Adam do with a non-finite gradient: it propagates into the weights and the run fails loudly. */
 int vcad_optimizer_step(vcad_engine* e, float lr, float beta1, float beta2, float eps, float max_norm, int step,
                         float grad_scale, float* norm_out, void* stream);
 

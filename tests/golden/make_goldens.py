@@ -156,6 +156,67 @@ def multiview_case(scratch):
     return {"config": cfg_name, "B": B, "T": T, "seed": seed, "num_views": rcfg["num_views"], "oracle_vs_reference": dev}
 
 
+def config_step_case(case, cfg_name, B, T, seed, scratch):
+    """r05: ONE full train step of the IMPORTED reference on another shipped configuration — logits, loss, metrics, every
+    gradient norm, the clip norm and post-Adam slices — for `cad_past_10_actions_and_states_large` (nhead 8: decoder head dim 128,
+    /root/reference/model_configs/transformer_experiments.json:146) and `..._large_multiview_only` (nhead 8, num_views 3, :165).  The oracle is
+    checked against the reference on the same step (recorded in meta.json) before the vectors are written."""
+    rcfg = json.load(open(os.path.join(HERE, "model_configs.json")))[cfg_name]
+    V = rcfg.get("num_views", 0)
+    ocfg = dict(O.CANONICAL_CONFIG); ocfg.update(nhead=rcfg["nhead"], num_views=V, window_size=rcfg["window_size"])
+    wts = {k: synth.make_param(k, s) for k, s in O.param_shapes(ocfg).items()}
+    modelx, mkx, _ = build_reference(cfg_name, wts, scratch)
+    trx = mkx(True)
+    batch_np = synth.make_batch(B, T, seed, num_views=V) if V else synth.make_batch(B, T, seed)
+    batch = tbatch(batch_np)
+    modelx.eval()
+    with torch.no_grad():
+        bd = trx.prepare_batch(batch)
+        cmds, params = modelx(trx._prepare_model_inputs(bd, False))
+    gradsx = {}
+    orig_clip = torch.nn.utils.clip_grad_norm_
+    def spyx(parameters, max_norm, *a, **k):
+        for n, p in modelx.named_parameters():
+            if p.grad is not None and n in wts:
+                gradsx[n] = p.grad.detach().clone()
+        out = orig_clip(modelx.parameters(), max_norm, *a, **k)
+        gradsx["__total_norm__"] = out.detach().clone()
+        return out
+    torch.nn.utils.clip_grad_norm_ = spyx
+    loss_s, metrics = trx._process_batch(batch)
+    torch.nn.utils.clip_grad_norm_ = orig_clip
+    post = {k: v.detach().clone() for k, v in modelx.state_dict().items() if k in wts}
+    ot = O.OracleTrainer(wts, ocfg)
+    oloss, ometrics, ototal, ocmds, oparams = ot.step(batch_np)
+    live = sorted(k for k in gradsx if k != "__total_norm__")
+    olive = sorted(k for k, p in ot.P.items() if p.grad is not None)
+    dev = {"cmds_rel": rel(ocmds, cmds), "params_rel": rel(oparams, params), "loss_abs": abs(float(oloss) - float(loss_s)),
+           "argmax_equal": bool((oparams.argmax(-1) == params.argmax(-1)).all() and (ocmds.argmax(-1) == cmds.argmax(-1)).all()),
+           "live_sets_equal": live == olive, "metrics_equal": ometrics == metrics,
+           "total_norm_rel": abs(ototal - float(gradsx["__total_norm__"])) / float(gradsx["__total_norm__"]),
+           "grad_rel_max": max(rel(ot.P[k].grad, gradsx[k]) for k in live if gradsx[k].norm() > 0),
+           "post_adam_maxabs": max(float((ot.P[k].detach() - post[k]).abs().max()) for k in live)}
+    print(case, json.dumps(dev))
+    assert dev["cmds_rel"] < 1e-5 and dev["params_rel"] < 1e-5 and dev["argmax_equal"] and dev["live_sets_equal"] and dev["metrics_equal"], dev
+    assert dev["grad_rel_max"] < 1e-3 and dev["post_adam_maxabs"] < 2e-6, dev
+    top2 = params.topk(2, dim=-1).values
+    out = {"cmds": cmds.numpy(), "params": params[:, :, :, ::8].numpy().copy(), "params_argmax": params.argmax(-1).numpy(),
+           "cmds_argmax": cmds.argmax(-1).numpy(), "loss": np.float32(loss_s.item()),
+           "total_grad_norm": np.float32(gradsx["__total_norm__"].item()), "grad_names": np.array(live),
+           "grad_norms": np.array([float(gradsx[k].double().norm()) for k in live], dtype=np.float64),
+           "metrics_json": np.array(json.dumps(metrics))}
+    slices = [k for k in SLICE_TENSORS if k in gradsx] + [k for k in ("embed_multiview.weight",) if k in gradsx]
+    for k in slices:
+        out["gslice:" + k] = sl(gradsx[k]); out["pslice:" + k] = sl(post[k])
+    np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)
+    return {"config": cfg_name, "B": B, "T": T, "seed": seed, "nhead": rcfg["nhead"], "num_views": V, "lengths": None,
+            "min_top2_gap_params": float((top2[..., 0] - top2[..., 1]).min()), "oracle_vs_reference": dev}
+
+
+NHEAD8_CASES = [("nhead8_large", "cad_past_10_actions_and_states_large", 2, 8, 21),
+                ("nhead8_multiview3", "cad_past_10_actions_and_states_large_multiview_only", 2, 6, 22)]
+
+
 def main():
     if "--only-multiview" in sys.argv:                  # tests/golden/multiview_2.npz alone (the full run writes the same file)
         scratch = tempfile.mkdtemp(prefix="vcad_golden_")
@@ -163,6 +224,16 @@ def main():
         os.chdir(scratch)
         info = multiview_case(scratch)
         meta = json.load(open(os.path.join(HERE, "meta.json"))); meta["cases"]["multiview_2"] = info
+        json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+    if "--only-nhead8" in sys.argv:                     # tests/golden/nhead8_*.npz alone (the full run writes the same files)
+        scratch = tempfile.mkdtemp(prefix="vcad_golden_")
+        shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
+        os.chdir(scratch)
+        meta = json.load(open(os.path.join(HERE, "meta.json")))
+        for case, cfg_name, B, T, seed in NHEAD8_CASES:
+            meta["cases"][case] = config_step_case(case, cfg_name, B, T, seed, scratch)
         json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
         shutil.rmtree(scratch, ignore_errors=True)
         return
@@ -374,6 +445,8 @@ def main():
     # ------------------------------------------------------------------ evaluation bookkeeping of the reference trainer
     meta["cases"]["eval_cases"] = eval_cases(model, mk, weights)
     meta["cases"]["multiview_2"] = multiview_case(scratch)
+    for case, cfg_name, B, T, seed in NHEAD8_CASES:
+        meta["cases"][case] = config_step_case(case, cfg_name, B, T, seed, scratch)
 
     # ------------------------------------------------------------------ loss-only cases on synthetic logits
     tr = mk(True); trn = mk(False)

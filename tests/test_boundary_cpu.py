@@ -170,7 +170,7 @@ def _q_get(q, procs, timeout=900):
     raise AssertionError("workers timed out")
 
 
-def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32"):
+def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32", extra=None):
     import torch.distributed as dist
     _cwd_with_class_weights(tmp)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -199,7 +199,7 @@ def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32"):
         batch = synth.make_batch(1, 2, seed=10 + rank)
         tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
         pk = {"loader": [tb], "sampler": None}
-        tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, "cpu", mtype, rank=rank)
+        tr = create_trainer(pk, pk, pk, model, dict({"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, **(extra or {})), "cpu", mtype, rank=rank)
         assert tr.gradsync.world == world
         assert native._engine.gemm_flags & L.GEMM_DYNAMIC, "data-parallel runs draw the persistent GEMM's items with tickets (RCCL holds CUs)"
         # GradSync's constructor broadcast rank 0's parameters (what the DDP wrap did in the reference, experiment.py:104-109)
@@ -216,7 +216,11 @@ def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32"):
             assert all(p.grad is None for p in model.parameters())
             if rank == 0:                                                       # the summed gradient itself (Adam's first step hides a doubled gradient)
                 q.put({"__grads__": {n: eng.view(n, eng.grads).detach().clone().numpy() for n in shapes}})
-        if dtype == "f16" and rank == 0:
+        if extra and rank == 0:                      # exchange variants: the summed gradient buffer itself + how many collectives carried it
+            eng = native._engine
+            q.put({"__flat__": eng.grads.detach().clone().numpy(), "collectives": tr.gradsync.collectives, "wire": str(eng.wire_dtype),
+                   "plans": [tr.gradsync.plan(lo, hi)[1] for lo, hi in eng.buckets], "buckets": list(eng.buckets)})
+        elif dtype == "f16" and rank == 0:
             eng = native._engine
             q.put({"__grads__": {n: eng.view(n, eng.grads).detach().clone().numpy() for n in shapes}, "scale": eng.grad_scale})
         elif rank == 0:
@@ -325,3 +329,50 @@ def test_gloo_data_parallel_step_on_the_fp16_build(tmp_path):
         gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
     errs = sorted((U.relerr(torch.from_numpy(got["__grads__"][n]), gsum[n]), n) for n in gsum if float(gsum[n].norm()) > 1e-6)
     assert errs[len(errs) // 2][0] < 4e-3 and errs[-1][0] < 0.05, (errs[len(errs) // 2], errs[-1])
+
+
+def _run_exchange(tmp_path, world, dtype, extra, tag):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 40 + tag
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q, False, dtype, extra)) for r in range(world)]
+    [p.start() for p in procs]
+    got = _q_get(q, procs)
+    [p.join(timeout=300) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    return got
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_gloo_exchange_variants_bound_the_change_in_the_summed_gradient(tmp_path, dtype):
+    """r05: the two knobs of GradSync on a 2-rank gloo group, kernels under the emulator — against the default exchange
+    (fp32 buckets, one all_reduce(SUM) each: what the reference's DDP does, experiment.py:104-109) on the same ranks and batches:
+      grad_exchange = "rs_ag": reduce_scatter + all_gather of every bucket — the SAME sums (two addends per element: bit-identical);
+      grad_wire = "half": buckets travel in the library's 16-bit storage format — bf16 for the bf16 / f32 library (8 significant bits per addend
+        and for the sum), fp16 with a power-of-two scale from the all-reduced max |g| for the fp16 library (11 bits): the norm-wise change of the
+        summed gradient buffer is bounded at 6e-3 / 8e-4, per bucket too; with "auto" only buckets of at least grad_rs_min_mb take rs_ag."""
+    U.load_emu()
+    if dtype == "f16":
+        U.load_emu("f16")
+    base = _run_exchange(tmp_path, 2, dtype, {"grad_wire": "fp32", "grad_exchange": "all_reduce", "experiment_name": "x0"}, 0)
+    nb = len(base["plans"])
+    assert base["collectives"] == nb and set(base["plans"]) == {"all_reduce"}
+    ref = torch.from_numpy(base["__flat__"])
+    assert float(ref.norm()) > 0
+    rs = _run_exchange(tmp_path, 2, dtype, {"grad_wire": "fp32", "grad_exchange": "rs_ag", "experiment_name": "x1"}, 1)
+    assert rs["collectives"] == 2 * nb and set(rs["plans"]) == {"rs_ag"}
+    assert torch.equal(torch.from_numpy(rs["__flat__"]), ref)
+    half = _run_exchange(tmp_path, 2, dtype, {"grad_wire": "half", "grad_exchange": "auto", "grad_rs_min_mb": 20.0, "experiment_name": "x2"}, 2)
+    assert half["wire"] == ("torch.float16" if dtype == "f16" else "torch.bfloat16")
+    assert "rs_ag" in half["plans"] and "all_reduce" in half["plans"]          # the big bucket takes rs_ag, the small ones all_reduce
+    extra = nb if dtype == "f16" else 0                                          # (fp16: one 4-byte MAX all-reduce per bucket fixes its scale)
+    assert half["collectives"] == nb + half["plans"].count("rs_ag") + extra
+    got = torch.from_numpy(half["__flat__"])
+    tol = 8e-4 if dtype == "f16" else 6e-3
+    assert U.relerr(got, ref) < tol, U.relerr(got, ref)
+    assert bool(torch.isfinite(got).all())
+    # per bucket as well: a small-magnitude bucket must not drown in a scale chosen for a large one (the scale is per exchanged range)
+    for lo, hi in half["buckets"]:
+        if float(ref[lo:hi].norm()) > 0:
+            assert U.relerr(got[lo:hi], ref[lo:hi]) < 2 * tol, (lo, hi, U.relerr(got[lo:hi], ref[lo:hi]))

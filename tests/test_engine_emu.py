@@ -434,3 +434,25 @@ def test_engine_f16_step_against_oracle_and_gradient_scale(emu16):
     # a lowered scale climbs back to the default after 2 000 finite norms in a row (host logic; no kernels involved)
     eng.set_grad_scale(1024.0); eng._good_norms = 1998
     assert not eng.check_grad_overflow(norm) and eng.grad_scale == 1024.0 and not eng.check_grad_overflow(norm) and eng.grad_scale == 2048.0
+    # a skipped update does not advance Adam's bias-correction step; reaching the remembered target returns the engine to automatic mode
+    eng._scale_target = 4096.0; eng.step_count = 10
+    assert eng.note_overflows(2, 32) and eng.step_count == 8 and eng.grad_scale == 1024.0 and eng._scale_target == 4096.0
+    assert not eng.note_overflows(0, 2000) and eng.grad_scale == 2048.0 and eng._scale_target == 4096.0
+    assert not eng.note_overflows(0, 2000) and eng._scale_target is None
+    _f16_grads(eng, batch, None)
+    assert eng.grad_scale == 1024.0              # automatic again: 2 x pow2ceil(B T) with its floor, not the 4096 it had been lowered from
+
+
+def test_f16_scale_of_an_engine_that_never_overflowed_stays_automatic(emu16):
+    """r04's host logic doubled the scale of ANY fp16 engine up to 4096 after 2 000 finite norms, leaving automatic mode for good
+    (a small-batch engine starts at the 1024 floor).  Growth now needs an overflow to have lowered the scale first."""
+    cfg = small_cfg()
+    eng, _ = build(cfg, L.VCAD_F16, emu16)
+    batch = synth.make_batch(2, 3, seed=8)
+    _f16_grads(eng, batch, None)
+    assert eng.grad_scale == 1024.0
+    norm = eng.optimizer_step(lr=1e-5)
+    for _ in range(3):
+        assert not eng.note_overflows(0, 2000)
+    assert not eng.check_grad_overflow(norm)
+    assert eng.grad_scale == 1024.0 and getattr(eng, "_scale_target", None) is None and eng.step_count == 1

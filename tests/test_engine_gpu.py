@@ -411,6 +411,64 @@ def test_multiview_branch_matches_reference_goldens(golden_dir, dtype, tol, gtol
         assert torch.equal(pa_, pb) and torch.equal(ca, cb)
 
 
+NHEAD8_MODES = [("f32", 1e-4, 2e-3), ("f16", 1e-3, 8e-3), ("bf16x3", 1e-4, 3e-3), ("bf16", 8e-3, 6e-2)]
+
+
+@pytest.mark.parametrize("mode,tol,gtol", NHEAD8_MODES, ids=[m[0] for m in NHEAD8_MODES])
+@pytest.mark.parametrize("case", ["nhead8_large", "nhead8_multiview3"])
+def test_nhead8_configs_full_step_matches_reference_goldens(golden_dir, case, mode, tol, gtol):
+    """r05: `cad_past_10_actions_and_states_large` (nhead 8 -> decoder head dim 128) and `..._large_multiview_only` (nhead 8,
+    num_views 3: the CAD tower runs B (1 + 3) images, embed_multiview is [1024, 1536]) — reference model_configs/transformer_experiments.json:146,165 —
+    against ONE FULL TRAIN STEP of the imported reference (tests/golden/nhead8_*.npz): logits, arg-max, loss, metrics, every gradient norm,
+    sampled gradient elements, the clip norm and the post-Adam weights, through the C ABI.  f32: 1e-4 / exact arg-max; f16: north_star's 1e-3 /
+    exact arg-max; bf16x3 like f32; bf16 (the throughput mode) measured and gated at its own level."""
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["cases"][case]
+    gold = np.load(os.path.join(golden_dir, case + ".npz"))
+    V = meta["num_views"]
+    dtype = {"f32": L.VCAD_F32, "f16": L.VCAD_F16, "bf16x3": L.VCAD_BF16X3, "bf16": L.VCAD_BF16}[mode]
+    cfg = dict(O.CANONICAL_CONFIG); cfg.update(nhead=meta["nhead"], num_views=V)
+    eng = NativeEngine(make_config(dtype=dtype, **{k: cfg[k] for k in CFG_KEYS + ("num_views",)}), DEV)
+    shapes = O.param_shapes(cfg)
+    assert set(eng.table) == set(shapes)
+    for k, sh in shapes.items():
+        eng.view(k).copy_(synth.make_param_torch(k, sh, DEV))
+    eng.sync_shadow()
+    batch = synth.make_batch_torch(meta["B"], meta["T"], meta["seed"], DEV, None, num_views=V) if V else synth.make_batch_torch(meta["B"], meta["T"], meta["seed"], DEV, None)
+    frames, actions, cad, mv = batch["frames"], batch["actions"], batch["cad_image"], batch.get("multiview_images")
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad, mv) if V else eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    gc = torch.from_numpy(gold["cmds"]).to(DEV); gp = torch.from_numpy(gold["params"]).to(DEV)
+    rel_c, rel_p = U.relerr(cmds, gc), U.relerr(pars[:, :, :, ::8], gp)
+    agree = float((pars.argmax(-1).cpu().numpy() == gold["params_argmax"]).mean())
+    print(f"\n[measured {mode} {case}] logits rel cmd {rel_c:.3e} params {rel_p:.3e}  arg-max agreement {agree:.5f}")
+    assert rel_c < tol * (2.5 if mode == "f16" else 1.0) and rel_p < tol, (rel_c, rel_p)
+    if mode != "bf16":
+        assert agree == 1.0 and np.array_equal(cmds.argmax(-1).cpu().numpy(), gold["cmds_argmax"])
+    else:
+        assert agree >= 0.95, agree
+    loss, met = eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    assert abs(float(loss[0]) - float(gold["loss"])) < {"f32": 1e-4, "bf16x3": 1e-4, "f16": 1e-3, "bf16": 2e-2}[mode] * abs(float(gold["loss"]))
+    if mode in ("f32", "bf16x3"):
+        from videocad_amd.trainer import metrics_from_counters
+        assert metrics_from_counters(met.tolist()) == json.loads(str(gold["metrics_json"]))
+    eng.backward()
+    live = [str(n) for n in gold["grad_names"]]
+    assert set(live) == set(shapes)
+    rels = [abs(float(eng.view(n, eng.grads).double().norm()) - gn) / (gn + 1e-12) for n, gn in zip(live, gold["grad_norms"])]
+    print(f"[measured {mode} {case}] grad-norm rel err: median {np.median(rels):.3e} max {np.max(rels):.3e}")
+    assert np.max(rels) < gtol * (4 if mode == "bf16" else 1) and np.median(rels) < gtol / (1 if mode in ("f32", "bf16") else 3), (np.median(rels), np.max(rels), live[int(np.argmax(rels))])
+    if mode == "f32":
+        for k in gold.files:
+            if k.startswith("gslice:"):
+                ref = gold[k]; got = sl(eng.view(k[len("gslice:"):], eng.grads))
+                assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-9, k
+    norm = eng.optimizer_step(lr=1e-5)
+    assert abs(float(norm[0]) - float(gold["total_grad_norm"])) < {"f32": 1e-3, "bf16x3": 1e-3, "f16": 4e-3, "bf16": 3e-2}[mode] * float(gold["total_grad_norm"])
+    if mode in ("f32", "bf16x3"):
+        for k in gold.files:
+            if k.startswith("pslice:"):
+                assert np.abs(sl(eng.view(k[len("pslice:"):])) - gold[k]).max() < 2e-6, k
+
+
 def test_staged_backward_with_side_stream_is_bitwise_the_whole_backward():
     """The data-parallel order (stages 0-1, the CAD ViT's stage on the side stream, the frame ViT's stages, join) must produce exactly the
     gradients of the single-call backward: same kernels, only the stream they are issued on differs."""

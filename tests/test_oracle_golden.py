@@ -136,3 +136,30 @@ def test_oracle_multiview_branch_matches_reference_goldens():
     assert live == [str(n) for n in g["grad_names"]] and "embed_multiview.weight" in live
     for n, gn in zip(live, g["grad_norms"]):
         assert abs(float(ot.P[n].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-10, n
+
+
+@pytest.mark.parametrize("case", ["nhead8_large", "nhead8_multiview3"])
+def test_oracle_nhead8_configs_match_reference_goldens(case):
+    """r05: the reference's other shipped head / view shapes — `cad_past_10_actions_and_states_large` (nhead 8: decoder head dim 128) and
+    `..._large_multiview_only` (nhead 8, num_views 3; /root/reference/model_configs/transformer_experiments.json:146,165) — one FULL train step of
+    the imported reference (make_goldens.py: config_step_case): logits, arg-max, loss, metrics, every gradient norm, clip norm, post-Adam slices."""
+    meta = json.load(open(os.path.join(GOLD, "meta.json")))["cases"][case]
+    g = np.load(os.path.join(GOLD, case + ".npz"))
+    V = meta["num_views"]
+    cfg = dict(O.CANONICAL_CONFIG); cfg.update(nhead=meta["nhead"], num_views=V)
+    ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in O.param_shapes(cfg).items()}, cfg)
+    batch = synth.make_batch(meta["B"], meta["T"], meta["seed"], num_views=V) if V else synth.make_batch(meta["B"], meta["T"], meta["seed"])
+    loss, metrics, total, cmds, params = ot.step(batch)
+    ref = torch.from_numpy(g["params"])
+    assert float((params[:, :, :, ::8] - ref).norm() / ref.norm()) < 5e-6
+    assert float((cmds - torch.from_numpy(g["cmds"])).norm() / torch.from_numpy(g["cmds"]).norm()) < 5e-6
+    assert np.array_equal(params.argmax(-1).numpy(), g["params_argmax"]) and np.array_equal(cmds.argmax(-1).numpy(), g["cmds_argmax"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"])) and metrics == json.loads(str(g["metrics_json"]))
+    assert abs(total - float(g["total_grad_norm"])) < 1e-4 * float(g["total_grad_norm"])
+    live = sorted(k for k, p in ot.P.items() if p.grad is not None)
+    assert live == [str(n) for n in g["grad_names"]] and ("embed_multiview.weight" in live) == (V > 0)
+    for n, gn in zip(live, g["grad_norms"]):
+        assert abs(float(ot.P[n].grad.double().norm()) - gn) <= 1e-4 * gn + 1e-10, n
+    for k in g.files:
+        if k.startswith("pslice:"):
+            assert np.abs(sl(ot.P[k[len("pslice:"):]]) - g[k]).max() < 1e-6, k

@@ -308,6 +308,34 @@ def test_frozen_mode_groups_round_trip_through_the_reference_layout(emu, tmp_pat
                                                   dict(other["param_groups"][2], params=other["param_groups"][2]["params"] + cad[len(cad) // 2:])]}
     with pytest.raises(ValueError):
         tr2.optimizer.load_state_dict_from(bad, names)
+    # in `frozen` mode torch numbers parameters GROUP BY GROUP (cad ViT, state ViT, rest — reference trainer.py:236-248), not in
+    # named_parameters() order.  optimizer_order() builds that list; a torch Adam constructed the reference's way agrees index for index, and a
+    # list in the wrong order is refused by the shape check instead of putting moments on the wrong tensors.
+    from videocad_amd.trainer import NativeAdam
+    fz_names = NativeAdam.optimizer_order(names, frozen=True)
+    assert fz_names != names and sorted(fz_names) == sorted(names) and NativeAdam.optimizer_order([(n, None) for n in names]) == names
+    plist = dict(model.named_parameters())
+    dummy = {n: torch.nn.Parameter(torch.zeros(1)) for n in names if n not in plist}                # the reference's dead parameters
+    allp = {n: plist.get(n, dummy.get(n)) for n in names}
+    ref_opt = torch.optim.Adam([{"params": [allp[n] for n in names if n.startswith("cad_embedding_model.")], "lr": 1e-6},
+                                {"params": [allp[n] for n in names if n.startswith("state_embedding_model.")], "lr": 2e-6},
+                                {"params": [allp[n] for n in names if not n.startswith(("cad_embedding_model.", "state_embedding_model."))], "lr": 3e-5}])
+    torch_order = [p for g in ref_opt.param_groups for p in g["params"]]
+    assert all(torch_order[i] is allp[n] for i, n in enumerate(fz_names))
+    sd_fz = tr.optimizer.state_dict_for(fz_names)
+    assert [g["params"] for g in sd_fz["param_groups"]] == [g["params"] for g in ref_opt.state_dict()["param_groups"]]
+    ref_opt.load_state_dict(sd_fz)                                                                    # torch accepts it as its own
+    model3, _, _ = make_model(cfg, ocfg)
+    tr3 = create_trainer(pk, pk, pk, model3, dict(tc, experiment_name="fz3"), "cpu", mtype, rank=0)
+    tr3.optimizer.load_state_dict_from(ref_opt.state_dict(), fz_names)
+    assert torch.equal(tr3.engine.m, tr.engine.m) and torch.equal(tr3.engine.v, tr.engine.v) and tr3.optimizer.lr == tr.optimizer.lr
+    # (the two towers are isomorphic, so named_parameters() order on a frozen checkpoint — state ViT and CAD ViT swapped — is NOT detectable from
+    #  shapes; what the check does catch is any list that puts a moment on a tensor of another shape or on a parameter this model never trains)
+    with pytest.raises(ValueError, match="optimizer's index order"):
+        tr3.optimizer.load_state_dict_from(ref_opt.state_dict(), fz_names[1:] + fz_names[:1])
+    dead_first = [n for n in fz_names if n not in shapes] + [n for n in fz_names if n in shapes]
+    with pytest.raises(ValueError, match="optimizer's index order"):
+        tr3.optimizer.load_state_dict_from(ref_opt.state_dict(), dead_first)
 
 
 def test_sample_writes_the_reference_files(emu, tmp_path, monkeypatch):
@@ -389,4 +417,4 @@ def test_f16_model_through_the_reference_surface(tmp_path, monkeypatch):
         loss2, _ = tr._process_batch(tb)                     # the fused native step on the same batch: same gradients, then Adam
         assert abs(float(loss2) - float(oloss)) < 2e-3 * abs(float(oloss))
         assert U.relerr(eng.grads, g_bridge) < 1e-6 and not torch.equal(eng.params, w0)
-        assert len(tr._norm_ring) == 1 and bool(torch.isfinite(tr._norm_ring[0][0]))
+        assert tr._ovf_n == 1 and int(tr._ovf_acc) == 0 and bool(torch.isfinite(tr._last_norm[0]))

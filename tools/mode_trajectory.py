@@ -21,7 +21,7 @@ for dtype in ("bf16", "f16"):
     for i in range(steps):
         bd = BI.synthetic_batch(B, T, 1000 + i % 8, dev)    # eight batches, cycled
         loss, _ = tr.train_step(bd)
-        norm = tr._norm_ring[-1] if dtype == "f16" else None
+        norm = tr._last_norm if dtype == "f16" else None
         rows.append((float(loss), float(norm[0]) if norm is not None else float("nan"), eng.grad_scale))
     out[dtype] = rows
     del tr, model

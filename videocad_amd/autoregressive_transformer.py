@@ -222,8 +222,7 @@ class AutoRegressiveTransformer(nn.Module):
         if self.num_views > 0 and mv is None:
             raise RuntimeError(f"model built with num_views = {self.num_views}: inputs['multiview_images'] [B, V, 1, S, S] is required "
                                "(the reference's image_projection would fail on the missing input)")
-        if self._engine.params.device.type != "cuda" and b"gfx950" in self._engine.lib.vcad_version():
-            raise RuntimeError("videocad_amd has no CPU fallback: move the model to a ROCm device (model.to('cuda'))")
+        # (a model that still lives in host memory: the library refuses — "no CPU fallback" — before any kernel runs, vcad_forward / vcad_infer_begin)
         if not self._shadow_fresh:
             self._engine.sync_shadow()
         self._shadow_fresh = False
@@ -275,8 +274,6 @@ class AutoRegressiveTransformer(nn.Module):
 
     def _sequential_cached(self, ui_images, cad_image, action):
         eng = self._engine
-        if eng.params.device.type != "cuda" and b"gfx950" in eng.lib.vcad_version():
-            raise RuntimeError("videocad_amd has no CPU fallback: move the model to a ROCm device (model.to('cuda'))")
         if not self._shadow_fresh:
             eng.sync_shadow()
         B, T = ui_images.shape[:2]

@@ -71,7 +71,7 @@ def synthetic_batch(B, T, seed, device, uint8=False):
     return {"frames": frames, "actions": actions, "cad_image": cad, "timesteps": torch.arange(S, device=device).repeat(B, 1)}
 
 
-def build_trainer(dtype: str, dropout: float, device, rank: int):
+def build_trainer(dtype: str, dropout: float, device, rank: int, extra_tcfg=None):
     """ModelFactory.create_model -> create_trainer, exactly the objects experiment.py builds (reference experiment.py:69-119)."""
     cfg = dict(CANONICAL_MODEL_CONFIG, compute_dtype=dtype, dropout=dropout)
     model, mtype = ModelFactory().create_model(cfg["model_name"], cfg, device)
@@ -80,6 +80,7 @@ def build_trainer(dtype: str, dropout: float, device, rank: int):
     pk = {"loader": [], "sampler": None}
     tcfg = {"lr": 1e-5, "use_mse": True, "experiment_name": "bench", "class_weights_path": CLASS_WEIGHTS,
             "checkpoint_dir": os.path.join(os.environ.get("TMPDIR", "/tmp"), "vcad_bench_ckpt")}
+    tcfg.update(extra_tcfg or {})
     cwd = os.getcwd()
     os.chdir(os.environ.get("TMPDIR", "/tmp"))           # the trainer creates logs/ under the CWD like the reference; keep the repo clean
     try:
@@ -299,7 +300,9 @@ def run(args):
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     B, T = args.batch, args.seq
-    model, tr = build_trainer(args.dtype, args.dropout, device, rank)
+    # data-parallel exchange knobs (GradSync; defaults = the reference's fp32 all-reduce): --grad-wire half / --grad-exchange rs_ag|auto
+    model, tr = build_trainer(args.dtype, args.dropout, device, rank,
+                              {"grad_wire": getattr(args, "grad_wire", "fp32"), "grad_exchange": getattr(args, "grad_exchange", "all_reduce")})
     eng = model._engine
     # A/B switches expressible as per-engine kernel-selection flags (the product default is 0 = automatic); the process-global
     # selectors of the A/B build are set by tools/bench_ab.py before it calls launch()
@@ -329,8 +332,10 @@ def run(args):
         ms_nc = e_nc / max(3, args.steps // 2) * 1e3
         comm = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "buckets": len(eng.buckets),
                 "bucket_MB": [round((hi - lo) * 4 / 1e6, 1) for lo, hi in eng.buckets],
+                "grad_wire": tr.gradsync.wire, "grad_exchange": tr.gradsync.exchange,
                 "ms_per_step_without_allreduce": round(ms_nc, 3), "exposed_comm_ms": round(ms - ms_nc, 3)}
-        # one more step with issue / completion events around every collective (ms since the backward started): where each all-reduce sat
+        # one more step with issue / completion events around every collective (ms since the backward started): where each exchange sat and the
+        # GB/s it achieved (wire bytes / duration; busGBps = x 2 (W - 1) / W, the per-link figure to hold against xGMI)
         tr.gradsync.timing = True
         tr.train_step(bd)
         comm["last_step"] = tr.gradsync.comm_report()
@@ -365,15 +370,14 @@ def run(args):
         tr.train_step(bd)                       # back to the headline plan (keeps later legs on the C2 workspace)
 
     # ---- the other compute modes at the headline shape, short legs with their own parity blocks: bf16x3 = the IN-TOLERANCE mode (logits within
-    # 1e-3 of the fp32 reference, arg-max exact), f32 = exact-fp32 MFMA, bf16+fp8 = MXFP8 forward GEMMs in the ViT
+    # 1e-3 of the fp32 reference, arg-max exact), f32 = exact-fp32 MFMA.  (r05: the MXFP8 forward probe is no longer a bench leg — it lost to bf16 by
+    # 12-13 % at configs[4]'s per-GPU shape in every r04 run, DESIGN.md §4.3 says why and what a winning fp8 path needs; `--fp8` still runs it on request)
     modes = None
     if rank == 0 and world == 1 and (B, T) == (32, 64) and args.dtype == "bf16" and not getattr(args, "no_modes", False):
         modes = {}
-        # fp8: BASELINE configs[4] is seq_len 186 — its per-GPU shape (B=16, T=186), next to the bf16 leg at that shape above
         # f16 = the fp16-storage build of the library (libvcad_hip_f16.so, VCAD_F16): the bf16 mode's kernels with ten mantissa bits — in tolerance at its speed
         for key, dt, f8, K3, B3, T3 in (("f16", "f16", False, 10, B, T), ("f16_seq_len_186", "f16", False, 6, 16, 186),
-                                        ("bf16x3", "bf16x3", False, 4, B, T), ("bf16x3_seq_len_186", "bf16x3", False, 3, 16, 186), ("f32", "f32", False, 2, B, T),
-                                        ("bf16_fp8_forward", "bf16", True, 4, 16, 186)):
+                                        ("bf16x3", "bf16x3", False, 4, B, T), ("bf16x3_seq_len_186", "bf16x3", False, 3, 16, 186), ("f32", "f32", False, 2, B, T)):
             try:
                 modes[key] = short_leg(dt, f8, B3, T3, K3, 3 if dt == "f16" else 1, device, rank, world, 2000, args.dropout, want_parity=not key.endswith("_seq_len_186"))
             except Exception as ex:               # a reporting leg never breaks the headline measurement

@@ -1042,7 +1042,17 @@ int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, v
     e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false; e->kvf.ready = false;
     return 0;
 }
+// No CPU fallback: an engine whose buffers still live in host memory (a model built on "cpu" and not yet moved) is refused by every entry point that
+// would launch kernels over them — with an error, not a memory fault.  (vc_rt.h: the emulator build's "device" is host memory.)
+static int need_device(const vcad_engine* e, const char* what) {
+    if (e->P && !vc_is_device_ptr(e->P)) {
+        vc_set_error("%s: the bound parameter buffer is not device memory — this library has no CPU fallback: move the model to a ROCm device (model.to('cuda'))", what);
+        return VC_ERR_ARG;
+    }
+    return 0;
+}
 int vcad_sync_shadow(vcad_engine* e, void* stream) {
+    CK(need_device(e, "vcad_sync_shadow"));
     if (e->Spk) return vc_pack_x3(e->P, e->Spk, e->ptotal, (vc_stream_t)stream);
     if (e->dt != VC_BF16) return 0;
     if (!e->P || !e->S) { vc_set_error("vcad_sync_shadow: not bound"); return VC_ERR_ARG; }
@@ -1109,6 +1119,7 @@ int vcad_forward_rgb8(vcad_engine* e, const uint8_t* frames_rgb, int64_t fbstrid
 static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, const float* actions, const void* cad, int u8, int B, int T,
                        float* cmds_out, float* pars_out, void* stream) {
     if (!e->P) { vc_set_error("vcad_forward: parameters not bound"); return VC_ERR_ARG; }
+    CK(need_device(e, "vcad_forward"));
     if (B < 1 || T < 1 || T > e->c.max_ep_len) { vc_set_error("vcad_forward: bad B=%d T=%d", B, T); return VC_ERR_ARG; }
     // any horizon up to max_ep_len (reference: 1 000): bf16 mode on the block-streaming decoder attention (attn_mfma.h), the fp32 / bf16x3 modes on the
     // wave-per-row kernels (attn.h: up to sixteen 64-key pieces per query)
@@ -1213,6 +1224,26 @@ int vcad_join_side(vcad_engine* e, void* stream) {
 // Whole backward: after stages 0-1 (heads + decoder, stem) the CAD ViT's backward (stage 2) is independent of the frame ViT's
 // (stages 3-4), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
 // soon as its stage returns) keeps everything on the caller's stream.
+// ---- gradient wire format of the data-parallel exchange (norm.h: wire_*_kernel; trainer.py: GradSync grad_wire = "half")
+static int wire_range(const vcad_engine* e, int64_t lo, int64_t hi, const char* what) {
+    if (!e->G) { vc_set_error("%s: buffers not bound", what); return VC_ERR_ARG; }
+    if (lo < 0 || hi < lo || hi > e->ptotal || (lo & 3)) { vc_set_error("%s: range [%lld, %lld) outside the gradient buffer or not 4-float aligned", what, (long long)lo, (long long)hi); return VC_ERR_ARG; }
+    return 0;
+}
+int vcad_wire_amax(vcad_engine* e, int64_t lo, int64_t hi, float* amax_out, void* stream) {
+    CK(wire_range(e, lo, hi, "vcad_wire_amax"));
+    if (!amax_out) { vc_set_error("vcad_wire_amax: amax_out is null"); return VC_ERR_ARG; }
+    return vc_wire_amax(e->G + lo, hi - lo, amax_out, (vc_stream_t)stream);
+}
+int vcad_wire_pack(vcad_engine* e, int64_t lo, int64_t hi, void* wire, const float* amax, int world, void* stream) {
+    CK(wire_range(e, lo, hi, "vcad_wire_pack"));
+    return vc_wire_pack(e->G + lo, wire, hi - lo, amax, world < 1 ? 1 : world, (vc_stream_t)stream);
+}
+int vcad_wire_unpack(vcad_engine* e, int64_t lo, int64_t hi, const void* wire, const float* amax, int world, void* stream) {
+    CK(wire_range(e, lo, hi, "vcad_wire_unpack"));
+    return vc_wire_unpack(wire, e->G + lo, hi - lo, amax, world < 1 ? 1 : world, (vc_stream_t)stream);
+}
+
 int vcad_set_bucket_callback(vcad_engine* e, vcad_bucket_ready_fn fn, void* user) { e->bucket_cb = fn; e->bucket_cb_user = user; return 0; }
 
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
@@ -1272,6 +1303,7 @@ size_t vcad_infer_workspace_bytes(const vcad_engine* e, int B, int Tmax) {
 
 static int infer_begin_any(vcad_engine* e, const void* cad, int u8, int B, int Tmax, void* stream) {
     if (!e->P) { vc_set_error("vcad_infer_begin: parameters not bound"); return VC_ERR_ARG; }
+    CK(need_device(e, "vcad_infer_begin"));
     if (e->c.num_views > 0) { vc_set_error("vcad_infer_begin: incremental inference has no multiview input (nor has the reference's sequential_inference)"); return VC_ERR_UNSUPPORTED; }
     if (B < 1 || Tmax < 1 || Tmax > 1024 || Tmax > e->c.max_ep_len) { vc_set_error("vcad_infer_begin: bad B=%d Tmax=%d (1 <= Tmax <= min(1024, max_ep_len))", B, Tmax); return VC_ERR_ARG; }
     if (!e->ws) { vc_set_error("vcad_infer_begin: no workspace"); return VC_ERR_WORKSPACE; }
@@ -1390,6 +1422,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
     if (!e->P || !e->G || !e->Mm || !e->Vv) { vc_set_error("vcad_optimizer_step: buffers not bound"); return VC_ERR_ARG; }
     if (!e->ws) { vc_set_error("vcad_optimizer_step: no workspace"); return VC_ERR_WORKSPACE; }
     if (step < 1) { vc_set_error("vcad_optimizer_step: step must be >= 1"); return VC_ERR_ARG; }
+    CK(need_device(e, "vcad_optimizer_step"));
     if (e->B == 0) plan(e, 1, 1, e->ws);
     vc_stream_t s = (vc_stream_t)stream;
     // the norm the reference clips against is that of the (already averaged) gradients
@@ -1402,7 +1435,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
         AdamParams a; memset(&a, 0, sizeof(a));
         a.p = e->P + lo; a.g = e->G + lo; a.m = e->Mm + lo; a.v = e->Vv + lo; a.n = hi - lo; a.lr = lr_bucket[b0]; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
         a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
-        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.finite = e->norm_out + 2; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr; a.shadow_pk = e->Spk ? e->Spk + lo : nullptr;
+        a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.finite = e->c.dtype == VCAD_F16 ? e->norm_out + 2 : nullptr; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr; a.shadow_pk = e->Spk ? e->Spk + lo : nullptr;
         CK(vc_adam(a, s));
         b0 = b1i + 1;
     }

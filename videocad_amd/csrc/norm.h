@@ -351,6 +351,66 @@ VC_KERNEL __launch_bounds__(256) void scale_kernel(const float* x, float* y, lon
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = alpha * x[(n4 << 2) + threadIdx.x];
 }
+// the same for a source or destination that is only 4-byte aligned (a caller's dlogits may be an offset view): one element per thread
+VC_KERNEL __launch_bounds__(256) void scale_unaligned_kernel(const float* x, float* y, long n, float alpha) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = alpha * x[i];
+}
+
+// ---- gradient wire format of the data-parallel exchange (engine.hip: vcad_wire_*): a bucket of the flat fp32 gradient buffer travels over xGMI in
+// the library's 16-bit storage format (bf16 here, IEEE half in the -DVC_H16 build): half the bytes of the reference's fp32 DDP buckets.
+// bf16 has fp32's exponent range: no scale.  fp16 does not: the bucket is multiplied by a power of two derived from its (all-reduced) maximum
+// magnitude so that the SUM over `world` ranks stays below 32 768; the scale is recomputed from the same device scalar on the way back.
+VC_DEV float wire_scale(const float* amax, int world) {
+    if (!amax) return 1.0f;
+    const float a = amax[0] * (float)world;
+    if (!(a > 0.0f) || !(a <= 3.0e38f)) return 1.0f;              // all-zero bucket, or a non-finite gradient (which must stay non-finite on the wire)
+    float e = floorf(log2f(32768.0f / a));
+    e = e < -60.0f ? -60.0f : (e > 60.0f ? 60.0f : e);
+    return exp2f(e);
+}
+VC_KERNEL __launch_bounds__(256) void wire_amax_stage1_kernel(const float* g, long n, float* partial) {
+    VC_SHARED float red[256];
+    float m = 0.f;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        if (i + 4 <= n) { float v[4]; quad_load<float>(g + i, v); for (int j = 0; j < 4; ++j) { const float a = fabsf(v[j]); m = a > m || a != a ? a : m; } }
+        else for (int j = 0; j < 4; ++j) if (i + j < n) { const float a = fabsf(g[i + j]); m = a > m || a != a ? a : m; }
+    }
+    red[threadIdx.x] = m;
+    vc_sync();
+    for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) { const float a = red[threadIdx.x + k], b = red[threadIdx.x]; red[threadIdx.x] = (a > b || a != a) ? a : b; } vc_sync(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+VC_KERNEL __launch_bounds__(256) void wire_amax_stage2_kernel(const float* partial, int nblk, float* out) {
+    VC_SHARED float red[256];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) { const float a = partial[i]; m = (a > m || a != a) ? a : m; }
+    red[threadIdx.x] = m;
+    vc_sync();
+    for (int k = 128; k >= 1; k >>= 1) { if ((int)threadIdx.x < k) { const float a = red[threadIdx.x + k], b = red[threadIdx.x]; red[threadIdx.x] = (a > b || a != a) ? a : b; } vc_sync(); }
+    if (threadIdx.x == 0) out[0] = red[0] != red[0] ? 3.4e38f : red[0];          // (NaN does not survive an all-reduce(MAX) on every backend: send "huge" instead)
+}
+VC_KERNEL __launch_bounds__(256) void wire_pack_kernel(const float* g, vc_bf16* w, long n, const float* amax, int world) {
+    const float sc = wire_scale(amax, world);
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4]; quad_load<float>(g + 4 * i, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= sc;
+        quad_store<vc_bf16>(w + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) vc_st(w + (n4 << 2) + threadIdx.x, sc * g[(n4 << 2) + threadIdx.x]);
+}
+VC_KERNEL __launch_bounds__(256) void wire_unpack_kernel(const vc_bf16* w, float* g, long n, const float* amax, int world) {
+    const float inv = 1.0f / wire_scale(amax, world);
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4]; quad_load<vc_bf16>(w + 4 * i, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= inv;
+        quad_store<float>(g + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) g[(n4 << 2) + threadIdx.x] = inv * vc_ld(w + (n4 << 2) + threadIdx.x);
+}
 
 // ---- fp32 -> T cast (weight shadows) and generic fill
 template <typename TY>

@@ -73,7 +73,12 @@ int vc_embed_action(int ty, const float* a, const float* W, const float* b, cons
                     long M, int H, int K, int T, vc_stream_t s);
 int vc_bcast_tanh(int ts, const void* src, float* out, long M, int H, int T, vc_stream_t s);
 int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s);
-int vc_scale(const float* x, float* y, long n, float alpha, vc_stream_t s);       // y = alpha * x; x, y 16-byte aligned (y may be x)
+int vc_scale(const float* x, float* y, long n, float alpha, vc_stream_t s);       // y = alpha * x (y may be x); 16-byte aligned pointers take the vector kernel, anything else one element per thread
+// gradient wire format (norm.h): 16-bit copies of a range of the fp32 gradient buffer in the library's storage format; amax = device scalar (max |g|
+// over all ranks) that fixes the fp16 build's power-of-two scale, or null (scale 1: bf16 has fp32's range).  amax_out: 1 + 1024 floats.
+int vc_wire_amax(const float* g, long n, float* amax_out, vc_stream_t s);
+int vc_wire_pack(const float* g, void* wire, long n, const float* amax, int world, vc_stream_t s);
+int vc_wire_unpack(const void* wire, float* g, long n, const float* amax, int world, vc_stream_t s);
 int vc_zero_cols(void* p, long ld_bytes, long rows, long width_bytes, vc_stream_t s);      // strided memset: 16-byte aligned rows / width
 int vc_cast(int ty, const float* x, void* y, long n, vc_stream_t s);
 int vc_pack_x3(const float* x, uint32_t* y, long n, vc_stream_t s);       // y[i] = hi bf16(x[i]) << 16 | lo bf16(x[i] - hi)

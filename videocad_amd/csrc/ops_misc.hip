@@ -143,9 +143,37 @@ int vc_add_inplace(float* a, const float* b, long n, vc_stream_t s) {
 }
 int vc_scale(const float* x, float* y, long n, float alpha, vc_stream_t s) {
     if (n <= 0) return VC_OK;
-    if (((uintptr_t)x | (uintptr_t)y) & 15) { vc_set_error("vc_scale: pointers must be 16-byte aligned"); return VC_ERR_ARG; }
+    if (((uintptr_t)x | (uintptr_t)y) & 15) {          // (caller-supplied dlogits of vcad_backward* on an fp16 engine: any 4-byte aligned view works)
+        long nb = VC_CEIL_DIV(n, 256); if (nb > 8192) nb = 8192;
+        VC_LAUNCH(scale_unaligned_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, y, n, alpha);
+        return VC_OK;
+    }
     long nb = VC_CEIL_DIV(n / 4 + 1, 256); if (nb > 4096) nb = 4096;
     VC_LAUNCH(scale_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, y, n, alpha);
+    return VC_OK;
+}
+int vc_wire_amax(const float* g, long n, float* amax_out, vc_stream_t s) {
+    long nb = VC_CEIL_DIV(n, 1024); if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+    VC_LAUNCH(wire_amax_stage1_kernel, dim3((unsigned)nb), dim3(256), 0, s, g, n, amax_out + 1);
+    VC_LAUNCH(wire_amax_stage2_kernel, dim3(1), dim3(256), 0, s, (const float*)(amax_out + 1), (int)nb, amax_out);
+    return VC_OK;
+}
+static int wire_check(const void* a, const void* b, const char* what) {
+    if (((uintptr_t)a & 15) || ((uintptr_t)b & 7)) { vc_set_error("%s: the gradient range must be 16-byte aligned, the wire buffer 8-byte aligned", what); return VC_ERR_ARG; }
+    return VC_OK;
+}
+int vc_wire_pack(const float* g, void* wire, long n, const float* amax, int world, vc_stream_t s) {
+    if (n <= 0) return VC_OK;
+    if (int rc = wire_check(g, wire, "vc_wire_pack")) return rc;
+    long nb = VC_CEIL_DIV(n / 4 + 1, 256); if (nb > 4096) nb = 4096;
+    VC_LAUNCH(wire_pack_kernel, dim3((unsigned)nb), dim3(256), 0, s, g, (vc_bf16*)wire, n, amax, world);
+    return VC_OK;
+}
+int vc_wire_unpack(const void* wire, float* g, long n, const float* amax, int world, vc_stream_t s) {
+    if (n <= 0) return VC_OK;
+    if (int rc = wire_check(g, wire, "vc_wire_unpack")) return rc;
+    long nb = VC_CEIL_DIV(n / 4 + 1, 256); if (nb > 4096) nb = 4096;
+    VC_LAUNCH(wire_unpack_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const vc_bf16*)wire, g, n, amax, world);
     return VC_OK;
 }
 VC_KERNEL __launch_bounds__(256) void pack_x3_kernel(const float* x, uint32_t* y, long n) {

@@ -44,6 +44,13 @@ static inline int vc_stream_wait_event(vc_stream_t s, vc_event_t ev) { return (i
 static inline void vc_stream_destroy(vc_stream_t s) { if (s) (void)hipStreamDestroy(s); }
 static inline void vc_event_destroy(vc_event_t ev) { if (ev) (void)hipEventDestroy(ev); }
 static inline bool vc_has_side_streams() { return true; }
+// is p memory a kernel of this library can address?  (the bound parameter buffer of an engine: a model that still lives in host memory must fail loudly —
+// there is no CPU fallback — instead of faulting inside the first kernel)
+static inline bool vc_is_device_ptr(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
 // small host -> device table upload, ordered on the stream; the (pageable) host buffer may be reused when it returns
 static inline int vc_upload(void* d, const void* h, size_t n, vc_stream_t s) { int rc = (int)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s); return rc ? rc : (int)hipStreamSynchronize(s); }
 static inline int vc_last_launch_error() { return (int)hipGetLastError(); }
@@ -213,6 +220,7 @@ static inline int vc_stream_wait_event(vc_stream_t, vc_event_t) { return 0; }
 static inline void vc_stream_destroy(vc_stream_t) {}
 static inline void vc_event_destroy(vc_event_t) {}
 static inline bool vc_has_side_streams() { return false; }
+static inline bool vc_is_device_ptr(const void*) { return true; }      // (the emulator's "device" is host memory)
 static inline int vc_last_launch_error() { return 0; }
 static inline unsigned vc_device_bit() { return 1u; }
 

@@ -111,25 +111,49 @@ class NativeEngine:
         gradient buffer holds true ones.  Re-plans the workspace on the next forward."""
         L.check(self.lib, self.lib.vcad_set_grad_scale(self.h, float(scale)), "set_grad_scale")
 
-    def check_grad_overflow(self, norm: torch.Tensor) -> bool:
-        """fp16 engines: `norm` = what optimizer_step returned some steps ago.  A non-finite gradient norm means the scaled backward overflowed fp16 (the
-        library skipped that update): halve the scale.  Host sync on `norm` — call it every few dozen steps, not every step."""
-        if self.cfg.dtype != L.VCAD_F16 or norm is None:
+    GROW_AFTER = 2000                 # finite steps in a row before a lowered scale is doubled again (torch.amp.GradScaler's growth_interval)
+
+    def note_overflows(self, bad: int, steps: int) -> bool:
+        """fp16 engines, host logic of the gradient scale (no kernels).  `bad` of the last `steps` optimizer steps came back with a non-finite
+        gradient norm — the scaled backward overflowed fp16 and the library skipped those updates.  Then: the Adam step counter is taken back
+        by `bad` (a skipped update must not advance the bias correction), the scale is halved once (explicit mode from here on) and the value
+        the automatic rule had chosen is remembered as the target.  Without an overflow the scale is only ever RAISED towards that target —
+        an engine that never overflowed stays in automatic mode at what `2 x pow2ceil(B T), floor 1024` gives it (r04 grew every
+        engine to 4096) — doubling after GROW_AFTER finite steps in a row; on reaching the target it returns to automatic mode, so that later
+        batch shapes adapt again."""
+        if self.cfg.dtype != L.VCAD_F16:
             return False
-        bad = not bool(torch.isfinite(norm[0]).item())
-        if bad:
+        if bad > 0:
             self._good_norms = 0
+            self.step_count = max(0, self.step_count - int(bad))
+            self.skipped_steps = getattr(self, "skipped_steps", 0) + int(bad)
             if getattr(self, "_scale_target", None) is None:
                 self._scale_target = self.grad_scale                 # (what the automatic rule chose for this batch shape)
             if self.grad_scale > 1.0:
                 self.set_grad_scale(self.grad_scale / 2)             # explicit from here on
-        else:
-            # 2 000 finite norms in a row: back up towards where it started (a scale lowered by one outlier batch should not stay low for the rest of the run)
-            self._good_norms = getattr(self, "_good_norms", 0) + 1
-            target = getattr(self, "_scale_target", None) or 4096.0
-            if self._good_norms >= 2000 and self.grad_scale < target:
-                self.set_grad_scale(self.grad_scale * 2); self._good_norms = 0
-        return bad
+            return True
+        target = getattr(self, "_scale_target", None)
+        if target is None:                                           # never lowered: nothing to grow back to
+            return False
+        self._good_norms = getattr(self, "_good_norms", 0) + int(steps)
+        if self._good_norms >= self.GROW_AFTER:
+            self._good_norms = 0
+            if self.grad_scale * 2 >= target:
+                self.set_grad_scale(0.0); self._scale_target = None  # back at the automatic rule's value: automatic mode again
+            else:
+                self.set_grad_scale(self.grad_scale * 2)
+        return False
+
+    def check_grad_overflow(self, norm: torch.Tensor) -> bool:
+        """one norm (what optimizer_step returned some steps ago) through note_overflows.  Host sync on `norm`: the trainer does not call this per
+        step — it counts non-finite norms on the device and reads one counter per 32 steps (trainer.BaseTrainer.train_step)."""
+        if self.cfg.dtype != L.VCAD_F16 or norm is None:
+            return False
+        return self.note_overflows(0 if bool(torch.isfinite(norm[0]).item()) else 1, 1)
+
+    def reset_overflow_history(self):
+        """after the parameters were replaced (checkpoint load, restore_best_weights): norms of the previous weights say nothing about the new ones"""
+        self._good_norms = 0
 
     def set_dropout(self, p: float, seed: int = 0):
         """p = 0 disables; call with a fresh seed before every training forward (masks = hash(seed, site, index))."""
@@ -263,6 +287,25 @@ class NativeEngine:
 
     def join_side(self):
         L.check(self.lib, self.lib.vcad_join_side(self.h, self.stream()), "join_side")
+
+    # ------------------------------------------------------------------ half-precision wire format of the gradient exchange (include/vcad.h: vcad_wire_*)
+    @property
+    def wire_dtype(self) -> torch.dtype:
+        """the 16-bit format this engine's library packs gradient buckets into: its storage format (bf16, or fp16 for VCAD_F16 engines)"""
+        return torch.float16 if self.lib.vcad_storage_format() == b"f16" else torch.bfloat16
+
+    def wire_amax(self, lo: int, hi: int, amax: torch.Tensor):
+        """amax: fp32 [1 + 1024] on the engine's device; amax[0] <- max |g| over grads[lo:hi] (the caller all-reduces it with MAX)"""
+        assert amax.dtype == torch.float32 and amax.numel() >= 1025 and amax.is_contiguous()
+        L.check(self.lib, self.lib.vcad_wire_amax(self.h, lo, hi, _ptr(amax), self.stream()), "wire_amax")
+
+    def wire_pack(self, lo: int, hi: int, wire: torch.Tensor, amax: Optional[torch.Tensor], world: int):
+        assert wire.dtype == self.wire_dtype and wire.numel() >= hi - lo and wire.is_contiguous()
+        L.check(self.lib, self.lib.vcad_wire_pack(self.h, lo, hi, _ptr(wire), _ptr(amax), int(world), self.stream()), "wire_pack")
+
+    def wire_unpack(self, lo: int, hi: int, wire: torch.Tensor, amax: Optional[torch.Tensor], world: int):
+        assert wire.dtype == self.wire_dtype and wire.numel() >= hi - lo and wire.is_contiguous()
+        L.check(self.lib, self.lib.vcad_wire_unpack(self.h, lo, hi, _ptr(wire), _ptr(amax), int(world), self.stream()), "wire_unpack")
 
     def optimizer_step(self, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, max_norm=1.0, grad_scale=1.0):
         """lr: one float, or one float per gradient bucket (the reference's `frozen` parameter groups)."""

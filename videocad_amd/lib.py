@@ -76,6 +76,9 @@ PROTOTYPES = {
     "vcad_side_stage": (_i, [_vp]),
     "vcad_set_bucket_callback": (_i, [_vp, _vp, _vp]),
     "vcad_join_side": (_i, [_vp, _vp]),
+    "vcad_wire_amax": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "vcad_wire_pack": (_i, [_vp, _i64, _i64, _vp, _vp, _i, _vp]),
+    "vcad_wire_unpack": (_i, [_vp, _i64, _i64, _vp, _vp, _i, _vp]),
     "vcad_optimizer_step": (_i, [_vp, _f, _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "vcad_optimizer_step_groups": (_i, [_vp, C.POINTER(_f), _f, _f, _f, _f, _i, _f, _vp, _vp]),
     "vcad_infer_workspace_bytes": (_sz, [_vp, _i, _i]),

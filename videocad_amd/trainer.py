@@ -148,10 +148,27 @@ class NativeAdam:
         sd = self.state_dict()["state"]
         return {self.names[i]: st for i, st in sd.items()}
 
+    @staticmethod
+    def optimizer_order(named_parameters, frozen=False):
+        """`param_names` for state_dict_for / load_state_dict_from: the names of a model's parameters IN THE ORDER torch.optim.Adam numbers them.
+        torch numbers parameters group by group.  The reference builds ONE group over `model.parameters()` (trainer.py:251-253) — then the order is
+        that of `named_parameters()` — except in its `frozen` mode (trainer.py:236-248), where the groups are [cad_embedding_model.*,
+        state_embedding_model.*, everything else]: index 0 is then the CAD ViT's first tensor, not the model's.  `named_parameters`: an iterable of
+        names or of (name, parameter) pairs, e.g. `reference_model.named_parameters()` or tests/golden/reference_param_order.json's list."""
+        names = [n if isinstance(n, str) else n[0] for n in named_parameters]
+        if not frozen:
+            return names
+        cad = [n for n in names if n.startswith("cad_embedding_model.")]
+        state = [n for n in names if n.startswith("state_embedding_model.")]
+        rest = [n for n in names if not n.startswith(("cad_embedding_model.", "state_embedding_model."))]
+        return cad + state + rest
+
     def state_dict_for(self, param_names):
-        """optimizer_state_dict as a `torch.optim.Adam` built over parameters named `param_names` (in that order — e.g.
-        `[n for n, _ in reference_model.named_parameters()]`) would hold it: state only for names this model trains (the reference's dead
-        parameters never receive gradients, so torch keeps no state for them either), one param_group over all indices."""
+        """optimizer_state_dict as a `torch.optim.Adam` built over parameters named `param_names` would hold it.  `param_names` must be in the
+        OPTIMIZER's index order — `NativeAdam.optimizer_order(reference_model.named_parameters(), frozen=...)`: plain `named_parameters()` order for the
+        reference's default single group, group order for its `frozen` mode.  State only for names this model trains (the reference's dead parameters
+        never receive gradients, so torch keeps no state for them either); one param_group per native group (one, or the three `frozen` ones), each
+        listing its indices in ascending order."""
         named, pos = self.named_state(), {n: i for i, n in enumerate(param_names)}
         missing = [n for n in named if n not in pos]
         if missing:
@@ -165,11 +182,29 @@ class NativeAdam:
         return {"state": {pos[n]: st for n, st in named.items()}, "param_groups": groups}
 
     def load_state_dict_from(self, sd, param_names):
-        """inverse of state_dict_for: accepts the optimizer_state_dict of an Adam built over `param_names` (a reference checkpoint).  Learning
-        rates are mapped through parameter NAMES: each native group takes the lr of the checkpoint group that holds its parameters (so the
-        reference's three `frozen` groups, in whatever order and with its extra dead parameters, land on the right buckets)."""
+        """inverse of state_dict_for: accepts the optimizer_state_dict of an Adam built over `param_names` (a reference checkpoint; `param_names` in the
+        optimizer's index order, see optimizer_order).  Every moment tensor's shape is checked against the native parameter it is mapped to — and a
+        moment must never land on a parameter this model does not train: most wrong orders fail here instead of loading moments into the wrong
+        tensors.  NOT detectable: the reference's two ViT towers are isomorphic, so plain named_parameters() order on a `frozen` checkpoint (state
+        ViT and CAD ViT swapped) passes every shape check — build the list with optimizer_order(..., frozen=True).  Learning rates are mapped through parameter NAMES: each native group takes the lr of the checkpoint group that holds its
+        parameters (so the reference's three `frozen` groups, in whatever order and with its extra dead parameters, land on the right buckets)."""
         idx = {n: i for i, n in enumerate(self.names)}
-        conv = {idx[param_names[int(i)]]: st for i, st in sd.get("state", {}).items() if param_names[int(i)] in idx}
+        conv = {}
+        for i, st in sd.get("state", {}).items():
+            if not 0 <= int(i) < len(param_names):
+                raise IndexError(f"load_state_dict_from: optimizer state index {i} outside param_names ({len(param_names)} names)")
+            n = param_names[int(i)]
+            if n not in idx:
+                # torch keeps optimiser state only for parameters that received gradients; the reference's parameters this model does not hold
+                # (GPT-2 trunk, ...) never do — state on such a name means the indices were read through the wrong name list
+                raise ValueError(f"load_state_dict_from: state {i} -> '{n}', which is not a trained parameter of this model — "
+                                 "param_names is not in the optimizer's index order (NativeAdam.optimizer_order)")
+            want = tuple(self.engine.table[n][2])
+            for key in ("exp_avg", "exp_avg_sq"):
+                if tuple(st[key].shape) != want:
+                    raise ValueError(f"load_state_dict_from: state {i} -> '{n}': {key} has shape {tuple(st[key].shape)}, the parameter {want} — "
+                                     "param_names is not in the optimizer's index order (NativeAdam.optimizer_order)")
+            conv[idx[n]] = st
         self.load_state_dict({"state": conv, "param_groups": []})
         src_groups = sd.get("param_groups") or []
         if not src_groups:
@@ -232,24 +267,37 @@ class GradSync:
     Construction does what the DDP constructor did for the reference: rank 0's parameters (and optimiser state) are broadcast,
     so every replica starts from the same weights whatever each process's RNG drew.
     Each backward stage finalises one contiguous bucket of the flat gradient buffer: heads + decoder first (360 MB, 71 % of the bytes —
-    its all-reduce starts before the stem's backward is even launched), then the stem (16 MB), the CAD ViT (65 MB, computed on the engine's
-    side stream), and the two halves of the frame ViT.  Every all-reduce(SUM) is issued on a communication stream right away so it runs over
+    its exchange starts before the stem's backward is even launched), then the stem (16 MB), the CAD ViT (65 MB, computed on the engine's
+    side stream), and the two halves of the frame ViT.  Every exchange is issued on a communication stream right away so it runs over
     xGMI underneath the next stage's kernels; the stem's bucket travels with the CAD ViT's (adjacent ranges: one collective).  The 1/world
     mean is folded into the Adam kernel.  Only live parameters travel (508 MB fp32 instead of the reference's 818 MB incl. dead GPT-2 zeros).
-    `timing = True` records issue / completion events around every collective; `comm_report()` turns the last step's into milliseconds
-    relative to the start of the backward (the first N-GPU run is then diagnosable from one line)."""
 
-    def __init__(self, engine, group=None, on_params_changed=None, force_staged=False):
+    r05 — two knobs for the first multi-GPU runs (training_config `grad_wire`, `grad_exchange`, `grad_rs_min_mb`; DESIGN.md §6 says which to try when):
+      wire = "fp32" (default: the reference's numerics) | "half": the bucket travels in the engine's 16-bit storage format (bf16; fp16 with a
+             power-of-two scale from the all-reduced max |g| for VCAD_F16 engines) — half the xGMI bytes, packed / unpacked by the library
+             (include/vcad.h: vcad_wire_*);
+      exchange = "all_reduce" (default) | "rs_ag": reduce_scatter + all_gather of the same bucket — the two halves of a ring all-reduce as separate
+             collectives, each a one-hop pattern on the fully connected xGMI mesh | "auto": rs_ag for buckets of at least `rs_min_mb` MB on the wire.
+    `timing = True` records issue / completion events around every exchange; `comm_report()` turns the last step's into milliseconds
+    relative to the start of the backward plus achieved GB/s (the first N-GPU run is then diagnosable from one line)."""
+
+    def __init__(self, engine, group=None, on_params_changed=None, force_staged=False, wire="fp32", exchange="all_reduce", rs_min_mb=32.0):
         import torch.distributed as dist
+        if wire not in ("fp32", "half") or exchange not in ("all_reduce", "rs_ag", "auto"):
+            raise ValueError(f"GradSync: grad_wire must be 'fp32' or 'half' (got {wire!r}), grad_exchange 'all_reduce', 'rs_ag' or 'auto' (got {exchange!r})")
         self.eng, self.dist, self.group = engine, dist, group
+        self.wire, self.exchange, self.rs_min_mb = wire, exchange, float(rs_min_mb)
         inited = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if inited else 1
+        self.rank = dist.get_rank(group) if inited else 0
         # force_staged: take the bucketed multi-stream path even in a 1-rank group (each all-reduce is then RCCL's one-rank copy): how the
         # stream / event choreography is exercised on a box with a single GPU (tests; training_config["force_bucketed_exchange"])
         self.staged = self.world > 1 or (bool(force_staged) and inited)
         self.stream = torch.cuda.Stream(device=engine.device) if (self.staged and engine.device.type == "cuda") else None
         self.skip_comm = False                                    # diagnostic only (bench: exposed communication time)
         self.timing, self._ev = False, []                         # diagnostic only: per-collective (label, MB, start, issue, done) events
+        self.collectives = 0                                      # collectives issued so far (tests count them)
+        self._wire_buf = self._shard_buf = self._amax = None      # scratch of the wire format / reduce_scatter shard (allocated on first use, largest bucket)
         if self.world > 1:
             engine.set_dynamic_items(True)        # RCCL's kernels hold CUs under the backward: the persistent GEMM draws its items with tickets then
             src = dist.get_global_rank(group, 0) if group is not None else 0
@@ -261,6 +309,52 @@ class GradSync:
             if on_params_changed is not None:
                 on_params_changed()
 
+    # ---- one bucket (or a run of adjacent buckets) of the flat gradient buffer, summed over the ranks in place
+    def _scratch(self, n):
+        eng = self.eng
+        if self.wire == "half" and (self._wire_buf is None or self._wire_buf.numel() < n):
+            self._wire_buf = torch.empty(n, dtype=eng.wire_dtype, device=eng.device)
+            if eng.wire_dtype == torch.float16 and self._amax is None:
+                self._amax = torch.zeros(1025, dtype=torch.float32, device=eng.device)
+        per = -(-n // max(self.world, 1))
+        if self.exchange != "all_reduce" and (self._shard_buf is None or self._shard_buf.numel() < per or self._shard_buf.dtype != (eng.wire_dtype if self.wire == "half" else torch.float32)):
+            self._shard_buf = torch.empty(per, dtype=eng.wire_dtype if self.wire == "half" else torch.float32, device=eng.device)
+
+    def plan(self, lo, hi):
+        """(wire bytes, 'all_reduce' | 'rs_ag') for the range — what exchange_range will do"""
+        n = hi - lo
+        nbytes = n * (2 if self.wire == "half" else 4)
+        rs = self.exchange == "rs_ag" or (self.exchange == "auto" and nbytes >= self.rs_min_mb * 1e6)
+        if n % max(self.world, 1):                                 # (never the case for the engine's buckets: their bounds are multiples of 128 floats)
+            rs = False
+        return nbytes, ("rs_ag" if rs else "all_reduce")
+
+    def exchange_range(self, lo, hi):
+        """grads[lo:hi] <- sum over ranks, on the CURRENT stream (the caller put the communication stream there and ordered it behind the producers)"""
+        eng, dist, W = self.eng, self.dist, self.world
+        n = hi - lo
+        _, how = self.plan(lo, hi)
+        self._scratch(n)
+        amax = None
+        if self.wire == "half":
+            buf = self._wire_buf[:n]
+            if eng.wire_dtype == torch.float16:                    # fp16: power-of-two scale from the global max |g| (one 4-byte all-reduce)
+                amax = self._amax
+                eng.wire_amax(lo, hi, amax)
+                dist.all_reduce(amax[:1], op=dist.ReduceOp.MAX, group=self.group); self.collectives += 1
+            eng.wire_pack(lo, hi, buf, amax, W)
+        else:
+            buf = eng.grads[lo:hi]
+        if how == "rs_ag":
+            shard = self._shard_buf[: n // W]
+            dist.reduce_scatter_tensor(shard, buf, group=self.group)
+            dist.all_gather_into_tensor(buf, shard, group=self.group)
+            self.collectives += 2
+        else:
+            dist.all_reduce(buf, group=self.group); self.collectives += 1
+        if self.wire == "half":
+            eng.wire_unpack(lo, hi, buf, amax, W)
+
     def backward(self, dcmds=None, dpars=None):
         eng = self.eng
         if not self.staged:
@@ -269,7 +363,7 @@ class GradSync:
         if self.stream is None:                                   # CPU / gloo (tests): sequential
             for st, (lo, hi) in enumerate(eng.buckets):
                 eng.backward(dcmds, dpars, stage=st)
-                self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
+                self.exchange_range(lo, hi)
             return
         cur = torch.cuda.current_stream(eng.device)
         side = eng.side_stage
@@ -278,7 +372,7 @@ class GradSync:
             t0 = torch.cuda.Event(enable_timing=True); t0.record(cur); self._ev = []
 
         def reduce_range(b_lo, b_hi, wait_side=False):
-            """all-reduce buckets b_lo..b_hi (adjacent ranges of the flat buffer) on the communication stream, behind everything enqueued on `cur`"""
+            """exchange buckets b_lo..b_hi (adjacent ranges of the flat buffer) on the communication stream, behind everything enqueued on `cur`"""
             lo, hi = eng.buckets[b_lo][0], eng.buckets[b_hi][1]
             ev = torch.cuda.Event(); ev.record(cur)
             with torch.cuda.stream(self.stream):
@@ -289,13 +383,14 @@ class GradSync:
                     return
                 if self.timing:
                     a = torch.cuda.Event(enable_timing=True); a.record(self.stream)
-                self.dist.all_reduce(eng.grads[lo:hi], group=self.group)
+                self.exchange_range(lo, hi)
                 if self.timing:
                     b = torch.cuda.Event(enable_timing=True); b.record(self.stream)
-                    self._ev.append((f"{b_lo}-{b_hi}" if b_hi != b_lo else str(b_lo), (hi - lo) * 4 / 1e6, t0, a, b))
+                    nbytes, how = self.plan(lo, hi)
+                    self._ev.append((f"{b_lo}-{b_hi}" if b_hi != b_lo else str(b_lo), nbytes / 1e6, t0, a, b, how))
 
         # The CAD ViT's stage (~230 small kernels) runs on the engine's side stream beside the frame ViT's stages.  Its bucket (+ the stem's) is
-        # all-reduced as soon as THAT stream is done: the communication stream — not the compute stream — waits for the side stream's completion
+        # exchanged as soon as THAT stream is done: the communication stream — not the compute stream — waits for the side stream's completion
         # event (vcad_join_side on the communication stream), so the exchange runs under the frame ViT's stages instead of after them.  If the
         # engine did not fork (enable_past_states off, side stream disabled, profiler on) the stage ran on `cur` and join_side() is a no-op: the
         # event recorded on `cur` AFTER the stage's launch (reduce_range does that) is what orders the collective behind it; when it did fork
@@ -312,12 +407,21 @@ class GradSync:
             self._t_end = torch.cuda.Event(enable_timing=True); self._t_end.record(cur)
 
     def comm_report(self):
-        """[{bucket, MB, issue_ms, done_ms}] of the last timed step (ms since the backward started) + when the backward's compute rejoined"""
+        """[{bucket, MB (on the wire), how, issue_ms, done_ms, GBps, busGBps}] of the last timed step (ms since the backward started) + when the backward's
+        compute rejoined.  GBps = wire bytes / (done - issue) — the exchange as this rank saw it, pack / unpack passes of the half wire format
+        included; busGBps = GBps x 2 (W - 1) / W, the per-link figure rccl-tests quotes (what to hold against xGMI's ~150 GB/s per link x 7)."""
         if not self._ev:
             return None
         torch.cuda.synchronize(self.eng.device)
-        rep = [{"bucket": lab, "MB": round(mb, 1), "issue_ms": round(t0.elapsed_time(a), 3), "done_ms": round(t0.elapsed_time(b), 3)} for lab, mb, t0, a, b in self._ev]
-        return {"collectives": rep, "backward_joined_ms": round(self._ev[0][2].elapsed_time(self._t_end), 3)}
+        W = max(self.world, 1)
+        rep = []
+        for lab, mb, t0, a, b, how in self._ev:
+            dur = a.elapsed_time(b)
+            gbps = mb / 1e3 / (dur / 1e3) if dur > 0 else None
+            rep.append({"bucket": lab, "MB": round(mb, 1), "how": how, "issue_ms": round(t0.elapsed_time(a), 3), "done_ms": round(t0.elapsed_time(b), 3),
+                        "GBps": round(gbps, 1) if gbps else None, "busGBps": round(gbps * 2 * (W - 1) / W, 1) if gbps else None})
+        return {"wire": self.wire if self.wire == "fp32" else str(self.eng.wire_dtype).replace("torch.", ""), "exchange": self.exchange,
+                "collectives": rep, "backward_joined_ms": round(self._ev[0][2].elapsed_time(self._t_end), 3)}
 
 
 # ------------------------------------------------------------------------------------------------ trainer
@@ -351,12 +455,15 @@ class BaseTrainer:
         self.restore_best_weights = cfg("restore_best_weights", False)
         self.stage_inputs = cfg("stage_inputs", True)             # double-buffered H2D staging of the train loader (data.DeviceStager)
         self.native._drop_rank = rank                             # every rank draws its own dropout masks
-        self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed, force_staged=cfg("force_bucketed_exchange", False))
+        self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed, force_staged=cfg("force_bucketed_exchange", False),
+                                 wire=cfg("grad_wire", "fp32"), exchange=cfg("grad_exchange", "all_reduce"), rs_min_mb=cfg("grad_rs_min_mb", 32.0))
         self.action_mask = self.native.action_mask.to(device) if hasattr(self.native.action_mask, "to") else self.native.action_mask
         self._best_params = None
 
     def _params_changed(self):
         self.native._shadow_fresh = False
+        if hasattr(self, "engine"):
+            self._reset_overflow_watch()              # (norms of the replaced weights must not move the new run's gradient scale)
 
     def log(self, message):
         if self.is_master:
@@ -375,6 +482,7 @@ class BaseTrainer:
         self.native.load_state_dict(strip_prefixes(ck["model_state_dict"]), strict=False)
         if ck.get("optimizer_state_dict"):
             self.optimizer.load_state_dict(ck["optimizer_state_dict"])
+        self._params_changed()
         return ck.get("epoch", 0)
 
     # ---- reference trainer.py:291-324 (uint8 frame batches stay uint8: they are normalised inside the patchify kernel)
@@ -437,13 +545,33 @@ class BaseTrainer:
                                   grad_scale=1.0 / self.gradsync.world)
         self.native.mark_shadow_fresh()
         if eng.cfg.dtype == L.VCAD_F16:
-            # fp16 engines: an overflowed backward leaves a non-finite gradient norm (the library skipped that update).  Looked at 32 steps late, so the
-            # host never waits for the step it just enqueued; every rank sees the same all-reduced gradients, hence the same norms and the same scale.
-            self._norm_ring = getattr(self, "_norm_ring", [])
-            self._norm_ring.append(norm)
-            if len(self._norm_ring) > 32 and eng.check_grad_overflow(self._norm_ring.pop(0)):
-                self._norm_ring.clear()
+            self._watch_overflow(norm)
         return out[0], met
+
+    OVERFLOW_WINDOW = 32
+
+    def _watch_overflow(self, norm):
+        """fp16 engines: an overflowed backward leaves a non-finite gradient norm (the library skipped that update).  Non-finite norms are COUNTED ON
+        THE DEVICE; the host reads one counter per OVERFLOW_WINDOW steps, and it reads the counter of the window BEFORE the one that just ended — so it
+        never waits for a step it has just enqueued (r04 did one `.item()` per step once its ring was full).  Every rank sees the same
+        all-reduced gradients, hence the same norms, counters and scale.  `_last_norm` keeps the newest norm tensor for diagnostics (tools/)."""
+        eng = self.engine
+        self._last_norm = norm
+        if getattr(self, "_ovf_acc", None) is None:
+            self._ovf_acc = torch.zeros((), dtype=torch.int32, device=norm.device); self._ovf_n = 0; self._ovf_prev = None
+        self._ovf_acc += (~torch.isfinite(norm[0])).to(torch.int32)
+        self._ovf_n += 1
+        if self._ovf_n >= self.OVERFLOW_WINDOW:
+            prev, self._ovf_prev = self._ovf_prev, (self._ovf_acc, self._ovf_n)
+            self._ovf_acc = torch.zeros((), dtype=torch.int32, device=norm.device); self._ovf_n = 0
+            if prev is not None:
+                bad = int(prev[0].item())                          # (a window that ended OVERFLOW_WINDOW steps ago)
+                if eng.note_overflows(bad, prev[1]):
+                    self.log(f"fp16 gradient overflow: {bad} of {prev[1]} updates skipped, gradient scale now {eng.grad_scale:.0f}")
+
+    def _reset_overflow_watch(self):
+        self._ovf_acc = None; self._ovf_prev = None; self._ovf_n = 0
+        self.engine.reset_overflow_history()
 
     def _class_w(self):
         return None
