@@ -326,3 +326,55 @@ def check_mx8(lib, device, M, N, K, to, bias=False, act=0, residual=False, seed=
     qerr = relerr(Cbuf.float(), exact)                       # what the 8-bit operands cost against the bf16 operands
     assert qerr < 6e-2, qerr
     return err, qerr
+
+
+def f16_overflow_drill(tr, batch, inject_at=3, factor=1e8, window=2, grow_after=8, max_steps=40):
+    """r05: the fp16 gradient-scale machinery of the TRAINER on a live run — a batch whose loss is `factor` times larger is injected
+    at step `inject_at` (the step is run by hand through the public engine API with external dlogits = factor x the loss's own: exactly a factor-times
+    larger loss); everything else is `trainer.train_step`.  Expected, and asserted: that update is SKIPPED (weights, moments, fp16 shadow untouched; a
+    non-finite norm comes back) -> one window later the trainer HALVES the scale and takes the Adam step counter back by one -> training RECOVERS
+    (finite norms, weights move again at the lower scale) -> after `grow_after` clean steps the scale CLIMBS BACK to the automatic rule's value and the
+    engine is in automatic mode again.  Returns the (step, scale, finite) history."""
+    import torch
+    from videocad_amd import lib as L
+    eng = tr.engine
+    assert eng.cfg.dtype == L.VCAD_F16
+    tr.OVERFLOW_WINDOW = window; eng.GROW_AFTER = grow_after
+    bd = tr.prepare_batch(batch)
+    B, T = bd["actions"].shape[0], bd["actions"].shape[1] - 1
+    hist, auto_scale, halved_at, regrown_at = [], None, None, None
+    for i in range(max_steps):
+        before = eng.params.clone()
+        if i == inject_at:
+            inputs = tr._prepare_model_inputs(bd, False)
+            tr.native._arm_dropout()
+            cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"])
+            eng.loss(cmds, pars, bd["actions"][:, 1:], tr._label_w(), use_mse=tr.use_mse, class_weights=tr._class_w())
+            dc, dp = eng.dl_views(B, T)
+            tr.gradsync.backward(dc * factor, dp * factor)
+            m0, v0, s0 = eng.m.clone(), eng.v.clone(), eng.shadow.clone()
+            norm = eng.optimizer_step(lr=tr.optimizer.lr, betas=tr.optimizer.betas, eps=tr.optimizer.eps, max_norm=1.0, grad_scale=1.0 / tr.gradsync.world)
+            tr.native.mark_shadow_fresh()
+            tr._watch_overflow(norm)
+            assert not bool(torch.isfinite(norm[0])), "the injected loss did not overflow the scaled backward"
+            assert torch.equal(eng.params, before) and torch.equal(eng.m, m0) and torch.equal(eng.v, v0) and torch.equal(eng.shadow, s0), "the overflowed update was not skipped"
+        else:
+            loss, _ = tr.train_step(bd)
+            assert bool(torch.isfinite(loss)) and bool(torch.isfinite(tr._last_norm[0])), i
+            assert not torch.equal(eng.params, before), f"step {i}: the weights did not move"
+        if auto_scale is None:
+            auto_scale = eng.grad_scale
+        hist.append((i, eng.grad_scale, i != inject_at))
+        if halved_at is None and eng.grad_scale < auto_scale:
+            halved_at = i
+            assert eng.grad_scale == auto_scale / 2 and eng.skipped_steps == 1 and eng._scale_target == auto_scale
+            assert eng.step_count == i + 1 - 1, (eng.step_count, i)            # the skipped update does not count towards Adam's bias correction
+        if halved_at is not None and regrown_at is None and eng.grad_scale == auto_scale and getattr(eng, "_scale_target", None) is None:
+            regrown_at = i
+            break
+    assert halved_at is not None and inject_at < halved_at <= inject_at + 2 * window, (halved_at, hist)
+    assert regrown_at is not None and regrown_at >= halved_at + grow_after - window, (regrown_at, hist)
+    # one more step in automatic mode at the restored scale
+    loss, _ = tr.train_step(bd)
+    assert bool(torch.isfinite(loss)) and eng.grad_scale == auto_scale and eng.skipped_steps == 1
+    return hist

@@ -456,3 +456,31 @@ def test_f16_scale_of_an_engine_that_never_overflowed_stays_automatic(emu16):
         assert not eng.note_overflows(0, 2000)
     assert not eng.check_grad_overflow(norm)
     assert eng.grad_scale == 1024.0 and getattr(eng, "_scale_target", None) is None and eng.step_count == 1
+
+
+def test_dropout_mask_stream_statistics(emu):
+    """r05: the dropout hash was shortened to two integer multiplies (csrc/vc_rt.h: vc_drop_hash; tools/dropout_hash_stats.py has the mixer study).
+    The masks the LIBRARY exports (vcad_dropout_mask: a pure function of (seed, site, index) — the same function every kernel draws from): keep rate
+    and scale of the effective p, no correlation between the two draws of one hash, neighbouring elements, rows, sites or step seeds."""
+    cfg = small_cfg()
+    eng, _ = build(cfg, L.VCAD_F32, emu)
+    n = 1 << 20
+    eng.set_dropout(0.1, seed=77)
+    a = eng.dropout_mask(1, 0, 3, n); b = eng.dropout_mask(1, 1, 3, n); c = eng.dropout_mask(3, 0, 11, n)
+    eng.set_dropout(0.1, seed=78)
+    a2 = eng.dropout_mask(1, 0, 3, n)
+    scale = 4096.0 / (4096 - 410)
+    vals = sorted(a.unique().tolist())
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - scale) < 1e-6 * scale
+    for m in (a, b, c, a2):
+        keep = float((m > 0).float().mean())
+        assert abs(keep - (1 - 410 / 4096)) < 1.5e-3, keep            # sd of the sample mean: 2.9e-4
+    def corr(x, y):
+        x = (x > 0).float(); y = (y > 0).float(); x = x - x.mean(); y = y - y.mean()
+        return abs(float((x * y).mean() / (x.pow(2).mean() * y.pow(2).mean()).sqrt()))
+    noise = 5.0 / n ** 0.5                                              # 5 sigma of an independent pair
+    assert corr(a[0::2], a[1::2]) < noise                               # the two draws of one hash
+    for s in (1, 2, 50, 512, 1024, 3072):
+        assert corr(a[:-s], a[s:]) < noise, s
+    assert corr(a, b) < noise and corr(a, c) < noise and corr(a, a2) < noise          # other layer / other module / next step's seed
+    eng.set_dropout(0.0)

@@ -144,3 +144,26 @@ def test_full_size_step_f16_in_tolerance_and_train_mode_sane(name, B, T):
     g_train = float(eng.optimizer_step(lr=1e-5)[0])
     assert np.isfinite(float(loss_t[0])) and np.isfinite(g_train) and 0.3 * g_eval < g_train < 3.0 * g_eval, (g_eval, g_train)
     assert not torch.equal(eng.view("embed_state.weight"), w0)
+
+
+def test_f16_overflow_drill_in_the_trainer(tmp_path):
+    """r05 on the device: a 1e8-times larger loss injected into a live trainer run -> that update is skipped -> the trainer halves the
+    gradient scale one window later (device-side counter, no per-step host sync) and takes the Adam step back -> the run recovers -> the scale climbs back
+    to the automatic rule's value (oputil.f16_overflow_drill asserts every stage); at the benchmark's batch shape, where the automatic scale is 4096."""
+    import shutil
+    from videocad_amd.model_factory import ModelFactory
+    from videocad_amd.trainer import create_trainer
+    HERE = os.path.dirname(os.path.abspath(__file__))
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), os.path.join(str(tmp_path), "class_weights.json")); os.chdir(tmp_path)
+    canon = json.load(open(os.path.join(HERE, "golden", "model_configs.json")))["cad_past_10_actions_and_states_timestep_embedding"]
+    sd = {k: synth.make_param_torch(k, s, DEV) for k, s in O.param_shapes().items()}
+    model, mtype = ModelFactory().create_model(canon["model_name"], dict(canon, compute_dtype="f16"), DEV, state_dict=sd)
+    model.train()
+    pk = {"loader": [], "sampler": None}
+    tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "drill"}, DEV, mtype, rank=0)
+    for (B, T, auto) in ((2, 6, 1024.0), (32, 64, 4096.0)):
+        tr._reset_overflow_watch(); tr.engine._scale_target = None; tr.engine.skipped_steps = 0; tr.engine.step_count = 0
+        tr.engine.set_grad_scale(0.0)
+        hist = U.f16_overflow_drill(tr, synth.make_batch_torch(B, T, 5, "cpu"), inject_at=5, window=4, grow_after=24, max_steps=80)
+        print(f"\n[f16 overflow drill B={B} T={T}] scale by step: " + " ".join(f"{int(s)}" + ("" if ok else "*") for _, s, ok in hist))
+        assert hist[0][1] == auto and min(h[1] for h in hist) == auto / 2 and hist[-1][1] == auto

@@ -418,3 +418,18 @@ def test_f16_model_through_the_reference_surface(tmp_path, monkeypatch):
         assert abs(float(loss2) - float(oloss)) < 2e-3 * abs(float(oloss))
         assert U.relerr(eng.grads, g_bridge) < 1e-6 and not torch.equal(eng.params, w0)
         assert tr._ovf_n == 1 and int(tr._ovf_acc) == 0 and bool(torch.isfinite(tr._last_norm[0]))
+
+
+def test_f16_overflow_drill_in_the_trainer(tmp_path, monkeypatch):
+    """skip -> halve -> recover -> climb back (oputil.f16_overflow_drill) under the emulator's fp16 build; the GPU twin is tests/test_f16_engine_gpu.py."""
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), "class_weights.json")
+    with U.emulated(), U.emulated("f16"):
+        cfg, ocfg = small(compute_dtype="f16")
+        model, mtype, shapes = make_model(cfg, ocfg)
+        model.train()
+        nb, tb = tbatch(1, 2, 4)
+        pk = {"loader": [tb], "sampler": None}
+        tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "drill"}, "cpu", mtype, rank=0)
+        hist = U.f16_overflow_drill(tr, tb, inject_at=3, window=2, grow_after=6)
+        assert hist[0][1] == 1024.0 and min(h[1] for h in hist) == 512.0 and hist[-1][1] == 1024.0

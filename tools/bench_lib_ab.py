@@ -1,0 +1,48 @@
+"""Interleaved A/B of two BUILDS of the product library on one box (box-to-box spread is +-2-3 %, a 1 % change only shows inside one call).
+
+    python tools/bench_lib_ab.py <libA.so> <libB.so> [rounds] [steps] [extra bench.py flags ...]
+
+Runs `bench.py --profile-only` (the headline train steps only) in a fresh process per leg, A B A B ..., with `videocad_amd.lib.LIB_PATH` pointed at the
+given build (tools only: the product has no library override), and prints ms per step of every leg plus the per-build medians.  A library path of
+"-" means the in-tree build.  Typical use: an older build kept under tools/_bin/ (git worktree of the previous commit, `make libvcad_hip.so`) against HEAD."""
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def leg(lib, steps, extra):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from videocad_amd import lib as L\n"
+            "p = %r\n"
+            "if p != '-': L.LIB_PATH = p\n"
+            "import bench\n"
+            "bench.main(['--profile-only', '--steps', %r, '--warmup', '5'] + %r)\n") % (ROOT, lib, str(steps), list(extra))
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            j = json.loads(line)
+            return j["ms_per_step"], j.get("ms_per_step_median")
+    raise RuntimeError(f"no bench line from {lib}: {out.stderr[-800:]}")
+
+
+def main():
+    a, b = sys.argv[1], sys.argv[2]
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    extra = sys.argv[5:]
+    res = {a: [], b: []}
+    for r in range(rounds):
+        for lib in (a, b):
+            ms, med = leg(lib, steps, extra)
+            res[lib].append(ms)
+            print(f"round {r} {'A' if lib == a else 'B'} {os.path.basename(lib) if lib != '-' else 'in-tree'}: {ms:.3f} ms/step (median of steps {med})", flush=True)
+    ma, mb = statistics.median(res[a]), statistics.median(res[b])
+    print(f"A median {ma:.3f} ms  B median {mb:.3f} ms  B - A = {mb - ma:+.3f} ms ({(mb / ma - 1) * 100:+.2f} %)")
+
+
+if __name__ == "__main__":
+    main()
