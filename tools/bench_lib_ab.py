@@ -1,6 +1,6 @@
 """Interleaved A/B of two BUILDS of the product library on one box (box-to-box spread is +-2-3 %, a 1 % change only shows inside one call).
 
-    python tools/bench_lib_ab.py <libA.so> <libB.so> [rounds] [steps] [extra bench.py flags ...]
+    python tools/bench_lib_ab.py <libA.so> <libB.so> [<libC.so> ...] [rounds] [steps] [extra bench.py flags ...]
 
 Runs `bench.py --profile-only` (the headline train steps only) in a fresh process per leg, A B A B ..., with `videocad_amd.lib.LIB_PATH` pointed at the
 given build (tools only: the product has no library override), and prints ms per step of every leg plus the per-build medians.  A library path of
@@ -30,18 +30,22 @@ def leg(lib, steps, extra):
 
 
 def main():
-    a, b = sys.argv[1], sys.argv[2]
-    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-    extra = sys.argv[5:]
-    res = {a: [], b: []}
+    args = sys.argv[1:]
+    libs = []
+    while args and not args[0].isdigit() and not args[0].startswith("--"):
+        libs.append(args.pop(0))
+    rounds = int(args.pop(0)) if args and args[0].isdigit() else 3
+    steps = int(args.pop(0)) if args and args[0].isdigit() else 20
+    extra = args
+    res = {lib: [] for lib in libs}
     for r in range(rounds):
-        for lib in (a, b):
+        for i, lib in enumerate(libs):
             ms, med = leg(lib, steps, extra)
             res[lib].append(ms)
-            print(f"round {r} {'A' if lib == a else 'B'} {os.path.basename(lib) if lib != '-' else 'in-tree'}: {ms:.3f} ms/step (median of steps {med})", flush=True)
-    ma, mb = statistics.median(res[a]), statistics.median(res[b])
-    print(f"A median {ma:.3f} ms  B median {mb:.3f} ms  B - A = {mb - ma:+.3f} ms ({(mb / ma - 1) * 100:+.2f} %)")
+            print(f"round {r} {chr(65 + i)} {os.path.basename(lib) if lib != '-' else 'in-tree'}: {ms:.3f} ms/step (median of steps {med})", flush=True)
+    meds = [statistics.median(res[lib]) for lib in libs]
+    for i, lib in enumerate(libs):
+        print(f"{chr(65 + i)} {os.path.basename(lib) if lib != '-' else 'in-tree'}: median {meds[i]:.3f} ms" + (f"  ({meds[i] - meds[0]:+.3f} ms, {(meds[i] / meds[0] - 1) * 100:+.2f} % vs A)" if i else ""))
 
 
 if __name__ == "__main__":

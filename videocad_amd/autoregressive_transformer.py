@@ -14,7 +14,10 @@ Differences that are deliberate and documented in DESIGN.md:
     by the optimiser, as in the reference where their .grad stays None; encoder != "vit" raises
   * dropout is a stateless counter-based mask (hash of step seed, site, element index) regenerated in the backward:
     statistically equivalent to nn.Dropout at the same sites, not bit-identical to torch's Philox stream
-There is no CPU fallback: calling forward on a non-CUDA module raises.
+  * `compute_dtype` (extra kwarg / JSON key): "f16" (DEFAULT since r05 — 16-bit tensors with ten mantissa bits on libvcad_hip_f16.so: logits within 1e-3
+    of the fp32 reference and arg-max exact, north_star's tolerance, at 98 % of the bf16 mode's speed; gradient scale handled by the engine and the
+    trainer), "bf16" (the throughput mode of BASELINE's metric: 3.9e-3 on logits), "bf16x3" (fp32 tensors, 7e-6), "f32" (exact fp32 MFMA)
+There is no CPU fallback: calling forward on a module whose buffers are not device memory raises (the library refuses).
 """
 from __future__ import annotations
 
@@ -82,7 +85,7 @@ class AutoRegressiveTransformer(nn.Module):
                  enable_past_actions=False, enable_past_states=False, enable_timestep_embedding=False, num_classes=5,
                  num_params=6, num_params_values=1000, num_decoder_layers=8, dim_feedforward=512,
                  use_pretrained_cad_model=False, nhead=4, dropout=0.1, normalize=False, device=None, encoder="vit",
-                 num_views=0, window_size=1, compute_dtype: str = "bf16", **kwargs):
+                 num_views=0, window_size=1, compute_dtype: str = "f16", **kwargs):
         super().__init__()
         assert window_size > 0, "Window size must be greater than 0"          # reference :52
         if encoder != "vit" or use_pretrained_cad_model:

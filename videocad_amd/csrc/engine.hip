@@ -46,9 +46,13 @@ struct DecW { long sa_w, sa_b, sa_ow, sa_ob, ca_w, ca_b, ca_ow, ca_ob, w1, b1, w
 // CAD ViT (32 images: ~230 launch-bound kernels, 6 % of a step when serialised) runs on concurrently with the frame ViT.
 struct Lane { float* scr_splitk; size_t scr_splitk_bytes; float* scr_colsum; size_t scr_colsum_bytes; float* scr_lnpart; size_t scr_lnpart_bytes;
               int* claim;          // 16 ints: ticket counters of the persistent GEMM's dynamic item claiming (gemm_dma.h), zero between launches
-              float *t_dx, *t_dpe; void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_dum; float* t_delta; uint8_t *q8a, *q8as; };
+              float *t_dx, *t_dpe; void *t_dz, *t_dh, *t_dao, *t_dqkv, *t_dpn, *t_dum; float* t_delta; uint8_t *q8a, *q8as;
+              void* t_y[2]; };     // r05, forward: 16-bit outputs of a ViT layer's to_out / net.4 Linear, added to the residual stream by the LayerNorm pass behind them
 
-struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo; };
+struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao; float* xm; float* stat_f; void* h_f; void* z; void* g; float* xo;
+                      // r05: per-layer homes of the backward's small reductions' partial rows — the two LayerNorm backwards' [blocks][dgamma | dbeta | bias gradient]
+                      // and the activation-derivative pass's [blocks][b1 gradient] — so their column sums can be deferred (vcad_engine::VitColsums)
+                      float *part_fn, *part_an, *part_b1; };
 struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e; };
 struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* st1; float* x1; void* q_c; void* kv_c; float* lse_c; void* ao_c;
                       float* s2; float* st2; float* x2; void* f1; float* s3; float* st3; float* x3;
@@ -119,6 +123,10 @@ struct vcad_engine {
     } def;
     // The eight cross-attention K / V projections depend only on the decoder's memory: ONE grouped launch in front of the layer loop (8 x 16 x 16 = 2 048
     // tiles of 128 x 128 over the 256 CUs) instead of eight dependent 2 048-row launches of 256 tiles each inside it (r04)
+    // r05: the ViT backward reduced every layer's LayerNorm-backward / activation-derivative partial rows with an in-line launch of 24 workgroups (~8 us each on
+    // the critical path, 4 per full layer): they are now left in per-layer buffers and reduced by ONE grouped column sum at the end of the stage that
+    // owns the parameters — the decoder's Deferred idea.  One job table per (tower, part of vit_backward); built on first use (device pointers inside).
+    struct VitColsums { std::vector<ColsumJob> jobs; ColsumJob* d_jobs = nullptr; float* partial = nullptr; int strips = 0, chunks = 0; bool ready = false; } vcs[2][3];
     struct KvForward { std::vector<GemmCall> calls; GemmParams* d_probs = nullptr; int* d_tiles = nullptr; int total_tiles = 0; double flops = 0; bool ready = false; } kvf;
 };
 
@@ -240,6 +248,15 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
             l.lse = b.take<float>(a.N * c.vit_heads * (P + 1) * 4); l.ao = b.take<void>(R * inner * es); l.xm = b.take<float>(R * D * 4);
             l.stat_f = b.take<float>(R * 2 * 4); l.h_f = b.take<void>(R * D * es); l.z = b.take<void>(R * c.vit_mlp * es);
             l.g = b.take<void>(R * c.vit_mlp * es); l.xo = b.take<float>(R * D * 4);
+            l.part_fn = b.take<float>((size_t)vc_ln_bwd_blocks(R) * 3 * D * 4); l.part_an = b.take<float>((size_t)vc_ln_bwd_blocks(R) * 3 * D * 4);
+            l.part_b1 = b.take<float>((size_t)vc_dact_bwd_blocks(R, c.vit_mlp) * c.vit_mlp * 4);
+        }
+        for (int part = 0; part < 3; ++part) {
+            vcad_engine::VitColsums& vc = e->vcs[v][part];
+            vc.d_jobs = b.take<ColsumJob>((size_t)c.vit_depth * 5 * sizeof(ColsumJob));
+            // pass-0 partials of the grouped kernel: per job ceil(rows / 128) x cols floats (LayerNorm jobs: <= 4 x 2 D and 4 x D; b1: <= 16 x vit_mlp)
+            vc.partial = b.take<float>((size_t)c.vit_depth * (2 * 4 * 3L * D + 17L * c.vit_mlp) * 4);
+            vc.ready = false;
         }
         a.statn = b.take<float>(a.N * 2 * 4); a.e = b.take<void>(a.N * D * es);
     }
@@ -276,6 +293,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         l.t_dx = b.take<float>(R * D * 4); l.t_dpe = b.take<float>(Rp * D * 4); l.t_dz = b.take<void>(R * c.vit_mlp * es);
         l.t_dh = b.take<void>(R * D * es); l.t_dao = b.take<void>(R * inner * es); l.t_dqkv = b.take<void>(R * 3 * inner * es);
         l.t_dpn = b.take<void>(Rp * pd * es);
+        l.t_y[0] = b.take<void>(R * D * es); l.t_y[1] = b.take<void>(R * D * es);
         l.t_dum = b.take<void>((R * D > M * H ? R * D : M * H) * 4);
         const long dmax = (long)B * c.nhead * T, vmax = Nv * c.vit_heads * (P + 1);
         l.t_delta = b.take<float>((dmax > vmax ? dmax : vmax) * 4);
@@ -324,6 +342,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 // the ViT MLP's GELU / GELU' as their own passes behind plain GEMMs (bf16 mode): 1 = yes, 0 = fused into the GEMM epilogues (r01; A/B build only)
 #define g_split_gelu VC_AB(split_gelu, 1)
 #define g_no_side VC_AB(no_side, 0)
+#define g_res_in_ln VC_AB(res_in_ln, 1)       // A/B: 0 = r04's residual adds in the to_out / net.4 GEMM epilogues
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CK_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -426,10 +445,12 @@ struct Ctx {
         if (need > L().scr_colsum_bytes) { vc_set_error("colsum scratch too small (%zu)", need); return VC_ERR_WORKSPACE; }
         return vc_colsum(X.dt, X.p, X.ld, rows, cols, out, accumulate, batch, bsx, bso, L().scr_colsum, s);
     }
-    int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C, bool pk = false) const {
+    // add / sum32 (r05): x + add (the 16-bit branch output of the Linear in front) is written to sum32 as the new residual stream and normalised
+    int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C, bool pk = false,
+               const void* add = nullptr, float* sum32 = nullptr) const {
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = x; p.ldx = ldx; p.gamma = Pf(wo); p.beta = Pf(bo); p.y32 = y32; p.ldy32 = ldy32; p.yt = yt; p.ldyt = ldyt;
-        p.stats = stats; p.rows = rows; p.eps = 1e-5f;
+        p.stats = stats; p.rows = rows; p.eps = 1e-5f; p.add = add; p.ldadd = C; p.sum32 = sum32; p.ldsum = C;
         return vc_ln_fwd(tx, vt(pk), C, 0, p, s);
     }
     // dx32 (+T copy) = add_in + LNbwd(dy);  dgamma/dbeta written to the grad buffer
@@ -447,7 +468,8 @@ struct Ctx {
         }
         // du_colsum: the bias gradient of the Linear that consumes du, reduced by this kernel instead of a column-sum pass over du
         // defer_partial: the dgamma / dbeta partial rows are left in that buffer (the caller reduces them later, in a grouped column sum)
-        if (defer_partial) return vc_ln_bwd(td, VC_F32, vt(du_pk), C, 0, p, defer_partial, nullptr, nullptr, L().scr_colsum, s, nullptr);
+        // (du_colsum with defer_partial: the kernel writes a third partial row per block — only its presence matters here, the deferred job table holds the destination)
+        if (defer_partial) return vc_ln_bwd(td, VC_F32, vt(du_pk), C, 0, p, defer_partial, nullptr, nullptr, L().scr_colsum, s, du ? du_colsum : nullptr);
         return vc_ln_bwd(td, VC_F32, vt(du_pk), C, 0, p, L().scr_lnpart, Gf(wo), Gf(bo), L().scr_colsum, s, du ? du_colsum : nullptr);
     }
 };
@@ -482,6 +504,11 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
     }
     const float* x = a.x0;
     const long TD = (long)(P + 1) * D, TI = (long)(P + 1) * inner;      // per-frame strides: cls rows are rows n*(P+1)
+    // r05, 16-bit engines: a full layer's to_out / net.4 Linears write their (bias + dropout) output y as a 16-bit tensor with the persistent kernel's
+    // wide-tile epilogue, and the LayerNorm pass that follows adds it to the residual stream (x + y -> xm / xo in fp32, then the statistics):
+    // the residual epilogue of the 128-wide tile ran at 0.17 matrix-core busy (profiles/r04_summary.md), the LayerNorm pass is HBM-bound either way.
+    const bool res_in_ln = e->dt == VC_BF16 && e->ct == VC_BF16 && !e->fp8 && g_res_in_ln;
+    const void* pend = nullptr; float* pend_sum = nullptr;              // branch output not yet added: the next LayerNorm pass writes x + pend -> pend_sum
     for (int L = 0; L < c.vit_depth; ++L) {
         const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
         // Only the cls token of the LAST layer is consumed (pool='cls'): its Q projection, attention output, out-proj and
@@ -490,7 +517,8 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
         const bool pk = cx.pk_acts() && !cls_only;          // bf16x3: this layer's GEMM-only tensors (h_a, qkv, ao, h_f, z, g) are stored pre-split
         const float scale = 1.0f / sqrtf((float)c.vit_dim_head);
         const char* q = (const char*)l.qkv;
-        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D, pk));
+        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D, pk, pend, pend_sum));
+        if (pend) { x = pend_sum; pend = nullptr; pend_sum = nullptr; }
         AttnParams ap; memset(&ap, 0, sizeof(ap));
         ap.q = q; ap.k = q + (size_t)inner * e->esz; ap.v = q + (size_t)2 * inner * e->esz; ap.o = l.ao;
         ap.ldq = ap.ldk = ap.ldv = 3 * inner; ap.ldo = inner; ap.lse = l.lse;
@@ -502,10 +530,15 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
             if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_a, D), wl.qkv, cx.AT(l.qkv, 3 * inner), (int)R, 3 * inner, D, Epi()));
             else CK(cx.lin_fwd(cx.VT(l.h_a, D, pk), cx.W(wl.qkv, D), cx.VT(l.qkv, 3 * inner, pk), (int)R, 3 * inner, D, Epi()));
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
+            if (res_in_ln) {
+                { Epi ep; ep.bias = cx.Pf(wl.ob); ep.drop = d_out; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.AT(cx.L().t_y[0], D), (int)R, D, inner, ep)); }
+                CK(cx.ln_fwd(VC_F32, x, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D, false, cx.L().t_y[0], l.xm));
+            } else {
             { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; ep.drop = d_out;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.ao, inner), wl.ow, cx.A32(l.xm, D), (int)R, D, inner, ep));
               else CK(cx.lin_fwd(cx.VT(l.ao, inner, pk), cx.W(wl.ow, inner), cx.A32(l.xm, D), (int)R, D, inner, ep)); }
             CK(cx.ln_fwd(VC_F32, l.xm, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D, pk));
+            }
             if (!q8 && e->dt == VC_BF16 && g_split_gelu) {     // bf16: plain GEMM (persistent kernel) -> z, then the activation pass (norm.h: act_fwd_bf16_kernel)
                 { Epi ep; ep.bias = cx.Pf(wl.b1); CK(cx.lin_fwd(cx.AT(l.h_f, D), cx.W(wl.w1, D), cx.AT(l.z, c.vit_mlp), (int)R, c.vit_mlp, D, ep)); }
                 CK(vc_act_fwd_bf16(l.z, l.g, R, c.vit_mlp, VC_ACT_GELU, d_act, cx.s));
@@ -513,7 +546,11 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
               Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_f, D), wl.w1, cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep));
               else CK(cx.lin_fwd(cx.VT(l.h_f, D, pk), cx.W(wl.w1, D), cx.VT(l.g, c.vit_mlp, pk), (int)R, c.vit_mlp, D, ep)); }     // (pk: the pre-activation side output z is pre-split too — it has the output's type)
-            { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
+            if (res_in_ln) {     // xo = xm + y: written by the NEXT layer's first LayerNorm pass (every layer, the class-token-only last one included, starts with one over all rows)
+                Epi ep; ep.bias = cx.Pf(wl.b4); ep.drop = d_mlp; CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_y[1], D), (int)R, D, c.vit_mlp, ep));
+                pend = cx.L().t_y[1]; pend_sum = l.xo;
+            } else {
+              Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.g, c.vit_mlp), wl.w4, cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep));
               else CK(cx.lin_fwd(cx.VT(l.g, c.vit_mlp, pk), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
         } else {
@@ -528,10 +565,53 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
             { Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = TD; ep.drop = d_mlp;
               CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, TD), (int)N, D, c.vit_mlp, ep)); }
         }
-        x = l.xo;
+        x = pend ? (const float*)l.xm : (const float*)l.xo;          // (with a pending branch output the stream is still xm; xo appears with the next LayerNorm pass)
     }
+    if (pend) { vc_set_error("internal: ViT forward ended with an unadded branch output"); return VC_ERR_ARG; }       // (cannot happen: the last layer is the class-token-only one)
     // final LN on the cls row only (pool = 'cls', mlp_head = Identity)
     CK(cx.ln_fwd(VC_F32, x, (long)(P + 1) * D, w.normw, w.normb, nullptr, 0, a.e, D, a.statn, N, D));
+    return 0;
+}
+
+// Job table of one (tower, part) of vit_backward: every layer's deferred column sums (vcad_engine::VitColsums), in the layer loop's order and under its
+// conditions — norm weight / bias pairs are adjacent in the flat buffer (one 2 D-wide job), the third partial row of a LayerNorm backward is the bias
+// gradient of the Linear that consumes the masked gradient it emitted (to_out.bias / the layer below's net.4 bias).
+int build_vit_colsums(const Ctx& cx, int v, int part) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
+    vcad_engine::VitColsums& vc = e->vcs[v][part];
+    const int D = c.vit_dim, g = c.image_size / c.patch_size, P = g * g;
+    const long N = a.N, R = N * (P + 1);
+    const int split_l = c.vit_depth / 2;
+    int Lhi = c.vit_depth - 1, Llo = 0;
+    if (part == 1) Llo = split_l; if (part == 2) Lhi = split_l - 1;
+    vc.jobs.clear();
+    auto add = [&](const float* x, long ld, long rows, int cols, float* out) {
+        ColsumJob j; memset(&j, 0, sizeof(j));
+        j.x = x; j.ld = ld; j.rows = (int)rows; j.cols = cols; j.out = out; j.is_bf16 = 0;
+        vc.jobs.push_back(j);
+    };
+    for (int L = Lhi; L >= Llo; --L) {
+        const VitW::L& wl = w.l[L]; const VitLayerActs& l = a.L[L];
+        const bool cls_only = (L == c.vit_depth - 1);
+        const long Rm = cls_only ? N : R;
+        if (wl.fnb != wl.fnw + D || wl.anb != wl.anw + D) { vc_set_error("internal: ViT LayerNorm weight / bias not adjacent"); return VC_ERR_ARG; }
+        if (e->dt == VC_BF16 && g_split_gelu && !cls_only) add(l.part_b1, c.vit_mlp, vc_dact_bwd_blocks(Rm, c.vit_mlp), c.vit_mlp, cx.Gf(wl.b1));
+        add(l.part_fn, 3L * D, vc_ln_bwd_blocks(Rm), 2 * D, cx.Gf(wl.fnw));
+        add(l.part_fn + 2 * D, 3L * D, vc_ln_bwd_blocks(Rm), D, cx.Gf(wl.ob));
+        if (L > Llo) {
+            add(l.part_an, 3L * D, vc_ln_bwd_blocks(R), 2 * D, cx.Gf(wl.anw));
+            add(l.part_an + 2 * D, 3L * D, vc_ln_bwd_blocks(R), D, cx.Gf(w.l[L - 1].b4));
+        } else add(l.part_an, 2L * D, vc_ln_bwd_blocks(R), 2 * D, cx.Gf(wl.anw));
+    }
+    int strips = 0, chunks = 1; long poff = 0;
+    for (auto& j : vc.jobs) {
+        j.strip_start = strips; j.part_off = poff; strips += VC_CEIL_DIV(j.cols, 256);
+        const int ch = VC_CEIL_DIV(j.rows, 128); poff += (long)ch * j.cols; chunks = ch > chunks ? ch : chunks;
+    }
+    if ((int)vc.jobs.size() > c.vit_depth * 5 || poff > (long)c.vit_depth * (2 * 4 * 3L * D + 17L * c.vit_mlp)) { vc_set_error("internal: ViT column-sum table overflows its plan"); return VC_ERR_WORKSPACE; }
+    vc.strips = strips; vc.chunks = chunks;
+    CK(vc_upload(vc.d_jobs, vc.jobs.data(), vc.jobs.size() * sizeof(ColsumJob), cx.s));
+    vc.ready = true;
     return 0;
 }
 
@@ -546,6 +626,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
     const int split = c.vit_depth / 2;
     int Lhi = c.vit_depth - 1, Llo = 0;
     if (part == 1) Llo = split; if (part == 2) Lhi = split - 1;
+    const bool defer_cs = true;                                                // the layers' small column sums: one grouped launch at the end (VitColsums)
+    if (defer_cs && !e->vcs[v][part].ready) CK(build_vit_colsums(cx, v, part));
     if (part != 2) {
         CK(vc_memset_async(dx, 0, (size_t)R * D * 4, cx.s));
         const float* xl = a.L[c.vit_depth - 1].xo;
@@ -572,13 +654,14 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
           if (cx.hasT(wl.w4T)) CK(cx.lin_dgrad_T(du, cx.WT(wl.w4T, D), cx.AT(cx.L().t_dz, c.vit_mlp), (int)Rm, D, c.vit_mlp, epg));
           else CK(cx.lin_dgrad(du, cx.W(wl.w4, c.vit_mlp), cx.VT(cx.L().t_dz, c.vit_mlp, pk), (int)Rm, D, c.vit_mlp, epg));
           // (the activation-derivative pass also reduces its output over rows: b1's gradient without a column-sum pass over dz)
-          if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), cx.L().scr_lnpart, cx.L().scr_lnpart_bytes, cx.L().scr_colsum));
+          if (split && defer_cs) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), l.part_b1, (size_t)vc_dact_bwd_blocks(Rm, c.vit_mlp) * c.vit_mlp * 4, nullptr, true));
+          else if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), cx.L().scr_lnpart, cx.L().scr_lnpart_bytes, cx.L().scr_colsum));
           have_db1 = split; }
         CK(cx.lin_wgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.VT(l.h_f, D, pk), cx.Gf(wl.w1), D, have_db1 ? nullptr : cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
         if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         else CK(cx.lin_dgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         // attention block (xm = x + drop(Wo ao + bo)): the LayerNorm backward also emits du = dx * mask_out
-        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, nullptr, cx.Gf(wl.ob), nullptr, pk));
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, nullptr, cx.Gf(wl.ob), defer_cs ? l.part_fn : nullptr, pk));
         CK(cx.lin_wgrad(du, cx.VT(l.ao, ldao, pk), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
         if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.VT(cx.L().t_dao, inner, pk), (int)Rm, D, inner, Epi()));
@@ -601,9 +684,10 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
         else CK(cx.lin_dgrad(cx.VT(cx.L().t_dqkv, 3 * inner, pk), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
         // (the layer below is never the cls-only one: the du it receives is pre-split whenever the mode stores pre-split tensors)
-        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), nullptr, cx.pk_acts())); have_du = true; }
-        else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D));
+        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), defer_cs ? l.part_an : nullptr, cx.pk_acts())); have_du = true; }
+        else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, vc_drop{0u, 0u, 1.0f}, nullptr, nullptr, nullptr, defer_cs ? l.part_an : nullptr));
     }
+    if (defer_cs) { const vcad_engine::VitColsums& vc = e->vcs[v][part]; CK(vc_colsum_grouped(vc.d_jobs, (int)vc.jobs.size(), vc.strips, vc.chunks, vc.partial, cx.s)); }
     if (part != 1) {
         { const vc_drop d = cx.site(v + 1, 0, Ctx::K_EMB);      // emb_dropout: everything below sees dx * mask
           if (d.key) CK(vc_dropout_mul(VC_F32, dx, D, dx, D, R, D, d, cx.s)); }
@@ -1040,6 +1124,7 @@ int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, v
     e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = e->dt == VC_BF16 ? (vc_bf16*)shadow : nullptr;
     e->Spk = e->ct == VC_X3 ? (uint32_t*)shadow : nullptr;      // optional: without it the bf16x3 GEMMs split the fp32 weights while staging
     e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false; e->kvf.ready = false;
+    for (int v = 0; v < 2; ++v) for (int part = 0; part < 3; ++part) e->vcs[v][part].ready = false;
     return 0;
 }
 // No CPU fallback: an engine whose buffers still live in host memory (a model built on "cpu" and not yet moved) is refused by every entry point that

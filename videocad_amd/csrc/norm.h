@@ -107,6 +107,11 @@ struct LnFwdParams {
     // EMBED mode: input row r = n*P + p  ->  output row n*(P+1) + p + 1, plus pos[p+1]; extra rows write cls+pos[0]
     const float* pos; const float* cls; int P;
     vc_drop drop;                     // EMBED mode: emb_dropout on the finished token rows (idx = out_row * C + col)
+    // r05 (plain mode): the residual add of the block in front of this LayerNorm.  `add` (type TY, [rows][ldadd]) is the branch output the preceding
+    // Linear wrote (bias and dropout applied, 16-bit); x + add is the new fp32 residual stream, written to sum32 and normalised.  The add used to sit
+    // in that Linear's epilogue, where the persistent GEMM's eight lock-stepped waves pay for the fp32 side stream with idle matrix cores
+    // (0.17 busy); here it rides on a pass that is HBM-bound anyway.
+    const void* add; long ldadd; float* sum32; long ldsum;
 };
 
 // MODE 0 plain, 1 PATCH (x = frames), 2 EMBED (see above; grid covers N*(P+1) output rows)
@@ -136,6 +141,13 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
     }
     if constexpr (MODE == 1) patch_load<VPL>(p.x, p.u8, row, v, lane, p.img, p.patch, p.P, p.ldx);   // P = T, ldx = batch stride
     else row_load<TX, VPL>((const TX*)p.x + in_row * p.ldx, v, lane);
+    if constexpr (MODE == 0) if (p.add) {
+        float a[VPL];
+        row_load<TY, VPL>((const TY*)p.add + row * p.ldadd, a, lane);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] += a[i];
+        if (p.sum32) row_store<float, VPL>(p.sum32 + row * p.ldsum, v, lane);
+    }
     float mean, rstd;
     row_stats<VPL>(v, p.eps, mean, rstd);
     float g[VPL], b[VPL];

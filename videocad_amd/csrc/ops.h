@@ -85,7 +85,7 @@ int vc_pack_x3(const float* x, uint32_t* y, long n, vc_stream_t s);       // y[i
 // g = dropout(act(z)) / dz = (dz * dropmask) * act'(z): compact bf16 [rows, cols], masks indexed like the fused GEMM epilogue
 int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_drop d, vc_stream_t s);
 int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out = nullptr, float* partial_ws = nullptr,
-                     size_t partial_bytes = 0, float* colsum_ws = nullptr);
+                     size_t partial_bytes = 0, float* colsum_ws = nullptr, bool defer_reduce = false);      // defer_reduce: leave the [vc_dact_bwd_blocks][cols] partial rows in partial_ws (the caller sums them later); fails if the fused form does not apply
 long vc_dact_bwd_blocks(long rows, int cols);
 // grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);

@@ -18,7 +18,8 @@ static int ln_fwd_m(int C, int mode, LnFwdParams p, vc_stream_t s) {
 }
 int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s) {
     if (p.rows <= 0) return VC_OK;
-    ProfScope ps(VC_CAT_NORM, 0, (double)p.rows * C * ((tx == VC_BF16 ? 2 : 4) + (p.y32 ? 4 : 0) + (p.yt ? (ty == VC_BF16 ? 2 : 4) : 0)), s);
+    if (p.add && (mode != 0 || ty == VC_PK)) { vc_set_error("ln_fwd: the fused residual add belongs to the plain mode with an fp32 / 16-bit branch tensor"); return VC_ERR_UNSUPPORTED; }
+    ProfScope ps(VC_CAT_NORM, 0, (double)p.rows * C * ((tx == VC_BF16 ? 2 : 4) + (p.y32 ? 4 : 0) + (p.yt ? (ty == VC_BF16 ? 2 : 4) : 0) + (p.add ? (ty == VC_BF16 ? 2 : 4) + (p.sum32 ? 4 : 0) : 0)), s);
     if (tx == VC_F32 && ty == VC_F32) return ln_fwd_m<float, float>(C, mode, p, s);
     if (tx == VC_F32 && ty == VC_BF16) return ln_fwd_m<float, vc_bf16>(C, mode, p, s);
     if (tx == VC_BF16 && ty == VC_BF16) return ln_fwd_m<vc_bf16, vc_bf16>(C, mode, p, s);
@@ -208,7 +209,7 @@ int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_dro
 // colsum_out (optional): column sums of the result, i.e. the bias gradient of the Linear whose pre-activation z is; partial_ws holds
 // vc_dact_bwd_blocks(rows, cols) x cols floats, colsum_ws as for vc_colsum
 long vc_dact_bwd_blocks(long rows, int cols) { const long b = VC_CEIL_DIV(rows, (long)(256 / (cols / 8 > 0 ? cols / 8 : 1))); return b > 2048 ? 2048 : (b < 1 ? 1 : b); }
-int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out, float* partial_ws, size_t partial_bytes, float* colsum_ws) {
+int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out, float* partial_ws, size_t partial_bytes, float* colsum_ws, bool defer_reduce) {
     if (rows <= 0) return VC_OK;
     if (int rc = act_check(dz, z, rows, cols, "dact_bwd")) return rc;
     if (kind == VC_ACT_GELU) kind = VC_ACT_GELU_FAST;
@@ -223,6 +224,7 @@ int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_
             VC_LAUNCH(dact_bwd_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(n8, 256)), dim3(256), 0, s, (vc_bf16*)dz, (const vc_bf16*)z, n8, kind, d);
         }
     }
+    if (defer_reduce) { if (!fused) { vc_set_error("dact_bwd: deferred reduction needs the fused partial-row form"); return VC_ERR_ARG; } return VC_OK; }
     if (!colsum_out) return VC_OK;
     if (fused) return vc_colsum(VC_F32, partial_ws, cols, vc_dact_bwd_blocks(rows, cols), cols, colsum_out, 0, 1, 0, 0, colsum_ws, s);
     return vc_colsum(VC_BF16, dz, cols, rows, cols, colsum_out, 0, 1, 0, 0, colsum_ws, s);

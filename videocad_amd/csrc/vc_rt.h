@@ -438,7 +438,7 @@ VC_DEV uint32_t vc_cvt_pk_e4m3(float a, float b) { return (uint32_t)vc_f32_to_e4
 // hash each (the two integer multiplies of the mixer are quarter-rate VALU on CDNA).
 // key = vc_drop_key(step seed, site id) (0 = disabled), thr = round(p * 4096), scale = 4096 / (4096 - thr) (unbiased for the
 // effective p = thr / 4096; p = 0.1 -> 0.10010).
-struct vc_drop { uint32_t key, thr; float scale; uint32_t key2; };      // (key2: second key word, derived from key — vc_drop_make)
+struct vc_drop { uint32_t key, thr; float scale; };
 VC_HD uint32_t vc_hash32(uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
 VC_HD uint32_t vc_drop_key(uint64_t seed, uint32_t site) {
     uint32_t k = vc_hash32((uint32_t)seed ^ vc_hash32((uint32_t)(seed >> 32) + 0x9E3779B9u * (site + 1u)));
@@ -446,20 +446,9 @@ VC_HD uint32_t vc_drop_key(uint64_t seed, uint32_t site) {
 }
 VC_HD vc_drop vc_drop_make(uint32_t key, float p) {
     vc_drop d; d.key = key; d.thr = (uint32_t)(p * 4096.0f + 0.5f); d.scale = 4096.0f / (float)(4096u - d.thr);
-    d.key2 = vc_hash32(key * 0x9E3779B1u + 0x7F4A7C15u);
     return d;
 }
-// One 32-bit hash per PAIR of elements (pair = idx >> 1): two integer multiplies (quarter-rate VALU on gfx950) instead of the three of r01-r04's
-// `murmur-fmix((pair * phi) ^ key)` — the mixer is a VALU cost in every kernel that draws masks (attention probabilities: ~20 % of the ViT attention
-// backward).  r05: key word 1 enters before the first multiply, key word 2 between the two (without it two sites' mask streams are XOR-permutations of
-// each other: mask_a(i) = mask_b(i ^ key_a ^ key_b)); the 12-bit draws come from bits 8-19 / 20-31, the well-mixed end.  Measured against the old
-// mixer on 4 M consecutive pairs x 5 keys (tools/dropout_hash_stats.py -> profiles/r05_dropout_hash_stats.txt): keep rates 0.1000-0.1003, chi-square of the
-// 4096 draw values within 2 sd, every probed correlation (lo / hi of one hash, strides 1..1536, across keys) at the 1e-3 noise floor of the sample.
-VC_HD uint32_t vc_drop_hash(const vc_drop& d, uint32_t pair) {
-    uint32_t x = (pair ^ d.key) * 0x9E3779B1u;
-    x ^= x >> 15; x ^= d.key2; x *= 0x2C1B3C6Du; x ^= x >> 13;
-    return x;
-}
+VC_HD uint32_t vc_drop_hash(const vc_drop& d, uint32_t pair) { return vc_hash32((pair * 0x9E3779B1u) ^ d.key); }          // pair = idx >> 1
 VC_HD bool vc_drop_keep_lo(const vc_drop& d, uint32_t h) { return ((h >> 8) & 0xFFFu) >= d.thr; }                           // even idx
 VC_HD bool vc_drop_keep_hi(const vc_drop& d, uint32_t h) { return (h >> 20) >= d.thr; }                                     // odd idx
 // element indices are 32-bit: every site has < 2^32 elements (checked on the host when the workspace is planned)
