@@ -447,10 +447,10 @@ struct Ctx {
     }
     // add / sum32 (r05): x + add (the 16-bit branch output of the Linear in front) is written to sum32 as the new residual stream and normalised
     int ln_fwd(int tx, const void* x, long ldx, long wo, long bo, float* y32, long ldy32, void* yt, long ldyt, float* stats, long rows, int C, bool pk = false,
-               const void* add = nullptr, float* sum32 = nullptr) const {
+               const void* add = nullptr, float* sum32 = nullptr, vc_drop add_drop = vc_drop{0u, 0u, 1.0f}) const {
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = x; p.ldx = ldx; p.gamma = Pf(wo); p.beta = Pf(bo); p.y32 = y32; p.ldy32 = ldy32; p.yt = yt; p.ldyt = ldyt;
-        p.stats = stats; p.rows = rows; p.eps = 1e-5f; p.add = add; p.ldadd = C; p.sum32 = sum32; p.ldsum = C;
+        p.stats = stats; p.rows = rows; p.eps = 1e-5f; p.add = add; p.ldadd = C; p.sum32 = sum32; p.ldsum = C; p.add_drop = add_drop;
         return vc_ln_fwd(tx, vt(pk), C, 0, p, s);
     }
     // dx32 (+T copy) = add_in + LNbwd(dy);  dgamma/dbeta written to the grad buffer
@@ -508,7 +508,9 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
     // wide-tile epilogue, and the LayerNorm pass that follows adds it to the residual stream (x + y -> xm / xo in fp32, then the statistics):
     // the residual epilogue of the 128-wide tile ran at 0.17 matrix-core busy (profiles/r04_summary.md), the LayerNorm pass is HBM-bound either way.
     const bool res_in_ln = e->dt == VC_BF16 && e->ct == VC_BF16 && !e->fp8 && g_res_in_ln;
-    const void* pend = nullptr; float* pend_sum = nullptr;              // branch output not yet added: the next LayerNorm pass writes x + pend -> pend_sum
+    // The branch's dropout moves with the add (same site, same element indices: the backward regenerates the same masks), so the Linear's epilogue is the
+    // plain one — bias folded into the accumulator start, convert, store.
+    const void* pend = nullptr; float* pend_sum = nullptr; vc_drop pend_drop = vc_drop{0u, 0u, 1.0f};     // branch output not yet added: the next LayerNorm pass writes x + mask * pend -> pend_sum
     for (int L = 0; L < c.vit_depth; ++L) {
         const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
         // Only the cls token of the LAST layer is consumed (pool='cls'): its Q projection, attention output, out-proj and
@@ -517,7 +519,7 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
         const bool pk = cx.pk_acts() && !cls_only;          // bf16x3: this layer's GEMM-only tensors (h_a, qkv, ao, h_f, z, g) are stored pre-split
         const float scale = 1.0f / sqrtf((float)c.vit_dim_head);
         const char* q = (const char*)l.qkv;
-        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D, pk, pend, pend_sum));
+        CK(cx.ln_fwd(VC_F32, x, D, wl.anw, wl.anb, nullptr, 0, l.h_a, D, l.stat_a, R, D, pk, pend, pend_sum, pend_drop));
         if (pend) { x = pend_sum; pend = nullptr; pend_sum = nullptr; }
         AttnParams ap; memset(&ap, 0, sizeof(ap));
         ap.q = q; ap.k = q + (size_t)inner * e->esz; ap.v = q + (size_t)2 * inner * e->esz; ap.o = l.ao;
@@ -531,8 +533,8 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
             else CK(cx.lin_fwd(cx.VT(l.h_a, D, pk), cx.W(wl.qkv, D), cx.VT(l.qkv, 3 * inner, pk), (int)R, 3 * inner, D, Epi()));
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
             if (res_in_ln) {
-                { Epi ep; ep.bias = cx.Pf(wl.ob); ep.drop = d_out; CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.AT(cx.L().t_y[0], D), (int)R, D, inner, ep)); }
-                CK(cx.ln_fwd(VC_F32, x, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D, false, cx.L().t_y[0], l.xm));
+                { Epi ep; ep.bias = cx.Pf(wl.ob); CK(cx.lin_fwd(cx.AT(l.ao, inner), cx.W(wl.ow, inner), cx.AT(cx.L().t_y[0], D), (int)R, D, inner, ep)); }
+                CK(cx.ln_fwd(VC_F32, x, D, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, R, D, false, cx.L().t_y[0], l.xm, d_out));
             } else {
             { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = D; ep.drop = d_out;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.ao, inner), wl.ow, cx.A32(l.xm, D), (int)R, D, inner, ep));
@@ -547,8 +549,8 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.h_f, D), wl.w1, cx.AT(l.g, c.vit_mlp), (int)R, c.vit_mlp, D, ep));
               else CK(cx.lin_fwd(cx.VT(l.h_f, D, pk), cx.W(wl.w1, D), cx.VT(l.g, c.vit_mlp, pk), (int)R, c.vit_mlp, D, ep)); }     // (pk: the pre-activation side output z is pre-split too — it has the output's type)
             if (res_in_ln) {     // xo = xm + y: written by the NEXT layer's first LayerNorm pass (every layer, the class-token-only last one included, starts with one over all rows)
-                Epi ep; ep.bias = cx.Pf(wl.b4); ep.drop = d_mlp; CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_y[1], D), (int)R, D, c.vit_mlp, ep));
-                pend = cx.L().t_y[1]; pend_sum = l.xo;
+                Epi ep; ep.bias = cx.Pf(wl.b4); CK(cx.lin_fwd(cx.AT(l.g, c.vit_mlp), cx.W(wl.w4, c.vit_mlp), cx.AT(cx.L().t_y[1], D), (int)R, D, c.vit_mlp, ep));
+                pend = cx.L().t_y[1]; pend_sum = l.xo; pend_drop = d_mlp;
             } else {
               Epi ep; ep.bias = cx.Pf(wl.b4); ep.residual = l.xm; ep.ldr = D; ep.drop = d_mlp;
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.g, c.vit_mlp), wl.w4, cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep));

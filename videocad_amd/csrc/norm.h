@@ -112,6 +112,7 @@ struct LnFwdParams {
     // in that Linear's epilogue, where the persistent GEMM's eight lock-stepped waves pay for the fp32 side stream with idle matrix cores
     // (0.17 busy); here it rides on a pass that is HBM-bound anyway.
     const void* add; long ldadd; float* sum32; long ldsum;
+    vc_drop add_drop;                 // dropout of the branch (element index row * C + col, the index the Linear's own epilogue would use): x + mask * add
 };
 
 // MODE 0 plain, 1 PATCH (x = frames), 2 EMBED (see above; grid covers N*(P+1) output rows)
@@ -144,6 +145,10 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
     if constexpr (MODE == 0) if (p.add) {
         float a[VPL];
         row_load<TY, VPL>((const TY*)p.add + row * p.ldadd, a, lane);
+        if (p.add_drop.key) {
+#pragma unroll
+            for (int q4 = 0; q4 < VPL / 4; ++q4) { float dm[4]; vc_drop_mul4(p.add_drop, (uint32_t)(row * C + q4 * 256 + lane * 4), dm); for (int k = 0; k < 4; ++k) a[q4 * 4 + k] *= dm[k]; }
+        }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) v[i] += a[i];
         if (p.sum32) row_store<float, VPL>(p.sum32 + row * p.ldsum, v, lane);

@@ -109,9 +109,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     // the forward layout, whose column-per-lane epilogue has the registers for it
     // — measured in-model (profiles/r02_gemm_policy_ab.txt): no faster than the register-staged kernel for the GELU Linear (29.73 vs 29.56 ms per
     // step), so it is taken only when the wide tile is forced (tests) or asked for (policy bit 8)
-    // r05: ... and automatically for "bias + dropout" alone (no activation, no pre-activation output): the ViT's to_out / net.4 Linears now write a 16-bit
-    // branch tensor that the following LayerNorm pass adds to the residual stream (engine.hip: res_in_ln) — 64 hashes per lane and item, not an erf each
-    const bool wide_fused = lay == 0 && !p.dact_src && !p.residual && !p.rowadd && (g_dma_wide == 1 || (g_policy & 8) || (!p.act && !p.aux && p.drop.key && c.to == VC_BF16));
+    const bool wide_fused = lay == 0 && !p.dact_src && !p.residual && !p.rowadd && (g_dma_wide == 1 || (g_policy & 8));
     for (int pass = 0; pass < 2; ++pass) {
         const int BN = pass == 0 ? 256 : GD_BN;
         if (pass == 0 && (!(plain_epi || wide_fused) || g_dma_wide == 0)) continue;
