@@ -53,31 +53,17 @@ struct AdamParams {
     vc_bf16* shadow;                            // optional bf16 copy of p (same flat offsets)
     uint32_t* shadow_pk;                        // optional pre-split (hi | lo bf16) copy of p for the bf16x3 GEMMs (gemm.h vc_pk)
 };
-VC_DEV void adam_one(const AdamParams& a, long i, float g, float m0, float v0, float p0, float c, float step, float rs2) {
-    g *= c;
-    const float m = a.beta1 * m0 + (1.0f - a.beta1) * g;
-    const float v = a.beta2 * v0 + (1.0f - a.beta2) * g * g;
-    const float p = p0 - step * (m / (sqrtf(v) * rs2 + a.eps));
-    a.m[i] = m; a.v[i] = v; a.p[i] = p;
-    if (a.shadow) a.shadow[i] = vc_f32_to_bf16(p);
-    if (a.shadow_pk) a.shadow_pk[i] = vc_pk_pack(p);
-}
-// r05: four elements per thread and trip, one grid stride apart — all SIXTEEN loads are issued before the first result is needed.  The one-element loop kept
-// 4 x 4 bytes per thread in flight: 2 048 threads per CU x 16 B against ~2 us of loaded HBM latency is ~4.2 TB/s, which is where the kernel sat (4.85 TB/s,
-// profiles/r04_summary.md).  (r04's seven 16-byte streams per thread measured slower; this keeps the 4-byte, fully coalesced accesses and only deepens the queue.)
-// Same arithmetic per element: results are bit-identical.
 VC_KERNEL __launch_bounds__(256) void adam_kernel(AdamParams a) {
     if (a.finite && a.finite[0] == 0.0f) return;
     const float c = (a.clip ? a.clip[0] : 1.0f) * a.gscale;
     const float step = a.lr / a.bc1, rs2 = 1.0f / sqrtf(a.bc2);
-    const long S = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * S < a.n; i += 4 * S) {
-        float g[4], m[4], v[4], p[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { g[u] = a.g[i + u * S]; m[u] = a.m[i + u * S]; v[u] = a.v[i + u * S]; p[u] = a.p[i + u * S]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) adam_one(a, i + u * S, g[u], m[u], v[u], p[u], c, step, rs2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
+        const float g = a.g[i] * c;
+        const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
+        const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
+        const float p = a.p[i] - step * (m / (sqrtf(v) * rs2 + a.eps));
+        a.m[i] = m; a.v[i] = v; a.p[i] = p;
+        if (a.shadow) a.shadow[i] = vc_f32_to_bf16(p);
+        if (a.shadow_pk) a.shadow_pk[i] = vc_pk_pack(p);
     }
-    for (; i < a.n; i += S) adam_one(a, i, a.g[i], a.m[i], a.v[i], a.p[i], c, step, rs2);
 }
