@@ -254,6 +254,8 @@ void vcad_debug_gemm_epilogue(int mode);     /* persistent kernel, k-contiguous 
 void vcad_debug_gemm_variant(int v);         /* 0 = lockstep persistent kernel, 1 = ping-pong wave groups (slower) */
 void vcad_debug_gemm_stagger(int n);         /* ablation (tools/gemm_ablate*.py) */
 void vcad_debug_gemm_skip(int mask);
+void vcad_debug_res_in_ln(int on);           /* 16-bit ViT layers: residual add + branch dropout inside the LayerNorm pass behind to_out / net.4 (1, default) or in the GEMM epilogue (0: r04) */
+void vcad_debug_wgrad_bk32(int on);          /* 256-wide weight-gradient kernel: four 32-deep ring stages (1, default) or two 64-deep ones (0: r04) */
 #endif
 
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */

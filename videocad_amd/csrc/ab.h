@@ -17,6 +17,7 @@ struct VcAb {
     int attn_variant;  // 0 current attention kernels, 1 r01 kernels
     int split_gelu;    // bf16 ViT MLP: 1 = activation as its own pass behind a plain GEMM, 0 = fused epilogue (r01)
     int no_side;       // 1 = no library side stream
+    int wgrad_bk32;    // 256-wide weight-gradient instantiation: 1 = 32-deep stages, four-stage ring (r05), 0 = two 64-deep stages
     int res_in_ln;     // 16-bit ViT layers: 1 = residual add inside the LayerNorm pass behind to_out / net.4 (r05), 0 = in the GEMM epilogue (r04)
     unsigned gemm_flags;   // OR-ed into every GemmCall::flags
 };

@@ -46,14 +46,21 @@ constexpr int GD_NS = 16;                                                       
 #ifndef GD_ABLATE
 #define GD_ABLATE 0
 #endif
-template <int BN> struct GdTile {
-    static constexpr int STAGES = BN == 128 ? 3 : 2;
+// BK (r05): k-tile depth of a ring stage: 64 in every product instantiation.  The A/B build also carries the 256-wide weight-gradient kernel on 32-deep stages in a
+// FOUR-stage ring (three stages = 96 KiB in flight per CU instead of one 64 KiB stage): the hypothesis was that a token reduction, which streams both operands from HBM
+// with nothing to re-use, runs at the pace of the bytes in flight.  It does not: 172 -> 211 us per launch in the model (profiles/r05_wgrad_bk32_ab.txt) — twice the
+// barriers, waits and DMA-issue turns per byte cost more than the deeper queue buys.  Only the row-contiguous (tr-read) layouts can take it without new LDS images
+// ([k][columns]: a 32-deep stage is the first 32 k-rows of the 64-deep one).  The ring bookkeeping below is written for any stage count.
+template <int BN, int BK = 64> struct GdTile {
+    static_assert(BK == 64 || (BK == 32 && BN == 256), "32-deep stages: 256-wide tile only");
+    static constexpr int STAGES = BN == 128 ? 3 : (BK == 32 ? 4 : 2);
     static constexpr int NJ = BN / 64;                                          // 32-column accumulator tiles per wave (2 or 4)
-    static constexpr int B_ELEMS = BN * GD_BK, STAGE_ELEMS = GD_A_ELEMS + B_ELEMS;
+    static constexpr int A_ELEMS = GD_BM * BK, B_ELEMS = BN * BK, STAGE_ELEMS = A_ELEMS + B_ELEMS;
     static constexpr size_t RING_BYTES = (size_t)STAGES * STAGE_ELEMS * 2;
-    static constexpr size_t LDS_BYTES = RING_BYTES + 3 * BN * sizeof(float) + 8 * sizeof(int);     // + three bias rows + the ticket ring of the dynamic claiming
-    static constexpr int PIECES_B = B_ELEMS * 2 / 1024;
-    static constexpr int PW = (GD_PIECES_A + PIECES_B) / 4;                     // 12 / 16
+    static constexpr int NBIAS = STAGES < 3 ? 3 : STAGES;                        // bias rows kept in LDS: the prefetch cursor runs up to STAGES - 1 items ahead of the consumer
+    static constexpr size_t LDS_BYTES = RING_BYTES + NBIAS * BN * sizeof(float) + 8 * sizeof(int);     // + bias rows + the ticket ring of the dynamic claiming
+    static constexpr int PIECES_A = A_ELEMS * 2 / 1024, PIECES_B = B_ELEMS * 2 / 1024;
+    static constexpr int PW = (PIECES_A + PIECES_B) / 4;                        // 12 / 16 / 8
     static constexpr int NS = 2 * NJ * 4;                                       // 16 / 32
 };
 
@@ -185,11 +192,13 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
 // 128 B/clk (ablations: profiles/r02_gemm_mainloop_ablation.txt); a 128 x 128 register tile needs 8 fragments per 16 MFMAs instead of 6
 // per 8 (128 KiB of reads per k-tile), and a wave hides its own fragment latency behind 16 back-to-back MFMAs.  All four waves issue
 // their quarter of every stage (no second wave on the SIMD to take turns with).
-template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
+template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8, int BK = 64>
 VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn, int* claim) {
-    using TL = GdTile<BN>;
-    static_assert(NW == 8 || (NW == 4 && BN == 256), "four-wave form: 256-wide tile only");
-    constexpr int NJ = TL::NJ, STAGES = TL::STAGES, STAGE_ELEMS = TL::STAGE_ELEMS, PIECES_B = TL::PIECES_B, HALF_N = BN / 2;
+    using TL = GdTile<BN, BK>;
+    static_assert(NW == 8 || (NW == 4 && BN == 256 && BK == 64), "four-wave form: 256-wide tile, 64-deep stages only");
+    static_assert(BK == 64 || (TRA && TRB), "32-deep stages: the row-contiguous (tr-read) layouts only");
+    constexpr int NJ = TL::NJ, STAGES = TL::STAGES, STAGE_ELEMS = TL::STAGE_ELEMS, PIECES_B = TL::PIECES_B, HALF_N = BN / 2, NBIAS = TL::NBIAS;
+    constexpr int GD_A_ELEMS_K = TL::A_ELEMS;
     constexpr int MI = NW == 8 ? 2 : 4, WR = MI * 32;                           // 32-row accumulator tiles / rows per wave
     // COL: column-per-lane accumulators (MFMA issued A x B; a lane owns NJ ADJACENT output columns of 16 rows).  r01's epilogue was
     // row-per-lane (swapped MFMA): every store / side-load instruction touched 32-64 different cache lines with 8-16 bytes each and
@@ -200,7 +209,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     constexpr int NS_ITEM = (COL ? 32 : TL::NS) * (MI / 2);                      // epilogue stores per wave per interior item
     VC_DYN_SHARED(vc_bf16, lds);
     float* bias_lds = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(lds) + TL::RING_BYTES);
-    int* const tk = reinterpret_cast<int*>(bias_lds + 3 * BN);            // dynamic claiming: item of sequence number s at tk[s & 7]
+    int* const tk = reinterpret_cast<int*>(bias_lds + NBIAS * BN);        // dynamic claiming: item of sequence number s at tk[s & 7]
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const unsigned char* Ag = (const unsigned char*)p.A;
@@ -262,17 +271,17 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     // workgroups: the first item here, item s + 1 at the ktile_begin in front of the prefetch cursor's LAST k-tile of item s (the prefetch that
     // follows that barrier is the one that moves on and reads tk[s + 1]).
     if (dyn) { claim_next(); vc_sync(); first = tk[0]; }
-    const int nt = p.k_per_split / GD_BK, ktiles = p.K / GD_BK;  // k-tiles per slice (the last slice may be shorter)
+    const int nt = p.k_per_split / BK, ktiles = p.K / BK;        // k-tiles per slice (the last slice may be shorter)
     const bool use_bias = p.bias && !p.partial;
     const bool use_side = NJ == 2 && (p.residual || p.dact_src) && !p.partial;   // (the 256-wide tile has no registers for side inputs)
     // The two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) take turns issuing a WHOLE stage (12 pieces per wave):
     // the group whose turn it is stalls ~0.3 us in the address path while the other group is already on the matrix cores,
     // then runs its own MFMAs while the first group waits at the next barrier — issue time no longer adds to MFMA time.
-    constexpr int NPA = GD_PIECES_A / 4, NPB = PIECES_B / 4;
+    constexpr int NPA = TL::PIECES_A / 4, NPB = PIECES_B / 4;
     const int grp = NW == 8 ? wave >> 2 : 0, wq = wave & 3;
     auto my_turn = [&](int tn) { return NW == 4 || grp == tn; };
     // bytes one k-tile advances the (wave-uniform) operand base
-    const long kstepA = TRA ? (long)GD_BK * p.lda * 2 : (long)GD_BK * 2, kstepB = TRB ? (long)GD_BK * p.ldb * 2 : (long)GD_BK * 2;
+    const long kstepA = TRA ? (long)BK * p.lda * 2 : (long)BK * 2, kstepB = TRB ? (long)BK * p.ldb * 2 : (long)BK * 2;
 
     auto locate = [&](GdCursor& c) {            // integer divisions: once per item, never per k-tile
         c.z = c.item / tmn; const int rem = c.item - c.z * tmn;
@@ -297,10 +306,10 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         const long kt_abs = (long)c.z * nt + c.kt;
         vc_bf16* st = lds + slot * STAGE_ELEMS;
         // the tile's bias values: issued AHEAD of the item's first stage, so the wait that retires that stage covers them
-        if (use_bias && c.kt == 0 && wq == 0 && lane < BN / 4) vc_dma16(p.bias + c.tn * BN + lane * 4, bias_lds + (c.seq % 3) * BN);
+        if (use_bias && c.kt == 0 && wq == 0 && lane < BN / 4) vc_dma16(p.bias + c.tn * BN + lane * 4, bias_lds + (c.seq % NBIAS) * BN);
         if constexpr (GD_ABLATE & 4) return;
         gd_issue<NPA>(Ag + kt_abs * kstepA, offA, st, wq * NPA);
-        gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS, wq * NPB);
+        gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS_K, wq * NPB);
     };
 
     GdCursor pf{first, 0, 1, 0, 0, 0, 0};
@@ -314,7 +323,9 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     }
 
     vc_f32x16 acc[MI][NJ];
-    int slot = 0, young_prev = 0, young_cur = 0;                 // stores issued in the previous / current iteration (lower bounds)
+    // VMEM operations this wave issued in the last k-tile iterations (lower bounds): e1 / e2 / e3 = epilogue stores of iterations t-1 / t-2 / t-3, d1 / d2 = DMA
+    // pieces of iterations t-1 / t-2; d_now = pieces issued in the current iteration (recorded by ktile_prefetch)
+    int slot = 0, e1 = 0, e2 = 0, e3 = 0, d1 = 0, d2 = 0, young_cur = 0, d_now = 0;
 
     // One k-tile: retire stage `slot`, re-arm the slot freed by the previous k-tile, feed the matrix cores.
     // Every instruction here is paid 300+ times per launch by every wave (a wave issues one instruction per ~4 cycles, a
@@ -331,10 +342,13 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         // and nothing younger of its own is in flight yet — the stage after next is issued below, after the barrier)
         // (3 stages: the stage was issued two k-tiles ago, after that k-tile's barrier and before its epilogue — the stores of the
         // last two epilogues are younger; 2 stages: issued one k-tile ago — only the last epilogue's stores are)
+        // (general form, r05: stage t was issued in iteration t - (STAGES - 1), in front of that iteration's epilogue; everything this wave issued since is younger —
+        //  the stores of iterations t - STAGES + 1 .. t - 1 and the DMA pieces of iterations t - STAGES + 2 .. t - 1.  With two or three stages the own-group pieces in
+        //  that window are zero — the r01 / r02 counts; the four-stage ring of the 32-deep weight-gradient form has ONE younger own stage in flight.)
+        e3 = e2; e2 = e1; e1 = young_cur; d2 = d1; d1 = d_now; young_cur = 0; d_now = 0;
         if constexpr (NW == 4) {                                 // every wave issued a quarter of the stage one k-tile ago; only the last epilogue's stores are younger
-            if (young_cur) vc_wait_vmcnt<(NS_ITEM > 63 ? 63 : NS_ITEM)>(); else vc_wait_vmcnt<0>();     // (6-bit counter: 63 rounds DOWN, which is safe)
-        } else if (grp == turn) gd_wait_le<TL::PW, NS_ITEM>(STAGES == 3 ? young_prev + young_cur : young_cur);
-        young_prev = young_cur; young_cur = 0;
+            if (e1) vc_wait_vmcnt<(NS_ITEM > 63 ? 63 : NS_ITEM)>(); else vc_wait_vmcnt<0>();     // (6-bit counter: 63 rounds DOWN, which is safe)
+        } else if (grp == turn) gd_wait_le<TL::PW, NS_ITEM>(STAGES == 2 ? e1 : (STAGES == 3 ? d1 + e1 + e2 : d1 + d2 + e1 + e2 + e3));
         vc_barrier_raw();                                        // everyone's pieces landed; everyone is done reading slot-1
     };
     // (Issuing the next stage's pieces BETWEEN the MFMAs instead of in one burst after the barrier was measured: +1-3 % on the
@@ -344,7 +358,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     auto ktile_prefetch = [&]() {
         if (pf.item < last) {
             // stage s is issued by group s & 1: during k-tile t (turn = t & 1) that is stage t + STAGES - 1
-            if (my_turn(STAGES == 3 ? turn : turn ^ 1)) issue(pf, slot == 0 ? STAGES - 1 : slot - 1);      // the slot freed by the previous k-tile
+            if (my_turn((STAGES & 1) ? turn : turn ^ 1)) { issue(pf, slot == 0 ? STAGES - 1 : slot - 1); d_now = TL::PW; }      // the slot freed by the previous k-tile (stage t + STAGES - 1: group (t + STAGES - 1) & 1)
             if (advance(pf) && pf.item < last) retarget(pf);
         }
         turn ^= 1;
@@ -376,16 +390,16 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     };
     auto ktile_mfma = [&]() {
         const vc_bf16* a_tile = lds + slot * STAGE_ELEMS;
-        const vc_bf16* b_tile = a_tile + GD_A_ELEMS;
+        const vc_bf16* b_tile = a_tile + GD_A_ELEMS_K;
         vc_s16x8 af[2][MI], bf[2][NJ];
         load_frags(a_tile, b_tile, 0, af[0], bf[0]);
 #pragma unroll
-        for (int ks = 0; ks < GD_BK / 16; ++ks) {
-            if (ks + 1 < GD_BK / 16) load_frags(a_tile, b_tile, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            if (ks + 1 < BK / 16) load_frags(a_tile, b_tile, ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
             mfma_step(af[ks & 1], bf[ks & 1]);
             // issue order of this region: one MFMA, then its share of the next k-step's LDS reads — a burst of reads from all eight waves
             // fills the LDS queue and the waves then sit in ds_read issue while the matrix pipe drains (r02 ablation: MFMA + reads = sum of both)
-            if (ks + 1 < GD_BK / 16) gd_interleave<MI * NJ, MI * (TRA ? 2 : 1) + NJ * (TRB ? 2 : 1)>();
+            if (ks + 1 < BK / 16) gd_interleave<MI * NJ, MI * (TRA ? 2 : 1) + NJ * (TRB ? 2 : 1)>();
             vc_sched_fence();
         }
         slot = slot == STAGES - 1 ? 0 : slot + 1;
@@ -408,7 +422,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         auto acc_init = [&]() {
             if (fold_bias) {
                 if constexpr (COL) {
-                    float b[NJ]; gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % 3) * BN + wn * HALF_N + NJ * (lane & 31), b);
+                    float b[NJ]; gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % NBIAS) * BN + wn * HALF_N + NJ * (lane & 31), b);
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -416,7 +430,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[i][jn][r] = b[jn];
                 } else {
-                    const float* br = bias_lds + (cp.seq % 3) * BN + wn * HALF_N + 4 * (lane >> 5);
+                    const float* br = bias_lds + (cp.seq % NBIAS) * BN + wn * HALF_N + 4 * (lane >> 5);
 #pragma unroll
                     for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
@@ -517,7 +531,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             float bv[NJ];
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn) bv[jn] = 0.0f;
-            if (use_bias) gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % 3) * BN + wn * HALF_N + NJ * cl, bv);
+            if (use_bias) gd_vec_ld_f32<NJ>(bias_lds + (cp.seq % NBIAS) * BN + wn * HALF_N + NJ * cl, bv);
             // ---- plain / k-slice-slab epilogues (most of the FLOPs): straight-line code.  The generic loop below decides partial / plain /
             // fused, the row bound and a 64-bit row address PER ROW — ~35 instructions and 4 branches per store, ~1 100 per wave and item,
             // a quarter of the QKV forward's time (profiles/r03_gemm_epilogue_fastpath_ab.txt).  Here: the mode and "interior tile" are
@@ -634,7 +648,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             }
         }
         ktile_prefetch();
-        const float* brow = bias_lds + (cp.seq % 3) * BN + wn * HALF_N + 4 * (lane >> 5);
+        const float* brow = bias_lds + (cp.seq % NBIAS) * BN + wn * HALF_N + 4 * (lane >> 5);
         ktile_mfma();
 
         // ---- epilogue from registers: lane holds row m = ..+(lane&31), columns n = ..+8*q+4*(lane>>5)+{0..3} for q = 0..3

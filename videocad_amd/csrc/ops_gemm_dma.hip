@@ -4,12 +4,12 @@
 #include "gemm_dma.h"
 
 // persistent DMA-fed kernel (gemm_dma.h): `total` work items = 256x128 tiles x k-slices
-template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8>
+template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8, int BK = 64>
 static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
 #ifndef VC_EMU
     static unsigned attr_set = 0;
     if (!(attr_set & vc_device_bit())) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN>::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GdTile<BN, BK>::LDS_BYTES);
         if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
         attr_set |= vc_device_bit();
     }
@@ -32,7 +32,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
             if (tiles_n % xn || a_bytes * xn > 0.5 * (double)tiles_mn * slice || tiles_m < 8 * 8 / xn) xn = 1;
         }
     }
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW>), dim3(grid), dim3(NW * 64), GdTile<BN>::LDS_BYTES, s, c.p, tiles_n, tiles_mn, nsplit, total, xn, c.claim);
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW, BK>), dim3(grid), dim3(NW * 64), (GdTile<BN, BK>::LDS_BYTES), s, c.p, tiles_n, tiles_mn, nsplit, total, xn, c.claim);
     }
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;
@@ -66,6 +66,11 @@ int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s) {
     }
 #endif
     if (BN == 256) {                       // plain epilogues only (checked by the dispatcher); no tr-read B instantiation
+#ifdef VCAD_AB
+        // r05 experiment (A/B build only): weight gradients on 32-deep stages in a four-stage ring — 96 KiB in flight per CU instead of 64 (gemm_dma.h: GdTile).  Measured
+        // SLOWER in the model: 172 -> 211 us per launch, +0.77 ms per C2 step (profiles/r05_wgrad_bk32_ab.txt): twice the barriers and waits per byte cost more than the deeper queue buys.
+        if (lay == 3 && g_ab.wgrad_bk32) return gemm_launch_dma<float, true, true, 256, false, 8, 32>(c, nsplit, s);
+#endif
         if (lay == 3) return gemm_launch_dma<float, true, true, 256, false>(c, nsplit, s);
         if (lay == 0 && c.to == VC_F32) return use_col(c, BN) ? gemm_launch_dma<float, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<float, false, false, 256, false>(c, nsplit, s);
         if (lay == 0) return use_col(c, BN) ? gemm_launch_dma<vc_bf16, false, false, 256, true>(c, nsplit, s) : gemm_launch_dma<vc_bf16, false, false, 256, false>(c, nsplit, s);
