@@ -360,9 +360,10 @@ def test_gloo_exchange_variants_bound_the_change_in_the_summed_gradient(tmp_path
     assert base["collectives"] == nb and set(base["plans"]) == {"all_reduce"}
     ref = torch.from_numpy(base["__flat__"])
     assert float(ref.norm()) > 0
-    rs = _run_exchange(tmp_path, 2, dtype, {"grad_wire": "fp32", "grad_exchange": "rs_ag", "experiment_name": "x1"}, 1)
-    assert rs["collectives"] == 2 * nb and set(rs["plans"]) == {"rs_ag"}
-    assert torch.equal(torch.from_numpy(rs["__flat__"]), ref)
+    if dtype == "f32":                       # (the exchange form does not depend on the engine's dtype: once is enough)
+        rs = _run_exchange(tmp_path, 2, dtype, {"grad_wire": "fp32", "grad_exchange": "rs_ag", "experiment_name": "x1"}, 1)
+        assert rs["collectives"] == 2 * nb and set(rs["plans"]) == {"rs_ag"}
+        assert torch.equal(torch.from_numpy(rs["__flat__"]), ref)
     half = _run_exchange(tmp_path, 2, dtype, {"grad_wire": "half", "grad_exchange": "auto", "grad_rs_min_mb": 20.0, "experiment_name": "x2"}, 2)
     assert half["wire"] == ("torch.float16" if dtype == "f16" else "torch.bfloat16")
     assert "rs_ag" in half["plans"] and "all_reduce" in half["plans"]          # the big bucket takes rs_ag, the small ones all_reduce

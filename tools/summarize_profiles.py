@@ -26,8 +26,10 @@ print("## bench line\n```json\n" + json.dumps(bench, indent=1)[:6000] + "\n```\n
 
 ours = [r for r in stats if "at::native" not in r["Name"] and "rocclr" not in r["Name"] and "Cijk" not in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in ours)
-print(f"## kernel-trace stats ({steps_traced} steps traced; library kernels only; {tot / steps_traced / 1e6:.2f} ms of kernel time per step)\n")
-print("| kernel | calls/step | avg us | ms/step | % |\n|---|---|---|---|---|")
+step_ms = float(bench.get("ms_per_step") or 0.0)
+print(f"## kernel-trace stats ({steps_traced} steps traced; library kernels only; {tot / steps_traced / 1e6:.2f} ms of kernel time per step against a {step_ms:.2f} ms step under the tracer:"
+      f" the side stream — CAD ViT, deferred decoder weight gradients — runs beside the main one, so kernel time sums to MORE than the step; the last column is the share of summed KERNEL time, not of the step)\n")
+print("| kernel | calls/step | avg us | ms/step | % of kernel time |\n|---|---|---|---|---|")
 for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"]))[:30]:
     print(f"| `{short(r['Name'])}` | {int(r['Calls']) / steps_traced:.1f} | {float(r['AverageNs']) / 1e3:.1f} | "
           f"{float(r['TotalDurationNs']) / steps_traced / 1e6:.3f} | {100 * float(r['TotalDurationNs']) / tot:.1f} |")
