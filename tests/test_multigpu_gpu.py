@@ -184,3 +184,61 @@ def test_bucketed_exchange_on_a_one_rank_rccl_group_is_bitwise_the_plain_step(tm
     assert p.exitcode == 0
     rep = q.get(timeout=5)
     print("comm report (1-rank RCCL group):", json.dumps(rep))
+
+
+def _one_rank_variants_main(port, tmp, q, dtype):
+    import torch.distributed as dist
+    from videocad_amd.model_factory import ModelFactory
+    from videocad_amd.trainer import create_trainer
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    os.chdir(tmp)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        out = {}
+        for name, extra in (("plain", {}), ("rs_ag", {"force_bucketed_exchange": True, "grad_exchange": "rs_ag"}),
+                            ("half", {"force_bucketed_exchange": True, "grad_wire": "half", "grad_exchange": "auto", "grad_rs_min_mb": 100.0})):
+            model, mtype = ModelFactory().create_model("autoregressive", dict(CANON, compute_dtype=dtype), dev)
+            model.load_state_dict({k: synth.make_param_torch(k, s, dev) for k, s in O.param_shapes().items()}, strict=True)
+            model.train()
+            pk = {"loader": [], "sampler": None}
+            tr = create_trainer(pk, pk, pk, model, dict({"lr": 1e-5, "use_mse": True, "experiment_name": "v" + name,
+                                                         "class_weights_path": os.path.join(HERE, "golden", "class_weights.json")}, **extra), dev, mtype, rank=0)
+            tr.gradsync.timing = bool(extra)
+            model._drop_seed_base = 7
+            loss, _ = tr._process_batch(synth.make_batch_torch(2, 9, 31, "cpu"))
+            torch.cuda.synchronize()
+            out[name] = (float(loss), model._engine.grads.clone(), tr.gradsync.comm_report() if extra else None, tr.gradsync.collectives)
+        q.put({k: v[2] for k, v in out.items() if v[2]})
+        g0 = out["plain"][1]
+        # reduce_scatter + all_gather through RCCL on a one-rank group: the same bytes come back
+        assert bool(torch.equal(out["rs_ag"][1], g0)) and out["rs_ag"][3] == 2 * 4 and all(c["how"] == "rs_ag" for c in out["rs_ag"][2]["collectives"])
+        # half wire format on the device: every gradient went through vcad_wire_pack / RCCL / vcad_wire_unpack — rounded to the library's 16-bit format, nothing else
+        gh = out["half"][1]
+        wire = torch.float16 if dtype == "f16" else torch.bfloat16
+        assert out["half"][2]["wire"] == ("float16" if dtype == "f16" else "bfloat16")
+        assert [c["how"] for c in out["half"][2]["collectives"]] == ["rs_ag", "all_reduce", "all_reduce", "all_reduce"]      # only bucket 0 (180 MB on the wire) is above the 100 MB threshold
+        assert bool(torch.isfinite(gh).all()) and U.relerr(gh, g0) < (8e-4 if dtype == "f16" else 6e-3), U.relerr(gh, g0)
+        if dtype != "f16":                                          # bf16 needs no scale: the result IS the bf16 rounding of every gradient
+            assert bool(torch.equal(gh, g0.to(wire).float()))
+        else:                                                       # fp16: a power-of-two scale per exchanged range — relative error of a rounding to 11 bits wherever the scaled value is a normal number
+            big = g0.abs() > 1e-3 * g0.abs().max()
+            assert float(((gh - g0).abs() / g0.abs().clamp_min(1e-30))[big].max()) < 2.0 ** -10
+        assert all(c["GBps"] and c["GBps"] > 0 and c["MB"] > 0 for c in out["half"][2]["collectives"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_exchange_variants_on_a_one_rank_rccl_group(tmp_path, dtype):
+    """r05 on the device: `grad_exchange = "rs_ag"` and `grad_wire = "half"` through RCCL itself (one-rank group): ncclReduceScatter / ncclAllGather and the
+    bf16 / fp16 all-reduce exist and are accepted on the buckets' sizes, the library's wire kernels (amax, pack, unpack) run on the communication stream behind the right events,
+    and what comes back is the plain step's gradient — bit for bit with fp32 buckets, rounded to the wire format with 16-bit ones.  The comm report carries MB on the wire and GB/s."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_variants_main, args=(29700 + (os.getpid() % 1000) + 5 * (dtype == "f16"), str(tmp_path), q, dtype))
+    p.start(); p.join(timeout=900)
+    assert p.exitcode == 0
+    print("comm reports (1-rank RCCL group):", json.dumps(q.get(timeout=5)))
