@@ -61,6 +61,13 @@ def test_state_dict_matches_appendix_b_and_factory_surface():
     # no CPU fallback: the product path fails loudly without a ROCm device
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model({"frames": torch.zeros(1, 1, 1, 224, 224), "actions": torch.zeros(1, 1, 7), "cad_image": torch.zeros(1, 1, 224, 224)})
+    # a checkpoint in the pre-1.2 vit-pytorch layout (PreNorm wrappers; the reference pins no version) is different arithmetic: refused, not silently ignored by strict=False
+    legacy = {"module.state_embedding_model.transformer.layers.0.0.fn.to_qkv.weight": torch.zeros(3072, 512), "embed_state.bias": torch.zeros(1024)}
+    with pytest.raises(RuntimeError, match="pre-1.2 vit-pytorch layout"):
+        ModelFactory().create_model("x", dict(CANON), "cpu", state_dict=legacy)
+    with pytest.raises(RuntimeError, match="pre-1.2 vit-pytorch layout"):
+        model2.load_state_dict({"cad_embedding_model.to_patch_embedding.1.weight": torch.zeros(512, 1024)}, strict=False)
+    model2.load_state_dict({"cad_embedding_model.to_patch_embedding.1.weight": torch.ones(1024), "state_embedding_model.transformer.layers.2.0.norm.weight": torch.ones(512)}, strict=False)   # the current layout's keys pass
     for bad in (dict(CANON, encoder="resnet"), dict(CANON, num_views=2, enable_past_actions=False), dict(CANON, window_size=0)):   # (views + states without actions: the reference's own shapes do not match)
         with pytest.raises((NotImplementedError, AssertionError)):
             ModelFactory().create_model("x", bad, "cpu")

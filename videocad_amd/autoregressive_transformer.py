@@ -169,7 +169,27 @@ class AutoRegressiveTransformer(nn.Module):
         self.action_mask = fn(self.action_mask)
         return self
 
+    @staticmethod
+    def _check_vit_layout(state_dict):
+        """The ViT towers come from `vit-pytorch`, which the reference neither vendors nor pins (requirements.txt:8).  This engine implements the >= 1.2
+        layout (LayerNorm inside `to_patch_embedding`, `Attention.norm`, `FeedForward.net.0` = LayerNorm, a final `transformer.norm`); the older PreNorm
+        layout (`transformer.layers.N.K.fn.*` / `.norm.*`, `to_patch_embedding.1` = the Linear, no final norm) is DIFFERENT ARITHMETIC, not just other key
+        names.  The reference's factory loads with strict=False (model/model_factory.py:35), which would silently leave both towers at their initial
+        weights for such a checkpoint: refuse loudly instead."""
+        for tower in ("state_embedding_model.", "cad_embedding_model."):
+            keys = [k for k in state_dict if k.startswith(tower)]
+            if not keys:
+                continue
+            import re
+            legacy = [k for k in keys if ".fn." in k or re.match(re.escape(tower) + r"transformer\.layers\.\d+\.1\.norm\.", k)]     # PreNorm(fn=...) wrappers / PreNorm around the FeedForward
+            v = state_dict.get(tower + "to_patch_embedding.1.weight")
+            if legacy or (v is not None and getattr(v, "dim", lambda: 1)() == 2):
+                raise RuntimeError(f"checkpoint keys such as '{(legacy or [tower + 'to_patch_embedding.1.weight'])[0]}' belong to the pre-1.2 vit-pytorch layout (PreNorm wrappers, no LayerNorm in "
+                                   "the patch embedding, no final transformer.norm): different arithmetic from the layout this engine implements (DESIGN.md §2, ViT caveat) — "
+                                   "the weights cannot be loaded; with strict=False they would have been silently ignored")
+
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        self._check_vit_layout(state_dict)
         own = set(self._param_names)
         filtered = {k: v for k, v in state_dict.items() if k in own}
         missing = [k for k in own if k not in state_dict]
