@@ -484,3 +484,26 @@ def test_dropout_mask_stream_statistics(emu):
         assert corr(a[:-s], a[s:]) < noise, s
     assert corr(a, b) < noise and corr(a, c) < noise and corr(a, a2) < noise          # other layer / other module / next step's seed
     eng.set_dropout(0.0)
+
+
+def test_f16_external_dlogits_need_no_16_byte_alignment(emu16):
+    """vcad_backward* on an fp16 engine copies caller-supplied dlogits into its scaled private buffers; r04's vector kernel rejected pointers that
+    were not 16-byte aligned (an offset view from Python).  Any 4-byte aligned view now works and gives the gradients of the aligned call."""
+    cfg = small_cfg()
+    eng, _ = build(cfg, L.VCAD_F16, emu16)
+    batch = synth.make_batch(2, 3, seed=8)
+    frames = torch.from_numpy(batch["frames"]); actions = torch.from_numpy(batch["actions"]); cad = torch.from_numpy(batch["cad_image"])
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    dc, dp = eng.dl_views(2, 3)
+    dc, dp = dc.clone(), dp.clone()
+    eng.backward(dc, dp)
+    g_aligned = eng.grads.clone()
+    buf_c = torch.zeros(dc.numel() + 1); buf_p = torch.zeros(dp.numel() + 1)
+    vc, vp = buf_c[1:].view_as(dc), buf_p[1:].view_as(dp)                 # 4 bytes past a 16-byte boundary
+    vc.copy_(dc); vp.copy_(dp)
+    assert vc.data_ptr() % 16 != 0 and vp.data_ptr() % 16 != 0 and vc.is_contiguous()
+    cmds, pars = eng.forward(frames[:, :-1], O.normalize_actions(actions[:, :-1]), cad)
+    eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
+    L.check(eng.lib, eng.lib.vcad_backward(eng.h, vc.data_ptr(), vp.data_ptr(), None), "backward (unaligned dlogits)")
+    assert torch.equal(eng.grads, g_aligned)
