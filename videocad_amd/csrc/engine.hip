@@ -1308,9 +1308,6 @@ int vcad_join_side(vcad_engine* e, void* stream) {
     return 0;
 }
 
-// Whole backward: after stages 0-1 (heads + decoder, stem) the CAD ViT's backward (stage 2) is independent of the frame ViT's
-// (stages 3-4), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
-// soon as its stage returns) keeps everything on the caller's stream.
 // ---- gradient wire format of the data-parallel exchange (norm.h: wire_*_kernel; trainer.py: GradSync grad_wire = "half")
 static int wire_range(const vcad_engine* e, int64_t lo, int64_t hi, const char* what) {
     if (!e->G) { vc_set_error("%s: buffers not bound", what); return VC_ERR_ARG; }
@@ -1331,6 +1328,9 @@ int vcad_wire_unpack(vcad_engine* e, int64_t lo, int64_t hi, const void* wire, c
     return vc_wire_unpack(wire, e->G + lo, hi - lo, amax, world < 1 ? 1 : world, (vc_stream_t)stream);
 }
 
+// Whole backward: after stages 0-1 (heads + decoder, stem) the CAD ViT's backward (stage 2) is independent of the frame ViT's
+// (stages 3-4), so it runs on the side stream beside them.  The staged entry point (data-parallel callers all-reduce a bucket as
+// soon as its stage returns) keeps everything on the caller's stream.
 int vcad_set_bucket_callback(vcad_engine* e, vcad_bucket_ready_fn fn, void* user) { e->bucket_cb = fn; e->bucket_cb_user = user; return 0; }
 
 int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* stream) {
