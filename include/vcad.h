@@ -255,7 +255,9 @@ void vcad_debug_gemm_variant(int v);         /* 0 = lockstep persistent kernel, 
 void vcad_debug_gemm_stagger(int n);         /* ablation (tools/gemm_ablate*.py) */
 void vcad_debug_gemm_skip(int mask);
 void vcad_debug_res_in_ln(int on);           /* 16-bit ViT layers: residual add + branch dropout inside the LayerNorm pass behind to_out / net.4 (1, default) or in the GEMM epilogue (0: r04) */
-void vcad_debug_wgrad_bk32(int on);          /* 256-wide weight-gradient kernel: four 32-deep ring stages (1, default) or two 64-deep ones (0: r04) */
+void vcad_debug_wgrad_bk32(int on);          /* 256-wide weight-gradient kernel: 0 (default) = two 64-deep ring stages; 1 = r05's experiment, four 32-deep stages — measured slower (172 -> 211 us, profiles/r05_wgrad_bk32_ab.txt) */
+void vcad_debug_cls_path(int on);            /* 16-bit engines, last ViT layer: class-token attention on (q W_k, normalised tokens) (1, default: r06, csrc/attn_cls.h) or K / V projections of all tokens (0: r05) */
+void vcad_debug_frame_first(int on);         /* whole backward with the side stream forked: frame tower's upper stage enqueued before the CAD tower's stage (1, default: r06) or after (0: r05) */
 #endif
 
 /* ---- single-op entry points (used by the parity tests; same kernels the engine launches) */
@@ -283,6 +285,12 @@ int vcad_op_attention_bwd(int t, int D, const void* q, const void* k, const void
                           int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,
                           void* dv, int64_t lddq, int64_t lddk, int64_t lddv, int B, int H, int Tq, int Tk, int window,
                           int causal, float scale, void* stream);
+/* class-token attention of the LAST ViT layer, re-associated (csrc/attn_cls.h; restates vit-pytorch Attention for the pooled row, ctor call reference
+ * model/trajectory_model.py:54-65): per frame n and head h, c = softmax_j(scale * g . ha_j) ha, with g = q W_k — no projected keys / values.  16-bit
+ * storage tensors: ha [N * P1][512] (ld_ha), g / c / dc / dg [N][H][512]; lse [N][H] fp32; dha [N * P1][512]; r0 (optional) [N][512] fp32 = row 0 of dha. */
+int vcad_op_cls_attention_fwd(const void* ha, int64_t ld_ha, const void* g, void* c, float* lse, int N, int H, int P1, float scale, void* stream);
+int vcad_op_cls_attention_bwd(const void* ha, int64_t ld_ha, const void* g, const void* dc, const float* lse, void* dg, void* dha, int64_t ld_dha,
+                              float* r0, int N, int H, int P1, float scale, void* stream);
 /* same, with the saved forward output o passed along (the kernels recompute D_i from P and dP; o is accepted for callers that hold it) */
 int vcad_op_attention_bwd_o(int t, int D, const void* q, const void* k, const void* v, const void* o, int64_t ldo, const void* dout,
                             int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, const float* lse, float* delta, void* dq, void* dk,

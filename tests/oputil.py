@@ -276,6 +276,38 @@ def check_attention_single_query(lib, device, B, H, Tk, dt, seed=0):
     assert relerr(lse, torch.logsumexp(sc, -1)) < 1e-5
 
 
+def check_cls_attention(lib, device, N, H, P1, dt, seed=0, pad=0):
+    """csrc/attn_cls.h: the last ViT layer's class-token attention on (g = q W_k, normalised tokens): c[n,h] = softmax_j(scale g[n,h] . ha[n,j]) ha[n]
+    and its backward, against fp64 autograd on the SAME 16-bit-rounded inputs (ha rows stored with `pad` extra leading-dimension elements)."""
+    D = 512
+    scale = 0.125
+    ld = D + pad
+    ha_st = torch.zeros(N * P1, ld, dtype=dt, device=device)
+    ha_log = rnd((N * P1, D), "cpu", seed=seed + 1).to(dt)
+    ha_st[:, :D] = ha_log.to(device)
+    g = rnd((N, H, D), device, dt, seed=seed + 2, scale=0.25)
+    dc = rnd((N, H, D), device, dt, seed=seed + 3)
+    c = torch.zeros(N, H, D, dtype=dt, device=device); lse = torch.zeros(N, H, device=device)
+    st = stream_of(device)
+    L.check(lib, lib.vcad_op_cls_attention_fwd(ptr(ha_st), ld, ptr(g), ptr(c), ptr(lse), N, H, P1, scale, st), "cls_attention_fwd")
+    ha64 = ha_log.double().view(N, P1, D).requires_grad_(True); g64 = g.double().cpu().requires_grad_(True)
+    sc = torch.einsum("nhd,njd->nhj", g64, ha64) * scale
+    ref = torch.einsum("nhj,njd->nhd", torch.softmax(sc, -1), ha64)
+    tol = 6e-3 * EPS16[dt] + 2e-5
+    ref_d = ref.detach()
+    assert relerr(c, ref_d) < tol, ("cls attention fwd", relerr(c, ref_d))
+    assert relerr(lse, torch.logsumexp(sc, -1).detach()) < 1e-5
+    ref.backward(dc.double().cpu())
+    dg = torch.zeros(N, H, D, dtype=dt, device=device); dha = torch.zeros(N * P1, ld, dtype=dt, device=device); r0 = torch.zeros(N, D, device=device)
+    L.check(lib, lib.vcad_op_cls_attention_bwd(ptr(ha_st), ld, ptr(g), ptr(dc), ptr(lse), ptr(dg), ptr(dha), ld, ptr(r0), N, H, P1, scale, st), "cls_attention_bwd")
+    assert relerr(dg, g64.grad) < tol, ("cls attention dg", relerr(dg, g64.grad))
+    dha_log = dha[:, :D].float().cpu().view(N, P1, D)
+    assert relerr(dha_log, ha64.grad) < tol, ("cls attention dha", relerr(dha_log, ha64.grad))
+    assert relerr(r0, ha64.grad[:, 0]) < tol, ("cls attention r0", relerr(r0, ha64.grad[:, 0]))      # (fp32 copy of the class row: the matrix cores' operands — dS, P~ — are rounded, the sum is not)
+    if pad:
+        assert float(dha[:, D:].float().abs().max()) == 0.0, "cls attention backward wrote into the row padding"
+
+
 # ------------------------------------------------------------------------------------------------ MXFP8 (csrc/gemm_mx8.h)
 def mx8_quant_ref(x):
     """[rows, cols] float -> (e4m3 bytes [rows, cols] uint8, E8M0 scale bytes [rows, cols/32] uint8): the OCP MX rule the kernel

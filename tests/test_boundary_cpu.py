@@ -177,7 +177,7 @@ def _q_get(q, procs, timeout=900):
     raise AssertionError("workers timed out")
 
 
-def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32", extra=None):
+def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32", extra=None, seed0=10):
     import torch.distributed as dist
     _cwd_with_class_weights(tmp)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
@@ -203,7 +203,7 @@ def _ddp_worker(rank, world, port, tmp, q, wrap=False, dtype="f32", extra=None):
                 calls["n"] += 1; calls["elems"] += t.numel()
                 return real(t, *a, **k)
             dist.all_reduce = counted
-        batch = synth.make_batch(1, 2, seed=10 + rank)
+        batch = synth.make_batch(1, 2, seed=seed0 + rank)
         tb = {k: (torch.from_numpy(v) if v is not None else None) for k, v in batch.items()}
         pk = {"loader": [tb], "sampler": None}
         tr = create_trainer(pk, pk, pk, model, dict({"lr": 1e-5, "use_mse": True, "experiment_name": "t"}, **(extra or {})), "cpu", mtype, rank=rank)
@@ -320,7 +320,12 @@ def test_gloo_data_parallel_step_on_the_fp16_build(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + 11
-    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q, False, "f16")) for r in range(world)]
+    # Batch seeds 20 / 21 (the fp32 twins use 10 / 11): these batches have TWO token rows, so one ReLU unit of the decoder's feed-forward whose pre-activation
+    # lies within fp16 rounding of zero flips between engine and oracle and moves every gradient upstream of it by ~1e-2 — a property of the two-row batch, not
+    # of the exchange under test (seed 11 hits such a unit since r06 moved the rounding points of the last ViT layer: unit 416 of linear1, gradient 0 vs 0.069,
+    # every other element within 1e-4; seed 12 flips another one).  20 / 21 have no unit that close to zero.
+    SEED0 = 20
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, str(tmp_path), q, False, "f16", None, SEED0)) for r in range(world)]
     [p.start() for p in procs]
     got = _q_get(q, procs)
     [p.join(timeout=300) for p in procs]
@@ -331,7 +336,7 @@ def test_gloo_data_parallel_step_on_the_fp16_build(tmp_path):
     ot = O.OracleTrainer({k: synth.make_param(k, s) for k, s in shapes.items()}, ocfg)
     gsum = None
     for r in range(world):
-        ot.loss_and_grads(synth.make_batch(1, 2, seed=10 + r))
+        ot.loss_and_grads(synth.make_batch(1, 2, seed=SEED0 + r))
         g = {k: p.grad.clone() for k, p in ot.P.items()}
         gsum = g if gsum is None else {k: gsum[k] + g[k] for k in g}
     errs = sorted((U.relerr(torch.from_numpy(got["__grads__"][n]), gsum[n]), n) for n in gsum if float(gsum[n].norm()) > 1e-6)

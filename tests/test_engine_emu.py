@@ -507,3 +507,20 @@ def test_f16_external_dlogits_need_no_16_byte_alignment(emu16):
     eng.loss(cmds, pars, actions[:, 1:], U.LABEL_W)
     L.check(eng.lib, eng.lib.vcad_backward(eng.h, vc.data_ptr(), vp.data_ptr(), None), "backward (unaligned dlogits)")
     assert torch.equal(eng.grads, g_aligned)
+
+
+def test_unsupported_vit_mlp_widths_are_refused_at_construction(emu):
+    """the 16-bit engines' activation-derivative pass has row blocks only for widths whose octet count divides 256 — vit_mlp >= 2056 used to
+    divide by zero in the workspace plan, 768 / 1536 / 3072 failed in the first backward.  Now the constructor says so; the fp32 engine has no such limit."""
+    keys = ("hidden_size", "nhead", "num_decoder_layers", "dim_feedforward", "window_size", "act_dim", "num_classes", "num_params",
+            "num_params_values", "max_ep_len", "vit_dim", "vit_depth", "vit_heads", "vit_dim_head", "vit_mlp", "image_size", "patch_size")
+    for width in (768, 1536, 3072, 4096):
+        cfg = small_cfg(vit_mlp=width)
+        with pytest.raises(RuntimeError, match="vit_mlp"):
+            NativeEngine(make_config(dtype=L.VCAD_BF16, **{k: cfg[k] for k in keys}), "cpu")
+    cfg = small_cfg(vit_mlp=768)
+    eng = NativeEngine(make_config(dtype=L.VCAD_F32, **{k: cfg[k] for k in keys}), "cpu")
+    assert int(eng.lib.vcad_workspace_bytes(eng.h, 1, 2)) > 0
+    cfg = small_cfg(vit_mlp=1024)
+    eng = NativeEngine(make_config(dtype=L.VCAD_BF16, **{k: cfg[k] for k in keys}), "cpu")
+    assert int(eng.lib.vcad_workspace_bytes(eng.h, 1, 2)) > 0

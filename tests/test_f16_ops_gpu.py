@@ -69,6 +69,8 @@ def test_layernorm_f16(hip, C_):
 def test_attention_vit_f16(hip):
     U.check_attention(hip, DEV, 6, 16, 50, 64, window=50, causal=0, dt=F16)
     U.check_attention_single_query(hip, DEV, 5, 16, 50, F16)
+    U.check_cls_attention(hip, DEV, 37, 16, 50, F16)
+    U.check_cls_attention(hip, DEV, 5, 6, 64, F16, seed=5, pad=8)
 
 
 @pytest.mark.parametrize("T,window,D", [(64, 64, 256), (64, 10, 256), (33, 10, 256), (186, 186, 256), (186, 10, 256), (500, 500, 256), (64, 64, 128), (186, 10, 128)])

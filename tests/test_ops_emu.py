@@ -243,3 +243,9 @@ def test_gemm_ragged_rows_with_aligned_operands(emu, ct, trb):
 def test_attention_f32_beyond_192_keys(emu, T, window, D):
     """r04: the fp32 modes' wave-per-row kernels with up to sixteen 64-key pieces per query (horizons up to 1 024; the reference's max_ep_len is 1 000)"""
     U.check_attention(emu, "cpu", 1, 2, T, D, window=window, causal=1, dt=F32)
+
+
+def test_cls_attention(emu):
+    """attn_cls.h under the emulator: the canonical head / token counts and a short model (H not a multiple of the heads-per-wave groups, 64 tokens)"""
+    U.check_cls_attention(emu, "cpu", 2, 16, 50, BF16)
+    U.check_cls_attention(emu, "cpu", 1, 6, 64, BF16, seed=5, pad=8)

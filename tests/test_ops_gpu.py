@@ -141,6 +141,13 @@ def test_attention_single_query(hip, dt):
     U.check_attention_single_query(hip, DEV, 3, 2, 64, dt, seed=3)
 
 
+def test_cls_attention(hip):
+    """attn_cls.h (r06): the last ViT layer's class-token attention on (q W_k, normalised tokens) — forward, backward and the fp32 class row"""
+    U.check_cls_attention(hip, DEV, 37, 16, 50, BF16)
+    U.check_cls_attention(hip, DEV, 5, 6, 64, BF16, seed=5, pad=8)
+    U.check_cls_attention(hip, DEV, 3, 1, 7, BF16, seed=9)
+
+
 @pytest.mark.parametrize("T,window,causal,D", [(64, 64, 1, 256), (37, 10, 1, 256), (33, 1, 1, 128), (5, 3, 1, 64), (50, 50, 0, 64), (64, 64, 0, 64), (31, 31, 0, 128)])
 def test_attention_f32_mfma(hip, T, window, causal, D):
     """fp32 tensors, Tq == Tk <= 64 (attn_f32.h): one wave per 32-query / 32-key block on the f32 matrix cores, forward + both backward kernels"""

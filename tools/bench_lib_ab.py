@@ -18,7 +18,10 @@ def leg(lib, steps, extra):
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from videocad_amd import lib as L\n"
             "p = %r\n"
-            "if p != '-': L.LIB_PATH = p\n"
+            "if p != '-':\n"
+            "    L.LIB_PATH = p\n"
+            "    import torch, ctypes; raw = ctypes.CDLL(p)           # an older build lacks entry points added since: declare what it has\n"
+            "    L.PROTOTYPES = {k: v for k, v in L.PROTOTYPES.items() if hasattr(raw, k)}\n"
             "import bench\n"
             "bench.main(['--profile-only', '--steps', %r, '--warmup', '5'] + %r)\n") % (ROOT, lib, str(steps), list(extra))
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=900)

@@ -19,6 +19,8 @@ struct VcAb {
     int no_side;       // 1 = no library side stream
     int wgrad_bk32;    // 256-wide weight-gradient instantiation: 1 = 32-deep stages, four-stage ring (r05), 0 = two 64-deep stages
     int res_in_ln;     // 16-bit ViT layers: 1 = residual add inside the LayerNorm pass behind to_out / net.4 (r05), 0 = in the GEMM epilogue (r04)
+    int cls_path;      // 16-bit engines, last ViT layer: 1 = class-token attention on (q W_k, normalised tokens) (r06, attn_cls.h), 0 = K / V projections of all tokens (r05)
+    int frame_first;   // whole backward with the side stream forked: 1 = frame tower's upper stage enqueued before the CAD tower's stage (r06), 0 = after (r05)
     unsigned gemm_flags;   // OR-ed into every GemmCall::flags
 };
 extern VcAb g_ab;

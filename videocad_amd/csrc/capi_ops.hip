@@ -105,4 +105,22 @@ int vcad_op_attention_bwd_o(int t, int D, const void* q, const void* k, const vo
     return vc_attn_bwd(t, D, p, (vc_stream_t)stream);
 }
 
+// class-token attention of the last ViT layer in its re-associated form (attn_cls.h): c = softmax(scale g . ha^T) ha per frame and head (16-bit storage)
+int vcad_op_cls_attention_fwd(const void* ha, int64_t ld_ha, const void* g, void* c, float* lse, int N, int H, int P1, float scale, void* stream) {
+    ClsAttnParams p; memset(&p, 0, sizeof(p));
+    p.ha = ha; p.ld_ha = ld_ha; p.g = g; p.c = c; p.lse = lse; p.N = N; p.H = H; p.P1 = P1; p.scale = scale;
+    int rc = vc_cls_attn_fwd(p, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_cls_attention_fwd: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
+int vcad_op_cls_attention_bwd(const void* ha, int64_t ld_ha, const void* g, const void* dc, const float* lse, void* dg, void* dha, int64_t ld_dha, float* r0,
+                              int N, int H, int P1, float scale, void* stream) {
+    ClsAttnParams p; memset(&p, 0, sizeof(p));
+    p.ha = ha; p.ld_ha = ld_ha; p.g = g; p.dc = dc; p.lse = (float*)lse; p.dg = dg; p.dha = dha; p.ld_dha = ld_dha; p.r0 = r0;
+    p.N = N; p.H = H; p.P1 = P1; p.scale = scale;
+    int rc = vc_cls_attn_bwd(p, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_cls_attention_bwd: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
+
 }  // extern "C"

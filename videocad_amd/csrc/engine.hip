@@ -128,6 +128,21 @@ struct vcad_engine {
     // owns the parameters — the decoder's Deferred idea.  One job table per (tower, part of vit_backward); built on first use (device pointers inside).
     struct VitColsums { std::vector<ColsumJob> jobs; ColsumJob* d_jobs = nullptr; float* partial = nullptr; int strips = 0, chunks = 0; bool ready = false; } vcs[2][3];
     struct KvForward { std::vector<GemmCall> calls; GemmParams* d_probs = nullptr; int* d_tiles = nullptr; int total_tiles = 0; double flops = 0; bool ready = false; } kvf;
+    // r06: the LAST ViT layer's attention consumes one query row per frame (pool = 'cls').  16-bit engines run it re-associated (attn_cls.h): g = q W_k and
+    // c = p h per head instead of the K / V projections of all tokens, so two thirds of that layer's QKV Linear and of its dgrad / wgrad are never formed.
+    // The per-head projections around the kernel (g = q W_k, out = c W_v^T, dc = dout W_v, dq = dg W_k^T) are batched launches of the DMA-ring GEMM (gemm_mid.h,
+    // one problem per head); the K / V weight-gradient slices are one grouped launch whose descriptor table holds pointers into the gradient buffer and
+    // the workspace and is rebuilt when either changes.  One instance per tower.
+    struct ClsPath {
+        bool on = false;
+        void *q = nullptr, *g = nullptr, *c = nullptr, *dc = nullptr, *dg = nullptr, *dq = nullptr; float* r0 = nullptr;
+        struct Tab { std::vector<GemmCall> calls; GemmParams* d_probs = nullptr; int* d_tiles = nullptr; int total_tiles = 0; double flops = 0; } wg;      // grouped weight gradients
+        // K / V slices of to_qkv.weight's gradient: 2 H problems of 64 x D over N frames — 128 tiles with a 2 048-long reduction each at the benchmark shape
+        // (150 us); the frames are cut into wg_split chunks, every chunk a problem of its own writing a slab [2 inner D] (the 2 H slices are contiguous in the
+        // flat buffer), and one column-sum pass adds the slabs in order (deterministic)
+        int wg_split = 1; float* wg_slab = nullptr;
+        bool bwd_ready = false; int bwd_lane = -1;
+    } cls[2];
 };
 
 namespace {
@@ -222,6 +237,8 @@ void build_params(vcad_engine* e) {
     }
 }
 
+#define g_frame_first VC_AB(frame_first, 1)   // A/B: 0 = r05's enqueue order of the whole backward (CAD tower's stage before the frame tower's)
+#define g_cls_path VC_AB(cls_path, 1)         // A/B: 0 = r05's last ViT layer (K / V projections of all tokens + single-query attention kernels)
 // ---------------------------------------------------------------------------------------------------------------
 // workspace plan
 // ---------------------------------------------------------------------------------------------------------------
@@ -259,6 +276,20 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
             vc.ready = false;
         }
         a.statn = b.take<float>(a.N * 2 * 4); a.e = b.take<void>(a.N * D * es);
+        {   // class-token attention of the last layer (vcad_engine::ClsPath)
+            vcad_engine::ClsPath& cp = e->cls[v];
+            cp.on = e->dt == VC_BF16 && e->ct == VC_BF16 && !e->fp8 && inner == (long)c.vit_heads * 64 && vc_cls_attn_ok(D, c.vit_heads, (int)(P + 1), c.vit_dim_head) && g_cls_path;
+            cp.bwd_ready = false; cp.bwd_lane = -1;
+            if (cp.on) {
+                const size_t hd = (size_t)a.N * c.vit_heads * D * es;
+                cp.q = b.take<void>(a.N * inner * es); cp.g = b.take<void>(hd); cp.c = b.take<void>(hd);
+                cp.dc = b.take<void>(hd); cp.dg = b.take<void>(hd); cp.dq = b.take<void>(a.N * inner * es); cp.r0 = b.take<float>(a.N * D * 4);
+                cp.wg_split = (int)(a.N / 256 < 1 ? 1 : (a.N / 256 > 16 ? 16 : a.N / 256));
+                cp.wg_slab = cp.wg_split > 1 ? b.take<float>((size_t)cp.wg_split * 2 * inner * D * 4) : nullptr;
+                const size_t np = (size_t)2 * c.vit_heads * cp.wg_split;
+                cp.wg.d_probs = b.take<GemmParams>(np * sizeof(GemmParams)); cp.wg.d_tiles = b.take<int>((np + 1) * 4);
+            }
+        }
     }
     e->ui = b.take<float>(M * H * 4); e->cadE = b.take<void>((long)B * H * es); e->cadterm = b.take<float>((long)B * H * 4);
     if (c.num_views > 0) {
@@ -484,6 +515,59 @@ bool ensure_side(vcad_engine* e) {
     return true;
 }
 
+// Class-token attention of tower v's last layer (vcad_engine::ClsPath).  Head h owns rows inner + 64 h .. (K slice) and 2 inner + 64 h .. (V slice) of
+// to_qkv.weight [3 inner, D]; q / dout / out / dq are [N, inner] (64 columns per head), g / c / dc / dg are [N][H][D].
+// One per-head projection for all heads: problem h at A + h bsa, W + h 64 D, C + h bsc (gemm_mid.h batched launch)
+int cls_proj(const Ctx& cx, Mat A, long bsa, Mat W, int trb, Mat C, long bsc, long N, int Nn, int K, int role) {
+    vcad_engine* e = cx.e;
+    GemmCall gc; memset(&gc, 0, sizeof(gc));
+    gc.role = role; gc.ct = e->ct; gc.sa = A.dt; gc.sb = W.dt; gc.to = C.dt; gc.tra = 0; gc.trb = trb; gc.flags = e->gemm_flags;
+    GemmParams& p = gc.p;
+    p.A = A.p; p.B = W.p; p.C = (void*)C.p; p.M = (int)N; p.N = Nn; p.K = K; p.lda = A.ld; p.ldb = W.ld; p.ldc = C.ld; p.alpha = 1.0f; p.rowadd_div = 1;
+    CK(vc_gemm_mid_batched(gc, e->c.vit_heads, bsa, 64L * e->c.vit_dim, bsc, cx.s));
+    ++e->kernel_launches[VC_TAG_GEMM_MID];
+    return 0;
+}
+// descriptor table of the K / V weight-gradient slices (grouped launch): dW_k,h = q_h^T dg_h and dW_v,h = dout_h^T c_h, the frames cut into wg_split chunks
+// (chunk s -> slab s; a single chunk goes straight into the gradient buffer)
+int build_cls_wgrads(const Ctx& cx, int v) {
+    vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
+    vcad_engine::ClsPath& cp = e->cls[v];
+    const int D = c.vit_dim, H = c.vit_heads, inner = H * c.vit_dim_head;
+    const long N = a.N, HD = (long)H * D;
+    const VitW::L& wl = w.l[c.vit_depth - 1];
+    const size_t es = e->esz;
+    auto at = [&](const void* base, long off_elems) { return (const void*)((const char*)base + (size_t)off_elems * es); };
+    vcad_engine::ClsPath::Tab& tb = cp.wg;
+    tb.calls.clear(); tb.flops = 0;
+    auto add = [&](Mat A, Mat B, float* C, int K) {
+        GemmCall gc; memset(&gc, 0, sizeof(gc));
+        gc.ct = e->ct; gc.sa = A.dt; gc.sb = B.dt; gc.to = VC_F32; gc.tra = 1; gc.trb = 1;
+        GemmParams& p = gc.p;
+        p.A = A.p; p.B = B.p; p.C = (void*)C; p.M = 64; p.N = D; p.K = K; p.lda = A.ld; p.ldb = B.ld; p.ldc = D; p.alpha = 1.0f; p.rowadd_div = 1;
+        tb.calls.push_back(gc); tb.flops += 2.0 * 64 * D * K;
+    };
+    const void* dao = cx.L().t_dao;                    // (the out-projection's dgrad leaves the class rows compact: [N, inner])
+    const int S = cp.wg_split; const long per = VC_CEIL_DIV(VC_CEIL_DIV(N, (long)S), 8) * 8;
+    for (int h = 0; h < H; ++h)
+        for (int sp = 0; sp < S; ++sp) {
+            const long f0 = sp * per, nf = (f0 + per <= N ? per : N - f0);
+            if (nf <= 0) { vc_set_error("internal: empty frame chunk in the class-token weight gradients"); return VC_ERR_ARG; }
+            float* ok_ = S > 1 ? cp.wg_slab + (size_t)sp * 2 * inner * D + (size_t)64 * h * D : cx.Gf(wl.qkv + ((long)inner + 64 * h) * D);
+            float* ov_ = S > 1 ? cp.wg_slab + (size_t)sp * 2 * inner * D + (size_t)inner * D + (size_t)64 * h * D : cx.Gf(wl.qkv + (2L * inner + 64 * h) * D);
+            add(cx.AT(at(cp.q, f0 * inner + 64 * h), inner), cx.AT(at(cp.dg, f0 * HD + (long)h * D), HD), ok_, (int)nf);
+            add(cx.AT(at(dao, f0 * inner + 64 * h), inner), cx.AT(at(cp.c, f0 * HD + (long)h * D), HD), ov_, (int)nf);
+        }
+    const int n = (int)tb.calls.size();
+    std::vector<GemmParams> probs(n); std::vector<int> tiles(n + 1);
+    CK(vc_gemm_grouped_prepare(tb.calls.data(), n, probs.data(), tiles.data(), 64));
+    tb.total_tiles = tiles[n];
+    CK(vc_upload(tb.d_probs, probs.data(), (size_t)n * sizeof(GemmParams), cx.s));
+    CK(vc_upload(tb.d_tiles, tiles.data(), (size_t)(n + 1) * sizeof(int), cx.s));
+    cp.bwd_ready = true; cp.bwd_lane = cx.ln;
+    return 0;
+}
+
 int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstride) {
     vcad_engine* e = cx.e; const vcad_config& c = e->c; const VitW& w = e->wv[v]; VitActs& a = e->va[v];
     const int D = c.vit_dim, inner = c.vit_heads * c.vit_dim_head, g = c.image_size / c.patch_size, P = g * g, pd = c.patch_size * c.patch_size;
@@ -556,10 +640,22 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
               if (q8) CK(cx.lin_fwd_q(cx.AT(l.g, c.vit_mlp), wl.w4, cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep));
               else CK(cx.lin_fwd(cx.VT(l.g, c.vit_mlp, pk), cx.W(wl.w4, c.vit_mlp), cx.A32(l.xo, D), (int)R, D, c.vit_mlp, ep)); }
         } else {
+            vcad_engine::ClsPath& cp = e->cls[v];
+            if (cp.on) {        // r06: scores and context on (g = q W_k, normalised tokens) — no K / V projections (attn_cls.h)
+                const long HD = (long)c.vit_heads * D;
+                const Mat Wk = cx.W(wl.qkv + (long)inner * D, D), Wv = cx.W(wl.qkv + 2L * inner * D, D);
+                CK(cx.lin_fwd(cx.AT(l.h_a, TD), cx.W(wl.qkv, D), cx.AT(cp.q, inner), (int)N, inner, D, Epi()));                                      // Q: cls rows
+                CK(cls_proj(cx, cx.AT(cp.q, inner), 64, Wk, 1, cx.AT(cp.g, HD), D, N, D, 64, VC_CAT_GEMM_FWD + 1));                                  // g_h = q_h W_k,h
+                ClsAttnParams ca; memset(&ca, 0, sizeof(ca));
+                ca.ha = l.h_a; ca.ld_ha = D; ca.g = cp.g; ca.c = cp.c; ca.lse = l.lse; ca.N = (int)N; ca.H = c.vit_heads; ca.P1 = P + 1; ca.scale = scale; ca.drop = ap.drop;
+                CK(vc_cls_attn_fwd(ca, cx.s));
+                CK(cls_proj(cx, cx.AT(cp.c, HD), D, Wv, 0, cx.AT(l.ao, TI), 64, N, 64, D, VC_CAT_GEMM_FWD + 1));                                     // out_h = c_h W_v,h^T (class rows of ao)
+            } else {
             CK(cx.lin_fwd(cx.AT(l.h_a, D), cx.W(wl.qkv + (long)inner * D, D), cx.AT(q + (size_t)inner * e->esz, 3 * inner), (int)R, 2 * inner, D, Epi()));   // K, V: all tokens
             CK(cx.lin_fwd(cx.AT(l.h_a, TD), cx.W(wl.qkv, D), cx.AT(l.qkv, 3 * TI), (int)N, inner, D, Epi()));                                       // Q: cls rows
             ap.Tq = 1; ap.ldq = 3 * TI; ap.ldo = TI;                                   // query row b -> cls row of frame b
             CK(vc_attn_fwd(e->dt, c.vit_dim_head, ap, cx.s));
+            }
             { Epi ep; ep.bias = cx.Pf(wl.ob); ep.residual = x; ep.ldr = TD; ep.drop = d_out; CK(cx.lin_fwd(cx.AT(l.ao, TI), cx.W(wl.ow, inner), cx.A32(l.xm, TD), (int)N, D, inner, ep)); }
             CK(cx.ln_fwd(VC_F32, l.xm, TD, wl.fnw, wl.fnb, nullptr, 0, l.h_f, D, l.stat_f, N, D));                   // h_f, z, g: compact [N, .]
             { Epi ep; ep.bias = cx.Pf(wl.b1); ep.act = VC_ACT_GELU; ep.aux = l.z; ep.ldaux = c.vit_mlp; ep.drop = d_act;
@@ -667,6 +763,24 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.lin_wgrad(du, cx.VT(l.ao, ldao, pk), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
         if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.VT(cx.L().t_dao, inner, pk), (int)Rm, D, inner, Epi()));
+        if (cls_only && e->cls[v].on) {      // r06 (attn_cls.h): dc = dout W_v -> kernel (dg, dh of every token) -> dq = dg W_k^T; weight gradients of the three slices
+            vcad_engine::ClsPath& cp = e->cls[v];
+            const long HD = (long)c.vit_heads * D;
+            const Mat Wk = cx.W(wl.qkv + (long)inner * D, D), Wv = cx.W(wl.qkv + 2L * inner * D, D);
+            if (!cp.bwd_ready || cp.bwd_lane != cx.ln) CK(build_cls_wgrads(cx, v));
+            CK(cls_proj(cx, cx.AT(cx.L().t_dao, inner), 64, Wv, 1, cx.AT(cp.dc, HD), D, N, D, 64, VC_CAT_GEMM_DGRAD + 1));                           // dc_h = dout_h W_v,h
+            ClsAttnParams ca; memset(&ca, 0, sizeof(ca));
+            ca.ha = l.h_a; ca.ld_ha = D; ca.g = cp.g; ca.dc = cp.dc; ca.lse = l.lse; ca.dg = cp.dg; ca.dha = cx.L().t_dh; ca.ld_dha = D; ca.r0 = cp.r0;
+            ca.N = (int)N; ca.H = c.vit_heads; ca.P1 = P + 1; ca.scale = 1.0f / sqrtf((float)c.vit_dim_head); ca.drop = cx.site(v + 1, L, Ctx::K_ATTN);
+            CK(vc_cls_attn_bwd(ca, cx.s));
+            CK(cls_proj(cx, cx.AT(cp.dg, HD), D, Wk, 0, cx.AT(cp.dq, inner), 64, N, 64, D, VC_CAT_GEMM_DGRAD + 1));                                   // dq_h = dg_h W_k,h^T
+            CK(vc_gemm_grouped_launch(cp.wg.calls[0], cp.wg.d_probs, cp.wg.d_tiles, (int)cp.wg.calls.size(), cp.wg.total_tiles, cp.wg.flops, cx.s, 64));   // K and V slices of to_qkv.weight
+            e->kernel_launches[VC_TAG_GEMM_GROUPED]++;
+            if (cp.wg_split > 1) CK(cx.colsum(cx.A32(cp.wg_slab, 2L * inner * D), cp.wg_split, 2 * inner * D, cx.Gf(wl.qkv + (long)inner * D), 0));
+            CK(cx.lin_wgrad(cx.AT(cp.dq, inner), cx.AT(l.h_a, TD), cx.Gf(wl.qkv), D, nullptr, (int)N, inner, D));                    // Q slice: class rows only
+            { Epi ep; ep.residual = cp.r0; ep.ldr = D;                                                                              // class row of dh: + dq W_q (fp32 sum, rounded once)
+              CK(cx.lin_dgrad(cx.AT(cp.dq, inner), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, TD), (int)N, inner, D, ep)); }
+        } else {
         {
             AttnParams p; memset(&p, 0, sizeof(p));
             const char* q = (const char*)l.qkv; char* dq = (char*)cx.L().t_dqkv;
@@ -685,6 +799,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         CK(cx.lin_wgrad(cx.VT(cx.L().t_dqkv, 3 * inner, pk), cx.VT(l.h_a, D, pk), cx.Gf(wl.qkv), D, nullptr, (int)R, 3 * inner, D));
         if (cx.hasT(wl.qkvT)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dqkv, 3 * inner), cx.WT(wl.qkvT, 3 * inner), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
         else CK(cx.lin_dgrad(cx.VT(cx.L().t_dqkv, 3 * inner, pk), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
+        }
         // (the layer below is never the cls-only one: the du it receives is pre-split whenever the mode stores pre-split tensors)
         if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), defer_cs ? l.part_an : nullptr, cx.pk_acts())); have_du = true; }
         else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, vc_drop{0u, 0u, 1.0f}, nullptr, nullptr, nullptr, defer_cs ? l.part_an : nullptr));
@@ -1089,6 +1204,11 @@ int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     { const int g = cfg->image_size / cfg->patch_size; if (g * g + 1 > 64) { vc_set_error("ViT token count %d exceeds the 64-token attention tile", g * g + 1); return VC_ERR_UNSUPPORTED; } }
     if (cfg->num_classes != 5 || cfg->num_params != 6 || cfg->num_params_values != 1000) { vc_set_error("heads must be 5 + 6x1000 (reference model/autoregressive_transformer.py:218)"); return VC_ERR_UNSUPPORTED; }
     if (cfg->dim_feedforward % 8 || cfg->vit_mlp % 8) { vc_set_error("dim_feedforward / vit_mlp must be multiples of 8 (16-byte bf16 rows)"); return VC_ERR_UNSUPPORTED; }
+    // 16-bit engines run the ViT MLP's activation derivative as a pass that also reduces the first Linear's bias gradient (partial rows of 256 / (vit_mlp / 8)
+    // token rows per workgroup) and defer that reduction: widths the pass has no row blocks for are refused here, not with a fault in the first backward
+    // (vit_mlp >= 2056 divided by zero in the workspace plan, 768 / 1536 / 3072 failed in the backward).  The reference hardcodes mlp_dim = 512.
+    if (s16 && !vc_dact_bwd_fused_ok(cfg->vit_mlp)) {
+        vc_set_error("vit_mlp %d unsupported by the 16-bit engines: vit_mlp / 8 must divide 256 (64, 128, 256, 512, 1024, 2048; the reference uses 512)", cfg->vit_mlp); return VC_ERR_UNSUPPORTED; }
     vcad_engine* e = new vcad_engine();
     e->c = *cfg; e->dt = s16 ? VC_BF16 : VC_F32; e->ct = cfg->dtype == VCAD_BF16X3 ? VC_X3 : e->dt; e->esz = s16 ? 2 : 4;
 #ifdef VC_H16
@@ -1127,6 +1247,7 @@ int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, v
     e->Spk = e->ct == VC_X3 ? (uint32_t*)shadow : nullptr;      // optional: without it the bf16x3 GEMMs split the fp32 weights while staging
     e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false; e->kvf.ready = false;
     for (int v = 0; v < 2; ++v) for (int part = 0; part < 3; ++part) e->vcs[v][part].ready = false;
+    for (int v = 0; v < 2; ++v) e->cls[v].bwd_ready = false;
     return 0;
 }
 // No CPU fallback: an engine whose buffers still live in host memory (a model built on "cpu" and not yet moved) is refused by every entry point that
@@ -1352,13 +1473,19 @@ int vcad_backward(vcad_engine* e, const float* dcmds, const float* dpars, void* 
     CK(vcad_backward_stage(e, 1, dcmds, dpars, stream));
     CK(ready(1, s));
     if (fork) { CK(vc_event_record(e->ev_fork, s)); CK(vc_stream_wait_event(e->side, e->ev_fork)); }
+    // r06: the CAD tower's ~180 launches are 5-20 us kernels — the GPU retires them as fast as the host enqueues them — and they used to be enqueued BEFORE the
+    // frame tower's first backward stage: the caller's stream sat idle (1.2-1.4 ms in the kernel trace) until the host got there.  With the side stream forked
+    // (and no per-bucket hook that expects stage order) the frame tower's upper stage is enqueued first: its 70-340 us kernels keep the GPU busy while the host
+    // feeds the side stream.  Same kernels, same streams, same events — only the host's enqueue order changes.
+    const bool frame_first = fork && !e->bucket_cb && NB_BUCKETS > CAD_STAGE + 1 && g_frame_first;
+    if (frame_first) CK(vcad_backward_stage(e, CAD_STAGE + 1, dcmds, dpars, stream));
     e->bwd_fork = fork;
     int rc = vcad_backward_stage(e, CAD_STAGE, dcmds, dpars, stream);
     e->bwd_fork = false;
     if (rc) return rc;
     CK(ready(CAD_STAGE, fork ? e->side : s));
     if (fork) CK(vc_event_record(e->ev_join, e->side));
-    for (int st = CAD_STAGE + 1; st < NB_BUCKETS; ++st) { CK(vcad_backward_stage(e, st, dcmds, dpars, stream)); CK(ready(st, s)); }
+    for (int st = CAD_STAGE + 1 + (frame_first ? 1 : 0); st < NB_BUCKETS; ++st) { CK(vcad_backward_stage(e, st, dcmds, dpars, stream)); CK(ready(st, s)); }
     if (fork) CK(vc_stream_wait_event(s, e->ev_join));
     return 0;
 }

@@ -47,6 +47,9 @@ struct GemmParams {
     int stagger;                                                          // first-wave start offset in units of s_sleep(127) (~3.4 us); 0 = off
     int n_group;                                                          // register-staged kernel: tile columns per sweep (0 = all: n fastest over the whole width); see gemm_tile_program
     int debug_skip;                                                       // ablation only (tools/gemm_ablate.py): 1 = no global loads in the loop, 2 = no LDS stores, 4 = no MFMA
+    // gemm_mid.h only (r06): `batch` independent problems of this shape in one grid (blockIdx.y), problem b at A + b bsa, B + b bsb, C + b bsc (elements) —
+    // the per-head projections around the class-token attention (attn_cls.h).  0 / 1 = a single problem.
+    int batch; long bsa, bsb, bsc;
 };
 
 VC_DEV float vc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -741,8 +744,8 @@ struct GemmGroup { const GemmParams* probs; const int* tile_start; int n; };
 template <typename CT, typename SA, typename SB, typename TO, bool TRA, bool TRB, int WT>
 VC_KERNEL __launch_bounds__(GEMM_THREADS, 2) void gemm_grouped_kernel(GemmGroup grp) {
     const int t = blockIdx.x;
-    int g = 0;
-    while (g + 1 < grp.n && grp.tile_start[g + 1] <= t) ++g;                    // n is a few dozen; wave-uniform scalar loop
+    int g = 0, hi = grp.n - 1;                                                  // the largest g with tile_start[g] <= t: wave-uniform binary search (r06: the class-token
+    while (g < hi) { const int mid = (g + hi + 1) >> 1; if (grp.tile_start[mid] <= t) g = mid; else hi = mid - 1; }   // weight gradients are 512 problems; a linear scan was one dependent scalar load per problem)
     const GemmParams p = grp.probs[g];
     constexpr int BT = 64 * WT;
     const int nx = (p.N + BT - 1) / BT, ny = (p.M + BT - 1) / BT;

@@ -37,6 +37,11 @@ template <int N> VC_DEV void gm_wait_stages(int younger) {      // at most `youn
 
 template <typename TO, bool TRB, int BM, int BN>
 VC_KERNEL __launch_bounds__(GM_THREADS, 1) void gemm_mid_kernel(GemmParams p) {
+    if (p.batch > 1) {                                       // batched launch: blockIdx.y picks the problem (wave-uniform pointer arithmetic)
+        const long bz = blockIdx.y;
+        p.A = (const unsigned char*)p.A + bz * p.bsa * 2; p.B = (const unsigned char*)p.B + bz * p.bsb * 2;
+        p.C = (unsigned char*)p.C + bz * p.bsc * (long)sizeof(TO);
+    }
     using TL = GmTile<BM, BN>;
     constexpr int MI = TL::MI, NJ = TL::NJ, NPA = TL::NPA, NPB = TL::NPB, ES = TL::ES;
     VC_DYN_SHARED(vc_bf16, lds);

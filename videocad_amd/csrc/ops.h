@@ -4,6 +4,7 @@
 #include "gemm.h"
 #include "norm.h"
 #include "attn.h"
+#include "attn_cls.h"
 #include "loss.h"
 #include "optim.h"
 #include "ab.h"
@@ -51,10 +52,11 @@ int vc_gemm_prepare(GemmCall& c);                                   // validatio
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s);   // persistent DMA-fed kernel (ops_gemm_dma.hip), tile 256 x BN; c already prepared
 int vc_gemm_mid_launch(GemmCall c, vc_stream_t s);          // gemm_mid.h (ops_gemm_mid.hip)
 int vc_gemm_mid_tile_m(int trb); int vc_gemm_mid_tile_n(int trb);
+int vc_gemm_mid_batched(GemmCall c, int batch, long bsa, long bsb, long bsc, vc_stream_t s);   // (ops_gemm_mid.hip) batch problems of one shape in one grid
 // grouped launch of many same-signature problems in one grid (see ops_gemm.hip)
-int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start);
+int vc_gemm_grouped_prepare(GemmCall* calls, int n, GemmParams* probs, int* tile_start, int tile = 128);       // tile: 128 (every signature) or 64 (16-bit weight gradients)
 bool vc_gemm_grouped_has_forward();
-int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s);
+int vc_gemm_grouped_launch(const GemmCall& sig, const GemmParams* probs, const int* tile_start, int n, int total_tiles, double flops, vc_stream_t s, int tile = 128);
 
 int vc_ln_fwd(int tx, int ty, int C, int mode, LnFwdParams p, vc_stream_t s);
 // partial_ws: >= ln_bwd_blocks(rows) * 2 * C floats; dgamma/dbeta written (not accumulated)
@@ -87,6 +89,7 @@ int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_dro
 int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out = nullptr, float* partial_ws = nullptr,
                      size_t partial_bytes = 0, float* colsum_ws = nullptr, bool defer_reduce = false);      // defer_reduce: leave the [vc_dact_bwd_blocks][cols] partial rows in partial_ws (the caller sums them later); fails if the fused form does not apply
 long vc_dact_bwd_blocks(long rows, int cols);
+bool vc_dact_bwd_fused_ok(int cols);           // the activation-derivative pass can reduce its output over rows (partial-row form): cols / 8 divides 256
 // grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]
@@ -98,6 +101,10 @@ int vc_gemm_mx8(Mx8Params q, int to, vc_stream_t s);
 
 int vc_attn_fwd(int t, int D, AttnParams p, vc_stream_t s);
 int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s);
+// class-token attention of the last ViT layer on (g = q W_k, normalised tokens) instead of projected keys / values (attn_cls.h); 16-bit storage only
+bool vc_cls_attn_ok(int D, int H, int P1, int dim_head);
+int vc_cls_attn_fwd(ClsAttnParams p, vc_stream_t s);
+int vc_cls_attn_bwd(ClsAttnParams p, vc_stream_t s);
 
 int vc_loss_fwd(LossParams p, vc_stream_t s);          // rows + finalize
 int vc_loss_bwd(LossParams p, vc_stream_t s);          // dlogits

@@ -3,6 +3,7 @@
 #include "attn_mfma.h"
 #include "attn_f32.h"
 #include "attn_x3.h"
+#include "attn_cls_kernels.h"
 
 static int clampw(const AttnParams& p) { int mx = (p.Tq + p.qpos) > p.Tk ? (p.Tq + p.qpos) : p.Tk; return p.window > mx ? mx : (p.window < 1 ? 1 : p.window); }
 static int max_keys(const AttnParams& p) { int w = clampw(p); return w < p.Tk ? w : p.Tk; }        // visible keys per query
@@ -284,4 +285,34 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
         return VC_OK;
     }
     return t == VC_BF16 ? attn_bwd_t<vc_bf16>(D, p, s) : attn_bwd_t<float>(D, p, s);
+}
+
+// ---------------------------------------------------------------------------------------------- class-token attention (attn_cls.h)
+bool vc_cls_attn_ok(int D, int H, int P1, int dim_head) { return D == CA_D && H >= 1 && H <= 16 && P1 >= 1 && P1 <= 64 && dim_head == 64; }
+static int cls_attn_check(const ClsAttnParams& p, bool bwd) {
+    if (p.N < 1 || !vc_cls_attn_ok(CA_D, p.H, p.P1, 64)) { vc_set_error("class-token attention: N=%d H=%d P1=%d outside the kernel's limits (H <= 16, P1 <= 64)", p.N, p.H, p.P1); return VC_ERR_UNSUPPORTED; }
+    auto bad = [](const void* q, long ld) { return !q || ((uintptr_t)q % 16) || (ld % 8); };
+    if (bad(p.ha, p.ld_ha) || bad(p.g, CA_D) || !p.lse || (!bwd && bad(p.c, CA_D)) || (bwd && (bad(p.dc, CA_D) || bad(p.dg, CA_D) || bad(p.dha, p.ld_dha)))) {
+        vc_set_error("class-token attention: tensors must be 16-byte aligned with leading dimensions multiple of 8"); return VC_ERR_ARG;
+    }
+    if ((double)p.N * p.H * p.P1 >= 4294967296.0) { vc_set_error("class-token attention: dropout index overflows 32 bits"); return VC_ERR_UNSUPPORTED; }
+    return VC_OK;
+}
+int vc_cls_attn_fwd(ClsAttnParams p, vc_stream_t s) {
+    if (int rc = cls_attn_check(p, false)) return rc;
+    static unsigned attr = 0;
+    if (!(attr & vc_device_bit())) { if (int rc = set_dyn_lds(cls_attn_fwd_kernel, cls_attn_fwd_lds(64))) return rc; attr |= vc_device_bit(); }
+    const double rows = (double)p.N * p.P1, hd = (double)p.N * p.H * CA_D;
+    ProfScope ps(VC_CAT_ATTN, 4.0 * p.N * p.H * p.P1 * CA_D, rows * CA_D * 2 + 2 * hd * 2, s);
+    VC_LAUNCH(cls_attn_fwd_kernel, dim3((unsigned)p.N), dim3(256), cls_attn_fwd_lds(p.P1), s, p);
+    return VC_OK;
+}
+int vc_cls_attn_bwd(ClsAttnParams p, vc_stream_t s) {
+    if (int rc = cls_attn_check(p, true)) return rc;
+    static unsigned attr = 0;
+    if (!(attr & vc_device_bit())) { if (int rc = set_dyn_lds(cls_attn_bwd_kernel, cls_attn_bwd_lds(64))) return rc; attr |= vc_device_bit(); }
+    const double rows = (double)p.N * p.P1, hd = (double)p.N * p.H * CA_D;
+    ProfScope ps(VC_CAT_ATTN, 10.0 * p.N * p.H * p.P1 * CA_D, 2 * rows * CA_D * 2 + 3 * hd * 2, s);
+    VC_LAUNCH(cls_attn_bwd_kernel, dim3((unsigned)p.N), dim3(512), cls_attn_bwd_lds(p.P1), s, p);
+    return VC_OK;
 }

@@ -208,7 +208,13 @@ int vc_act_fwd_bf16(const void* z, void* g, long rows, int cols, int act, vc_dro
 }
 // colsum_out (optional): column sums of the result, i.e. the bias gradient of the Linear whose pre-activation z is; partial_ws holds
 // vc_dact_bwd_blocks(rows, cols) x cols floats, colsum_ws as for vc_colsum
-long vc_dact_bwd_blocks(long rows, int cols) { const long b = VC_CEIL_DIV(rows, (long)(256 / (cols / 8 > 0 ? cols / 8 : 1))); return b > 2048 ? 2048 : (b < 1 ? 1 : b); }
+// (a width the fused partial-row form does not take — more than 256 octets per row, or an octet count that does not divide 256 — has no row blocks: 1,
+// never a division by zero; vc_dact_bwd_fused_ok says whether the form applies)
+bool vc_dact_bwd_fused_ok(int cols) { const int c8n = cols / 8; return cols % 8 == 0 && c8n >= 1 && c8n <= 256 && 256 % c8n == 0; }
+long vc_dact_bwd_blocks(long rows, int cols) {
+    if (!vc_dact_bwd_fused_ok(cols)) return 1;
+    const long b = VC_CEIL_DIV(rows, (long)(256 / (cols / 8))); return b > 2048 ? 2048 : (b < 1 ? 1 : b);
+}
 int vc_dact_bwd_bf16(void* dz, const void* z, long rows, int cols, int kind, vc_drop d, vc_stream_t s, float* colsum_out, float* partial_ws, size_t partial_bytes, float* colsum_ws, bool defer_reduce) {
     if (rows <= 0) return VC_OK;
     if (int rc = act_check(dz, z, rows, cols, "dact_bwd")) return rc;

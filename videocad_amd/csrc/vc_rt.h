@@ -368,6 +368,22 @@ VC_HD uint32_t vc_pack_bf16x2(float lo, float hi) {
 }
 #endif
 
+// c + a.lo * b.lo + a.hi * b.hi on two packed pairs of the 16-bit storage format, fp32 accumulate: one v_dot2c_f32_{bf16,f16} on gfx950 (attn_cls.h: the
+// 512-long dot products of the class-token attention are VALU work — too small for the matrix cores' tile shapes to pay)
+VC_DEV float vc_dot2(uint32_t a, uint32_t b, float c) {
+#if !defined(VC_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#ifdef VC_H16
+    typedef _Float16 vc_d2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(vc_d2_hw, a), __builtin_bit_cast(vc_d2_hw, b), c, false);
+#else
+    typedef __bf16 vc_d2_hw __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vc_d2_hw, a), __builtin_bit_cast(vc_d2_hw, b), c, false);
+#endif
+#else
+    return c + vc_lo16_f32(a) * vc_lo16_f32(b) + vc_hi16_f32(a) * vc_hi16_f32(b);
+#endif
+}
+
 template <typename T> struct vc_cvt;
 template <> struct vc_cvt<float> {
     VC_HD static float to_f32(float v) { return v; }

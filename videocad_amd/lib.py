@@ -100,6 +100,8 @@ PROTOTYPES = {
     "vcad_op_attention_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "vcad_op_attention_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "vcad_op_cls_attention_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "vcad_op_cls_attention_bwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _f, _vp]),
     "vcad_op_attention_bwd_o": (_i, [_i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                      _i, _i, _i, _i, _i, _i, _f, _vp]),
 }
@@ -109,7 +111,7 @@ PROTOTYPES = {
 AB_PROTOTYPES = {name: (None, [_i]) for name in (
     "vcad_debug_force_gemm_tile", "vcad_debug_gemm_dma", "vcad_debug_gemm_wide", "vcad_debug_gemm_mid", "vcad_debug_gemm_xcd_cols",
     "vcad_debug_attn_variant", "vcad_debug_gemm_waves", "vcad_debug_split_gelu", "vcad_debug_no_side_stream", "vcad_debug_gemm_policy",
-    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip", "vcad_debug_res_in_ln", "vcad_debug_wgrad_bk32")}
+    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip", "vcad_debug_res_in_ln", "vcad_debug_wgrad_bk32", "vcad_debug_cls_path", "vcad_debug_frame_first")}
 AB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_bin", "libvcad_ab.so")
 
 
