@@ -104,6 +104,8 @@ int vcad_set_multiview(vcad_engine* e, const void* images);
 /* keep-multipliers of one site, recomputed from (seed, site, index); a pure function of the engine's dropout setting (the parity tests hand them to the oracle)
  *  (module 1 = frame ViT, 2 = CAD ViT, 3 = decoder; kind ids in engine.hip) -> HOST buffer */
 int vcad_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int64_t n, float* host_out);
+/* same, elements first .. first + n - 1 of the site's index space */
+int vcad_dropout_mask_range(const vcad_engine* e, int module, int layer, int kind, int64_t first, int64_t n, float* host_out);
 
 /* ---- AutoRegressiveTransformer.forward (reference model/autoregressive_transformer.py:121-220)
  * frames: fp32, frame (b,t) at frames + b*frame_bstride + t*S*S  (so batch['frames'][:, :-1] needs no copy)
@@ -257,6 +259,8 @@ void vcad_debug_gemm_skip(int mask);
 void vcad_debug_res_in_ln(int on);           /* 16-bit ViT layers: residual add + branch dropout inside the LayerNorm pass behind to_out / net.4 (1, default) or in the GEMM epilogue (0: r04) */
 void vcad_debug_wgrad_bk32(int on);          /* 256-wide weight-gradient kernel: 0 (default) = two 64-deep ring stages; 1 = r05's experiment, four 32-deep stages — measured slower (172 -> 211 us, profiles/r05_wgrad_bk32_ab.txt) */
 void vcad_debug_cls_path(int on);            /* 16-bit engines, last ViT layer: class-token attention on (q W_k, normalised tokens) (1, default: r06, csrc/attn_cls.h) or K / V projections of all tokens (0: r05) */
+void vcad_debug_dec_h16(int on);             /* 16-bit engines: decoder LayerNorms also emit 16-bit copies for the Linears / deferred weight gradients behind them (1, default: r06) or not (0: r05) */
+void vcad_debug_pe_fold(int on);             /* 16-bit engines: patch-embedding LayerNorm affine folded into its Linear (1, default: r06) or applied to the patches with a dgrad + LayerNorm backward for its gradients (0: r05) */
 void vcad_debug_frame_first(int on);         /* whole backward with the side stream forked: frame tower's upper stage enqueued before the CAD tower's stage (1, default: r06) or after (0: r05) */
 #endif
 

@@ -213,6 +213,45 @@ def config_step_case(case, cfg_name, B, T, seed, scratch):
             "min_top2_gap_params": float((top2[..., 0] - top2[..., 1]).min()), "oracle_vs_reference": dev}
 
 
+def seqinf_cases(scratch):
+    """r06: f1 pinned to the IMPORTED reference's own `sequential_inference` (model/autoregressive_transformer.py:222-275), action=False
+    (zero actions: the branch that runs upstream — action=True raises IndexError in apply_action_mask, :104, which is asserted here) — canonical configuration
+    and `..._large` (nhead 8), B = 2, T = 8.  The oracle's prefix runs are checked against it before the vectors are written."""
+    out, info = {}, {}
+    for tag, cfg_name, seed in (("canon", "cad_past_10_actions_and_states_timestep_embedding", 31), ("nhead8_large", "cad_past_10_actions_and_states_large", 32)):
+        rcfg = json.load(open(os.path.join(HERE, "model_configs.json")))[cfg_name]
+        ocfg = dict(O.CANONICAL_CONFIG); ocfg.update(nhead=rcfg["nhead"], window_size=rcfg["window_size"])
+        wts = {k: synth.make_param(k, s) for k, s in O.param_shapes(ocfg).items()}
+        model, _, _ = build_reference(cfg_name, wts, scratch)
+        model.eval()
+        B, T = 2, 8
+        b = synth.make_batch(B, T - 1, seed=seed)
+        frames, cad = torch.tensor(b["frames"]), torch.tensor(b["cad_image"])
+        with torch.no_grad():
+            c0, p0 = model.sequential_inference(frames, cad, action=False)
+            try:                                   # (the action=True branch fails upstream: apply_action_mask indexes a 2-D tensor with three indices, :104)
+                model.sequential_inference(frames, cad, action=True)
+                raise AssertionError("the reference's action=True branch ran: add it to the fixture")
+            except IndexError:
+                pass
+        P = {k: torch.from_numpy(v) for k, v in wts.items()}
+        worst = 0.0
+        for t in range(T):                         # oracle: forward on the prefix [0..t] with zero actions == step t of the reference's loop
+            with torch.no_grad():
+                oc, op = O.model_forward(P, frames[:, : t + 1], torch.zeros(B, t + 1, 7), cad, ocfg)[:2]
+            worst = max(worst, rel(op[:, -1], p0[:, t]), rel(oc[:, -1], c0[:, t]))
+        assert worst < 1e-5, worst
+        top2 = p0.topk(2, dim=-1).values
+        for name, (c, p_) in (("a0", (c0, p0)),):
+            out[f"{tag}:{name}:cmds"] = c.numpy(); out[f"{tag}:{name}:params"] = p_[:, :, :, ::8].numpy().copy()
+            out[f"{tag}:{name}:params_argmax"] = p_.argmax(-1).numpy(); out[f"{tag}:{name}:cmds_argmax"] = c.argmax(-1).numpy()
+        info[tag] = {"config": cfg_name, "B": B, "T": T, "seed": seed, "nhead": rcfg["nhead"], "oracle_prefix_runs_vs_reference": worst,
+                     "min_top2_gap_params_a0": float((top2[..., 0] - top2[..., 1]).min())}
+        print("seqinf", tag, json.dumps(info[tag]))
+    np.savez_compressed(os.path.join(HERE, "seqinf.npz"), **out)
+    return info
+
+
 NHEAD8_CASES = [("nhead8_large", "cad_past_10_actions_and_states_large", 2, 8, 21),
                 ("nhead8_multiview3", "cad_past_10_actions_and_states_large_multiview_only", 2, 6, 22)]
 
@@ -224,6 +263,15 @@ def main():
         os.chdir(scratch)
         info = multiview_case(scratch)
         meta = json.load(open(os.path.join(HERE, "meta.json"))); meta["cases"]["multiview_2"] = info
+        json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+    if "--only-seqinf" in sys.argv:                     # tests/golden/seqinf.npz alone
+        scratch = tempfile.mkdtemp(prefix="vcad_golden_")
+        shutil.copy(os.path.join(HERE, "class_weights.json"), scratch)
+        os.chdir(scratch)
+        meta = json.load(open(os.path.join(HERE, "meta.json")))
+        meta["seqinf"] = seqinf_cases(scratch)
         json.dump(meta, open(os.path.join(HERE, "meta.json"), "w"), indent=1)
         shutil.rmtree(scratch, ignore_errors=True)
         return
@@ -447,6 +495,7 @@ def main():
     meta["cases"]["multiview_2"] = multiview_case(scratch)
     for case, cfg_name, B, T, seed in NHEAD8_CASES:
         meta["cases"][case] = config_step_case(case, cfg_name, B, T, seed, scratch)
+    meta["seqinf"] = seqinf_cases(scratch)
 
     # ------------------------------------------------------------------ loss-only cases on synthetic logits
     tr = mk(True); trn = mk(False)

@@ -158,35 +158,39 @@ def test_engine_fp8_forward_mode(emu):
     assert torch.equal(p2, p_bf) and torch.equal(c2, c_bf)
 
 
-def engine_masks(eng, cfg, B, T):
-    """Rebuild every dropout keep-multiplier tensor the engine uses (vcad_dropout_mask) in the oracle's tensor shapes.
-    The last ViT layer computes the cls row only, so its site masks are indexed per frame: cls rows get them, the unused
-    rows get 1."""
-    M, P1, D, Hh = B * T, 50, cfg["vit_dim"], cfg["vit_heads"]
+def engine_masks(eng, cfg, B, T, clip0=0, nclips=None):
+    """Rebuild every dropout keep-multiplier tensor the engine uses (vcad_dropout_mask) in the oracle's tensor shapes — for clips clip0 .. clip0 + nclips - 1 of
+    a B-clip batch (default: all of them; r06: two clips of a benchmark-sized batch).  Every site is indexed clip-major (frame-major in the towers), so a clip
+    range is a contiguous range of each site's index space.  The last ViT layer computes the cls row only, so its site masks are indexed per frame: cls rows
+    get them, the unused rows get 1."""
+    nc = B - clip0 if nclips is None else nclips
+    P1, D, Hh = 50, cfg["vit_dim"], cfg["vit_heads"]
     masks = {}
-    for v, (pre, N) in enumerate((("state_embedding_model.", M), ("cad_embedding_model.", B))):
+    for v, (pre, n0, N) in enumerate((("state_embedding_model.", clip0 * T, nc * T), ("cad_embedding_model.", clip0, nc))):
         mod = v + 1
-        masks[pre + "emb"] = eng.dropout_mask(mod, 0, 1, N * P1 * D).reshape(N, P1, D)
+        dm = lambda layer, kind, per: eng.dropout_mask(mod, layer, kind, N * per, first=n0 * per)
+        masks[pre + "emb"] = dm(0, 1, P1 * D).reshape(N, P1, D)
         for L in range(cfg["vit_depth"]):
             last = L == cfg["vit_depth"] - 1
             if not last:
-                masks[f"{pre}L{L}.attn"] = eng.dropout_mask(mod, L, 2, N * Hh * P1 * P1).reshape(N, Hh, P1, P1)
+                masks[f"{pre}L{L}.attn"] = dm(L, 2, Hh * P1 * P1).reshape(N, Hh, P1, P1)
                 for kind, name in ((3, "out"), (4, "mlp_act"), (5, "mlp_out")):
-                    masks[f"{pre}L{L}.{name}"] = eng.dropout_mask(mod, L, kind, N * P1 * D).reshape(N, P1, D)
+                    masks[f"{pre}L{L}.{name}"] = dm(L, kind, P1 * D).reshape(N, P1, D)
             else:
-                a = torch.ones(N, Hh, P1, P1); a[:, :, 0, :] = eng.dropout_mask(mod, L, 2, N * Hh * P1).reshape(N, Hh, P1)
+                a = torch.ones(N, Hh, P1, P1); a[:, :, 0, :] = dm(L, 2, Hh * P1).reshape(N, Hh, P1)
                 masks[f"{pre}L{L}.attn"] = a
                 for kind, name in ((3, "out"), (4, "mlp_act"), (5, "mlp_out")):
-                    t = torch.ones(N, P1, D); t[:, 0, :] = eng.dropout_mask(mod, L, kind, N * D).reshape(N, D)
+                    t = torch.ones(N, P1, D); t[:, 0, :] = dm(L, kind, D).reshape(N, D)
                     masks[f"{pre}L{L}.{name}"] = t
-    H, nh = cfg["hidden_size"], cfg["nhead"]
+    H, nh, ff = cfg["hidden_size"], cfg["nhead"], cfg["dim_feedforward"]
+    dd = lambda layer, kind, per: eng.dropout_mask(3, layer, kind, nc * per, first=clip0 * per)
     for L in range(cfg["num_decoder_layers"]):
-        masks[f"dec{L}.sa"] = eng.dropout_mask(3, L, 6, B * nh * T * T).reshape(B, nh, T, T)
-        masks[f"dec{L}.sa_out"] = eng.dropout_mask(3, L, 7, M * H).reshape(B, T, H)
-        masks[f"dec{L}.ca"] = eng.dropout_mask(3, L, 8, B * nh * T * T).reshape(B, nh, T, T)
-        masks[f"dec{L}.ca_out"] = eng.dropout_mask(3, L, 9, M * H).reshape(B, T, H)
-        masks[f"dec{L}.ff_act"] = eng.dropout_mask(3, L, 10, M * cfg["dim_feedforward"]).reshape(B, T, cfg["dim_feedforward"])
-        masks[f"dec{L}.ff_out"] = eng.dropout_mask(3, L, 11, M * H).reshape(B, T, H)
+        masks[f"dec{L}.sa"] = dd(L, 6, nh * T * T).reshape(nc, nh, T, T)
+        masks[f"dec{L}.sa_out"] = dd(L, 7, T * H).reshape(nc, T, H)
+        masks[f"dec{L}.ca"] = dd(L, 8, nh * T * T).reshape(nc, nh, T, T)
+        masks[f"dec{L}.ca_out"] = dd(L, 9, T * H).reshape(nc, T, H)
+        masks[f"dec{L}.ff_act"] = dd(L, 10, T * ff).reshape(nc, T, ff)
+        masks[f"dec{L}.ff_out"] = dd(L, 11, T * H).reshape(nc, T, H)
     return masks
 
 

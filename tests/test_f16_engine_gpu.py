@@ -167,3 +167,10 @@ def test_f16_overflow_drill_in_the_trainer(tmp_path):
         hist = U.f16_overflow_drill(tr, synth.make_batch_torch(B, T, 5, "cpu"), inject_at=5, window=4, grow_after=24, max_steps=80)
         print(f"\n[f16 overflow drill B={B} T={T}] scale by step: " + " ".join(f"{int(s)}" + ("" if ok else "*") for _, s, ok in hist))
         assert hist[0][1] == auto and min(h[1] for h in hist) == auto / 2 and hist[-1][1] == auto
+
+
+@pytest.mark.parametrize("name,B,T", [("C2", 32, 64), ("C4_per_gpu", 16, 186)])
+def test_full_size_train_mode_matches_oracle_on_clip_pairs_f16(name, B, T):
+    """the package's default dtype in the mode bench.py times (dropout 0.1), at the benchmark's shapes, against the oracle with the engine's own masks of the
+    first and the last clip pair (tests/test_fullsize_gpu.py: train_mode_pairs_check): north_star's 1e-3 on logits, 2e-3 on the probed gradient norms"""
+    FS.train_mode_pairs_check(name, B, T, L.VCAD_F16, 1e-3, 2e-3, builder=build)

@@ -133,6 +133,66 @@ def test_full_size_step_bf16_close_and_train_mode_sane(name, B, T):
     assert not torch.equal(eng.view("embed_state.weight"), w0)
 
 
+def _engine_masks(eng, B, T, clip0, nclips):
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("engine_emu_helpers", os.path.join(os.path.dirname(__file__), "test_engine_emu.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod.engine_masks(eng, O.CANONICAL_CONFIG, B, T, clip0, nclips)
+
+
+def train_mode_pairs_check(name, B, T, dtype, tol_logit, tol_grad, builder=None):
+    """The mode bench.py times — model.train(), dropout 0.1 at every site (reference trainer.py:339,386) — at the benchmark's shape, against the oracle with the
+    SAME masks.  B distinct clips go through one full-size train-mode forward; for the first and the last clip pair the engine's masks of
+    exactly those clips are exported (a clip range is a contiguous index range of every site) and the oracle runs the pair with them as explicit multipliers:
+    logits must agree.  Backward: the oracle's d loss / d logits of the pair, zeros for every other clip, are handed to the full-size backward — every kernel
+    runs at full grid size, all other clips contribute exact zeros — and the probed parameter gradients must be the oracle's."""
+    eng = (builder or build)(dtype)
+    eng.set_dropout(0.1, seed=123)
+    batch = synth.make_batch(B, T, seed=700 + T)
+    frames, actions, cad = (torch.from_numpy(batch[k]).to(DEV) for k in ("frames", "actions", "cad_image"))
+    an = O.normalize_actions(actions[:, :-1])
+    cmds, pars = eng.forward(frames[:, :-1], an, cad)
+    weights = {k: eng.view(k).cpu().numpy() for k in eng.table}
+    worst_logit, worst_grad = 0.0, 0.0
+    for clip0 in (0, B - 2):
+        sub = {k: (v[clip0:clip0 + 2] if v is not None else None) for k, v in batch.items()}
+        ot = O.OracleTrainer(weights)
+        ot.masks = _engine_masks(eng, B, T, clip0, 2)
+        oc, op, tgt = ot.forward(sub)
+        oc.retain_grad(); op.retain_grad()
+        loss, _ = O.compute_loss(oc, op, tgt, True)
+        loss.backward()
+        rc, rp = U.relerr(cmds[clip0:clip0 + 2], oc.detach()), U.relerr(pars[clip0:clip0 + 2], op.detach())
+        worst_logit = max(worst_logit, rc, rp)
+        assert rp < tol_logit and rc < tol_logit * 2.5, (name, clip0, rc, rp)
+        agree = float((pars[clip0:clip0 + 2].argmax(-1).cpu() == op.detach().argmax(-1)).float().mean())
+        # (random-init logits: top-1 / top-2 gaps go down to 4e-4 of the logit scale, SURVEY §6 — the 16-bit modes flip a few near-ties: measured 765 of 768 in f16)
+        assert agree == 1.0 if dtype == L.VCAD_F32 else agree > (0.99 if dtype == L.VCAD_F16 else 0.985), (name, clip0, agree)
+        dc = torch.zeros_like(cmds); dp = torch.zeros_like(pars)
+        dc[clip0:clip0 + 2] = oc.grad.to(DEV); dp[clip0:clip0 + 2] = op.grad.to(DEV)
+        eng.backward(dc, dp)
+        for n in GRAD_PROBES:
+            want = float(ot.P[n].grad.double().norm())
+            got = float(eng.view(n, eng.grads).double().norm())
+            worst_grad = max(worst_grad, abs(got - want) / want)
+            assert abs(got - want) <= tol_grad * want + 1e-12, (name, clip0, n, got, want)
+        # one full tensor, element for element: the frame tower's last to_qkv.weight (class-token attention path, r06) and a decoder matrix
+        for n, tol_e in (("state_embedding_model.transformer.layers.5.0.to_qkv.weight", 10 * tol_grad), ("transformer_decoder.layers.0.self_attn.in_proj_weight", 10 * tol_grad)):
+            assert U.relerr(eng.view(n, eng.grads), ot.P[n].grad) < tol_e, (name, clip0, n, U.relerr(eng.view(n, eng.grads), ot.P[n].grad))
+    record(name + "_train_mode_pairs_dtype%d" % dtype, worst_logit_rel=worst_logit, worst_probed_grad_norm_rel=worst_grad)
+
+
+@pytest.mark.parametrize("name,B,T", [("C2", 32, 64), ("C4_per_gpu", 16, 186)])
+def test_full_size_train_mode_matches_oracle_on_clip_pairs_f32(name, B, T):
+    train_mode_pairs_check(name, B, T, L.VCAD_F32, 1e-4, 2e-3)
+
+
+@pytest.mark.parametrize("name,B,T", [("C2", 32, 64), ("C4_per_gpu", 16, 186)])
+def test_full_size_train_mode_matches_oracle_on_clip_pairs_bf16(name, B, T):
+    """the headline dtype (BASELINE's): gated at ~2x what it measures (gpurun_out/fullsize_measured.jsonl)"""
+    train_mode_pairs_check(name, B, T, L.VCAD_BF16, 6e-3, 3e-3)      # measured 3.6e-3 .. 3.8e-3 on logits, 1.4e-3 on the probed gradient norms
+
+
 def test_full_size_fp8_forward_mode_c5_per_gpu_shape():
     """BASELINE configs[4]'s per-GPU shape (16 clips x 186 steps) in the VCAD_FP8 forward mode (ViT Linears on the MXFP8 matrix cores):
     logits against the fp32 oracle at fp8 accuracy (reported), repetitions bit-identical, the bf16 backward on top, one train-mode step."""

@@ -163,3 +163,22 @@ def test_oracle_nhead8_configs_match_reference_goldens(case):
     for k in g.files:
         if k.startswith("pslice:"):
             assert np.abs(sl(ot.P[k[len("pslice:"):]]) - g[k]).max() < 1e-6, k
+
+
+@pytest.mark.parametrize("tag", ["canon", "nhead8_large"])
+def test_oracle_prefix_runs_match_the_reference_sequential_inference(tag):
+    """r06: the imported reference's own `sequential_inference(action=False)` (model/autoregressive_transformer.py:222-275; fixture tests/golden/seqinf.npz):
+    step t of its loop == the last row of the oracle's forward on the prefix [0..t] with zero actions — the statement the GPU tests of f1 build on."""
+    meta = json.load(open(os.path.join(GOLD, "meta.json")))["seqinf"][tag]
+    g = np.load(os.path.join(GOLD, "seqinf.npz"))
+    cfg = dict(O.CANONICAL_CONFIG); cfg.update(nhead=meta["nhead"])
+    P = {k: torch.from_numpy(synth.make_param(k, s)) for k, s in O.param_shapes(cfg).items()}
+    B, T = meta["B"], meta["T"]
+    b = synth.make_batch(B, T - 1, seed=meta["seed"])
+    frames, cad = torch.from_numpy(b["frames"]), torch.from_numpy(b["cad_image"])
+    gp, gc = torch.from_numpy(g[f"{tag}:a0:params"]), torch.from_numpy(g[f"{tag}:a0:cmds"])
+    for t in (0, 3, T - 1):                           # (three prefixes: every prefix is 36 frame encodes on the host)
+        with torch.no_grad():
+            oc, op = O.model_forward(P, frames[:, : t + 1], torch.zeros(B, t + 1, 7), cad, cfg)[:2]
+        assert float((op[:, -1, :, ::8] - gp[:, t]).norm() / gp[:, t].norm()) < 5e-6 and float((oc[:, -1] - gc[:, t]).norm() / gc[:, t].norm()) < 5e-6, t
+        assert np.array_equal(op[:, -1].argmax(-1).numpy(), g[f"{tag}:a0:params_argmax"][:, t])

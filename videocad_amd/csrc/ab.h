@@ -21,6 +21,8 @@ struct VcAb {
     int res_in_ln;     // 16-bit ViT layers: 1 = residual add inside the LayerNorm pass behind to_out / net.4 (r05), 0 = in the GEMM epilogue (r04)
     int cls_path;      // 16-bit engines, last ViT layer: 1 = class-token attention on (q W_k, normalised tokens) (r06, attn_cls.h), 0 = K / V projections of all tokens (r05)
     int frame_first;   // whole backward with the side stream forked: 1 = frame tower's upper stage enqueued before the CAD tower's stage (r06), 0 = after (r05)
+    int pe_fold;       // 16-bit engines: 1 = patch-embedding LayerNorm affine folded into its Linear (r06), 0 = applied to the patches, dgrad + LayerNorm backward for its gradients (r05)
+    int dec_h16;       // 16-bit engines: 1 = decoder LayerNorms also emit 16-bit copies for the Linears / deferred weight gradients behind them (r06), 0 = those read the fp32 stream (r05)
     unsigned gemm_flags;   // OR-ed into every GemmCall::flags
 };
 extern VcAb g_ab;

@@ -53,13 +53,20 @@ struct VitLayerActs { float* stat_a; void* h_a; void* qkv; float* lse; void* ao;
                       // r05: per-layer homes of the backward's small reductions' partial rows — the two LayerNorm backwards' [blocks][dgamma | dbeta | bias gradient]
                       // and the activation-derivative pass's [blocks][b1 gradient] — so their column sums can be deferred (vcad_engine::VitColsums)
                       float *part_fn, *part_an, *part_b1; };
-struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e; };
+struct VitActs { long N; void* pn; float* pstat; float* pe; float* stat2; float* x0; std::vector<VitLayerActs> L; float* statn; void* e;
+                 // r06, 16-bit engines: the patch embedding's LayerNorm(1024) affine is folded into its Linear (norm.h pe_fold_kernel): pn holds the normalised patches
+                 // WITHOUT gamma / beta, pe_wf = 16-bit(W diag(gamma)), pe_bf = b + W beta (refreshed after every weight change), t_dwf = the folded Linear's weight
+                 // gradient, from which one small kernel takes dW, dgamma and dbeta — no dgrad to the patches, no LayerNorm backward pass over them
+                 bool pe_fold = false; void* pe_wf = nullptr; float* pe_bf = nullptr; float* t_dwf = nullptr; };
 struct DecLayerActs { void* qkv_s; float* lse_s; void* ao_s; float* s1; float* st1; float* x1; void* q_c; void* kv_c; float* lse_c; void* ao_c;
                       float* s2; float* st2; float* x2; void* f1; float* s3; float* st3; float* x3;
                       // per-layer homes of the backward's dY tensors, so the layer's 7 weight gradients can be deferred (see Deferred)
                       void *g_du_ff, *g_df1, *g_du_ca, *g_dq, *g_dkv, *g_du_sa, *g_dqkv;
                       // ... and of the three LayerNorm backwards' dgamma / dbeta partial rows ([vc_ln_bwd_blocks(M)][2][H]), reduced by the same grouped column sum
-                      float* ln_part[3]; };
+                      float* ln_part[3];
+                      // r06: 16-bit copies of the three post-norm outputs (second output of the LayerNorm pass): the Linears that consume them round to 16 bits
+                      // while staging anyway — same values — and the deferred weight gradients read 2 instead of 4 bytes per element
+                      void *x1h, *x2h, *x3h; };
 
 }  // namespace
 
@@ -86,6 +93,7 @@ struct vcad_engine {
     int in_u8 = 0;                // frames / cad are uint8 grayscale pixels, normalised inside the patchify kernels (vcad_forward_u8)
     VitActs va[2]; std::vector<DecLayerActs> da;
     float *ui, *cadterm, *mem, *act; void* cadE;
+    void *tgt0h = nullptr, *memh = nullptr; bool dec_h16 = false;     // r06: 16-bit copies of the decoder's input and of the memory (DecLayerActs::x1h ..)
     float *xfinal;                // = da.back().x3
     // backward temporaries
     float *t_dmem, *t_dcur, *t_dui, *t_dcadterm, *t_dcadE, *t_dec, *t_des, *t_dpre;
@@ -107,6 +115,10 @@ struct vcad_engine {
     // (ds_read_b128) GEMM instead of a ds_read_b64_tr_b16 one (measured: dqkv dgrad 569 -> 462 us); refreshed lazily after
     // every weight change (optimizer step / shadow sync / re-plan)
     vc_bf16* wT = nullptr; bool wT_fresh = false; std::vector<TransposeJob> wT_jobs;
+    // r06: the frame tower's backward is two stages (DDP buckets); the upper one's last LayerNorm backward also emits the masked gradient the lower one's first
+    // Linear consumes (and its bias gradient), as every layer boundary inside a stage does — the stage boundary used to cost a dropout pass + a column sum
+    bool du_carry = false; Mat du_carry_mat{nullptr, 0, 0};
+    bool pe_fresh[2] = {false, false};       // folded patch-embedding weights (VitActs::pe_wf / pe_bf) match the parameters
     // VCAD_FP8 forward mode (vcad_set_fp8): the four Linears of every full ViT layer run on the block-scaled fp8 matrix cores (gemm_mx8.h):
     // weights quantised from the fp32 master once per optimiser step (q8w / q8ws mirror the flat parameter layout: byte i <-> parameter i,
     // scale byte i/32), activations quantised into the lane's q8a / q8as right before each GEMM.  Backward is the bf16 path, unchanged.
@@ -238,6 +250,8 @@ void build_params(vcad_engine* e) {
 }
 
 #define g_frame_first VC_AB(frame_first, 1)   // A/B: 0 = r05's enqueue order of the whole backward (CAD tower's stage before the frame tower's)
+#define g_dec_h16 VC_AB(dec_h16, 1)           // A/B: 0 = r05's decoder (in-proj / q-proj / linear1 / heads and the deferred weight gradients read the fp32 residual stream)
+#define g_pe_fold VC_AB(pe_fold, 1)           // A/B: 0 = r05's patch embedding (LayerNorm affine applied to the patches; dgrad + LayerNorm backward for its parameter gradients)
 #define g_cls_path VC_AB(cls_path, 1)         // A/B: 0 = r05's last ViT layer (K / V projections of all tokens + single-query attention kernels)
 // ---------------------------------------------------------------------------------------------------------------
 // workspace plan
@@ -259,6 +273,8 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         const long R = a.N * (P + 1), Rp = a.N * P;
         a.pn = b.take<void>(Rp * pd * es); a.pstat = b.take<float>(Rp * 2 * 4); a.pe = b.take<float>(Rp * D * 4);
         a.stat2 = b.take<float>(Rp * 2 * 4); a.x0 = b.take<float>(R * D * 4);
+        a.pe_fold = e->dt == VC_BF16 && e->ct == VC_BF16 && g_pe_fold; e->pe_fresh[v] = false;
+        if (a.pe_fold) { a.pe_wf = b.take<void>((size_t)D * pd * es); a.pe_bf = b.take<float>((size_t)D * 4); a.t_dwf = b.take<float>((size_t)D * pd * 4); }
         a.L.resize(c.vit_depth);
         for (auto& l : a.L) {
             l.stat_a = b.take<float>(R * 2 * 4); l.h_a = b.take<void>(R * D * es); l.qkv = b.take<void>(R * 3 * inner * es);
@@ -307,10 +323,13 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
         d.g_du_ff = b.take<void>(M * H * es); d.g_df1 = b.take<void>(M * c.dim_feedforward * es); d.g_du_ca = b.take<void>(M * H * es);
         d.g_dq = b.take<void>(M * H * es); d.g_dkv = b.take<void>(M * 2 * H * es); d.g_du_sa = b.take<void>(M * H * es); d.g_dqkv = b.take<void>(M * 3 * H * es);
         for (int i = 0; i < 3; ++i) d.ln_part[i] = b.take<float>((size_t)vc_ln_bwd_blocks(M) * 2 * H * 4);
+        d.x1h = b.take<void>(M * H * es); d.x2h = b.take<void>(M * H * es); d.x3h = b.take<void>(M * H * es);
     }
+    e->dec_h16 = e->dt == VC_BF16 && e->ct == VC_BF16 && g_dec_h16;
+    e->tgt0h = b.take<void>(M * H * es); e->memh = b.take<void>(M * H * es);
     {   // deferred-wgrad descriptor tables (device) + column-sum partials
         const int nl = c.num_decoder_layers;
-        for (int g = 0; g < 2; ++g) { e->def.d_probs[g] = b.take<GemmParams>((size_t)nl * 4 * sizeof(GemmParams)); e->def.d_tiles[g] = b.take<int>((size_t)(nl * 4 + 1) * 4); }
+        for (int g = 0; g < 2; ++g) { e->def.d_probs[g] = b.take<GemmParams>((size_t)nl * 7 * sizeof(GemmParams)); e->def.d_tiles[g] = b.take<int>((size_t)(nl * 7 + 1) * 4); }
         e->def.d_cs = b.take<ColsumJob>((size_t)nl * 10 * sizeof(ColsumJob));
         e->def.cs_partial = b.take<float>((size_t)nl * (VC_CEIL_DIV(M, 128) + 1) * (7L * H + 2L * H + c.dim_feedforward + 3 * 2L * H) * 4);
         e->def.ready = false;
@@ -355,7 +374,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
     }
     if (e->grad_scale != 1.0f || e->grad_scale_auto) { e->dls_cmds = b.take<float>(M * c.num_classes * 4); e->dls_pars = b.take<float>(M * nlog * 4); }
     e->norm_part = b.take<float>(1024 * 4); e->norm_out = b.take<float>(8 * 4);
-    e->wT = nullptr; e->wT_jobs.clear(); e->wT_fresh = false;
+    e->wT = nullptr; e->wT_jobs.clear(); e->wT_fresh = false; e->pe_fresh[0] = e->pe_fresh[1] = false;
     if (e->dt == VC_BF16 && c.enable_past_states) {
         long off = 0;
         auto job = [&](long src, int rows, int cols) { e->wT_jobs.push_back(TransposeJob{src, off, rows, cols}); const long o = off; off += (long)rows * cols; return o; };
@@ -489,8 +508,8 @@ struct Ctx {
     int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
                const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C,
                vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr, float* defer_partial = nullptr,
-               bool du_pk = false) const {
-        LnBwdParams p; memset(&p, 0, sizeof(p));
+               bool du_pk = false, vc_drop d32 = vc_drop{0u, 0u, 1.0f}) const {
+        LnBwdParams p; memset(&p, 0, sizeof(p)); p.drop32 = d32;
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
         if (du) {
@@ -577,9 +596,14 @@ int vit_forward(const Ctx& cx, int v, const void* img, long img_T, long img_bstr
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = img; p.gamma = cx.Pf(w.ln1w); p.beta = cx.Pf(w.ln1b); p.yt = a.pn; p.ldyt = pd; p.stats = a.pstat; p.rows = Rp; p.eps = 1e-5f;
         p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.ldx = img_bstride; p.u8 = v == 1 && e->in_u8 ? 1 : e->in_u8;     // (the CAD image is always one gray plane)
+        if (a.pe_fold) {                                          // gamma / beta live in the folded Linear (VitActs): the patches are stored normalised only
+            p.gamma = p.beta = nullptr;
+            if (!e->pe_fresh[v]) { CK(vc_pe_fold(cx.Pf(w.pew), cx.Pf(w.peb), cx.Pf(w.ln1w), cx.Pf(w.ln1b), a.pe_wf, a.pe_bf, D, pd, cx.s)); e->pe_fresh[v] = true; }
+        }
         CK(vc_ln_fwd(VC_F32, e->dt, pd, 1, p, cx.s));
     }
-    { Epi ep; ep.bias = cx.Pf(w.peb); CK(cx.lin_fwd(cx.AT(a.pn, pd), cx.W(w.pew, pd), cx.A32(a.pe, D), (int)Rp, D, pd, ep)); }
+    if (a.pe_fold) { Epi ep; ep.bias = a.pe_bf; CK(cx.lin_fwd(cx.AT(a.pn, pd), cx.AT(a.pe_wf, pd), cx.A32(a.pe, D), (int)Rp, D, pd, ep)); }
+    else { Epi ep; ep.bias = cx.Pf(w.peb); CK(cx.lin_fwd(cx.AT(a.pn, pd), cx.W(w.pew, pd), cx.A32(a.pe, D), (int)Rp, D, pd, ep)); }
     {   // LN(512) + cls + pos  -> x0
         LnFwdParams p; memset(&p, 0, sizeof(p));
         p.x = a.pe; p.ldx = D; p.gamma = cx.Pf(w.ln2w); p.beta = cx.Pf(w.ln2b); p.y32 = a.x0; p.ldy32 = D; p.stats = a.stat2;
@@ -696,7 +720,7 @@ int build_vit_colsums(const Ctx& cx, int v, int part) {
         if (e->dt == VC_BF16 && g_split_gelu && !cls_only) add(l.part_b1, c.vit_mlp, vc_dact_bwd_blocks(Rm, c.vit_mlp), c.vit_mlp, cx.Gf(wl.b1));
         add(l.part_fn, 3L * D, vc_ln_bwd_blocks(Rm), 2 * D, cx.Gf(wl.fnw));
         add(l.part_fn + 2 * D, 3L * D, vc_ln_bwd_blocks(Rm), D, cx.Gf(wl.ob));
-        if (L > Llo) {
+        if (L > Llo || (part == 1 && L > 0)) {              // (part 1's lowest layer hands its masked gradient to part 2: vcad_engine::du_carry)
             add(l.part_an, 3L * D, vc_ln_bwd_blocks(R), 2 * D, cx.Gf(wl.anw));
             add(l.part_an + 2 * D, 3L * D, vc_ln_bwd_blocks(R), D, cx.Gf(w.l[L - 1].b4));
         } else add(l.part_an, 2L * D, vc_ln_bwd_blocks(R), 2 * D, cx.Gf(wl.anw));
@@ -725,6 +749,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
     int Lhi = c.vit_depth - 1, Llo = 0;
     if (part == 1) Llo = split; if (part == 2) Lhi = split - 1;
     const bool defer_cs = true;                                                // the layers' small column sums: one grouped launch at the end (VitColsums)
+    // r06: emb_dropout's backward mask applied by layer 0's norm backward — when THIS call both walks layer 0 and runs the embedding's backward
+    const bool emb_in_ln = e->dt == VC_BF16 && e->ct == VC_BF16 && part != 1 && Llo == 0 && Lhi >= 0;
     if (defer_cs && !e->vcs[v][part].ready) CK(build_vit_colsums(cx, v, part));
     if (part != 2) {
         CK(vc_memset_async(dx, 0, (size_t)R * D * 4, cx.s));
@@ -733,6 +759,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
     }
     const long TD = (long)(P + 1) * D, TI = (long)(P + 1) * inner;
     Mat du{nullptr, VC_F32, 0}; bool have_du = false;          // masked gradient entering the current Linear (and whether the previous LayerNorm backward already produced it)
+    if (v == 0 && part == 2 && e->du_carry) { du = e->du_carry_mat; have_du = true; }      // ... by the upper stage's last one
+    if (v == 0) e->du_carry = false;
     for (int L = Lhi; L >= Llo; --L) {
         const VitW::L& wl = w.l[L]; VitLayerActs& l = a.L[L];
         const float* xin = L == 0 ? a.x0 : a.L[L - 1].xo;
@@ -801,13 +829,18 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         else CK(cx.lin_dgrad(cx.VT(cx.L().t_dqkv, 3 * inner, pk), cx.W(wl.qkv, D), cx.AT(cx.L().t_dh, D), (int)R, 3 * inner, D, Epi()));
         }
         // (the layer below is never the cls-only one: the du it receives is pre-split whenever the mode stores pre-split tensors)
-        if (L > Llo) { CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), defer_cs ? l.part_an : nullptr, cx.pk_acts())); have_du = true; }
-        else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, vc_drop{0u, 0u, 1.0f}, nullptr, nullptr, nullptr, defer_cs ? l.part_an : nullptr));
+        if (L > Llo || (part == 1 && L > 0)) {
+            CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), defer_cs ? l.part_an : nullptr, cx.pk_acts())); have_du = true;
+            if (L == Llo && v == 0) { e->du_carry = true; e->du_carry_mat = du; }        // stage boundary: the lower stage (vit_backward part 2, next call) starts from this du
+        }
+        // bottom layer: the embedding dropout (everything below sees dx * mask) rides on this pass's fp32 output (16-bit engines; norm.h LnBwdParams::drop32)
+        else CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, vc_drop{0u, 0u, 1.0f}, nullptr, nullptr, nullptr, defer_cs ? l.part_an : nullptr, false,
+                          emb_in_ln ? cx.site(v + 1, 0, Ctx::K_EMB) : vc_drop{0u, 0u, 1.0f}));
     }
     if (defer_cs) { const vcad_engine::VitColsums& vc = e->vcs[v][part]; CK(vc_colsum_grouped(vc.d_jobs, (int)vc.jobs.size(), vc.strips, vc.chunks, vc.partial, cx.s)); }
     if (part != 1) {
         { const vc_drop d = cx.site(v + 1, 0, Ctx::K_EMB);      // emb_dropout: everything below sees dx * mask
-          if (d.key) CK(vc_dropout_mul(VC_F32, dx, D, dx, D, R, D, d, cx.s)); }
+          if (d.key && !emb_in_ln) CK(vc_dropout_mul(VC_F32, dx, D, dx, D, R, D, d, cx.s)); }
         // pos / cls gradients: column sums over frames of dx viewed as [N, (P+1)*D]
         CK(cx.colsum(cx.A32(dx, (long)(P + 1) * D), N, (P + 1) * D, cx.Gf(w.pos), 0));
         CK(vc_memcpy_d2d_async(cx.Gf(w.cls), cx.Gf(w.pos), (size_t)D * 4, cx.s));
@@ -821,6 +854,11 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             CK(vc_ln_bwd(VC_F32, VC_F32, e->dt == VC_BF16 ? VC_BF16 : VC_F32, D, 2, p, cx.L().scr_lnpart, cx.Gf(w.ln2w), cx.Gf(w.ln2b), cx.L().scr_colsum, cx.s));
         }
         const Mat dpe = e->dt == VC_BF16 ? cx.AT(cx.L().t_dpe, D) : cx.A32(cx.L().t_dpe, D);
+        if (a.pe_fold) {     // folded LayerNorm affine: dWf = dpe^T (normalised patches) carries dW, dgamma and dbeta (norm.h pe_fold_bwd_kernel); the frames take no gradient
+            CK(cx.lin_wgrad(dpe, cx.AT(a.pn, pd), a.t_dwf, pd, cx.Gf(w.peb), (int)Rp, D, pd));
+            if (w.ln1b != w.ln1w + pd) { vc_set_error("internal: patch-embedding LayerNorm weight / bias not adjacent"); return VC_ERR_ARG; }
+            CK(vc_pe_fold_bwd(a.t_dwf, cx.Gf(w.peb), cx.Pf(w.pew), cx.Pf(w.ln1w), cx.Pf(w.ln1b), cx.Gf(w.pew), cx.Gf(w.ln1w), D, pd, cx.L().scr_lnpart, cx.L().scr_colsum, cx.s));
+        } else {
         CK(cx.lin_wgrad(dpe, cx.AT(a.pn, pd), cx.Gf(w.pew), pd, cx.Gf(w.peb), (int)Rp, D, pd));
         CK(cx.lin_dgrad(dpe, cx.W(w.pew, pd), cx.AT(cx.L().t_dpn, pd), (int)Rp, D, pd, Epi()));
         {   // LN(1024) parameter gradients (input frames need no gradient)
@@ -828,6 +866,7 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
             p.dy = cx.L().t_dpn; p.lddy = pd; p.x = img; p.ldx = img_bstride; p.stats = a.pstat; p.gamma = cx.Pf(w.ln1w); p.rows = Rp;
             p.img = c.image_size; p.patch = c.patch_size; p.P = (int)img_T; p.u8 = v == 1 && e->in_u8 ? 1 : e->in_u8;
             CK(vc_ln_bwd(e->dt, VC_F32, e->dt, pd, 1, p, cx.L().scr_lnpart, cx.Gf(w.ln1w), cx.Gf(w.ln1b), cx.L().scr_colsum, cx.s));
+        }
         }
     }
     return 0;
@@ -924,10 +963,14 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     } else {
         CK(vc_bcast_tanh(e->dt, e->cadE, e->mem, M, H, T, s));
     }
-    if (pa) CK(vc_embed_action(VC_F32, e->in_actions, cx.Pf(e->o_ea_w), cx.Pf(e->o_ea_b), ts, e->act, nullptr, M, H, c.act_dim, T, s));
+    const bool h16 = e->dec_h16;
+    if (pa) CK(vc_embed_action(h16 ? e->dt : VC_F32, e->in_actions, cx.Pf(e->o_ea_w), cx.Pf(e->o_ea_b), ts, e->act, h16 ? e->tgt0h : nullptr, M, H, c.act_dim, T, s));
     const float* tgt = pa ? e->act : (ps ? e->ui : e->mem);
+    if (h16 && !pa) CK(vc_cast(e->dt, tgt, e->tgt0h, M * H, s));
+    if (h16) CK(vc_cast(e->dt, e->mem, e->memh, M * H, s));
     const int sa_window = pa ? T : c.window_size;
     const float* x = tgt;
+    const void* xh = e->tgt0h;                                 // 16-bit copy of x (h16)
     // every layer's cross-attention K / V projection of the memory in one grouped launch (bf16 mode; the other modes keep the per-layer launches)
     const bool kv_batched = e->dt == VC_BF16 && e->ct == VC_BF16 && vc_gemm_grouped_has_forward();
     if (kv_batched) {
@@ -937,27 +980,28 @@ int engine_forward(vcad_engine* e, float* cmds_out, float* pars_out, vc_stream_t
     }
     for (int L = 0; L < c.num_decoder_layers; ++L) {
         const DecW& w = e->wd[L]; DecLayerActs& d = e->da[L];
-        { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, 3 * H), (int)M, 3 * H, H, ep)); }
+        { Epi ep; ep.bias = cx.Pf(w.sa_b); CK(cx.lin_fwd(h16 ? cx.AT(xh, H) : cx.A32(x, H), cx.W(w.sa_w, H), cx.AT(d.qkv_s, 3 * H), (int)M, 3 * H, H, ep)); }
         { const char* q = (const char*)d.qkv_s;
           CK(dec_attn(cx, false, q, 3 * H, q + (size_t)H * es, q + (size_t)2 * H * es, 3 * H, d.ao_s, d.lse_s, sa_window, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_SA))); }
         { Epi ep; ep.bias = cx.Pf(w.sa_ob); ep.residual = x; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_SA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_s, H), cx.W(w.sa_ow, H), cx.A32(d.s1, H), (int)M, H, H, ep)); }
-        CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, nullptr, 0, d.st1, M, H));
-        { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), (int)M, H, H, ep)); }
+        CK(cx.ln_fwd(VC_F32, d.s1, H, w.n1w, w.n1b, d.x1, H, h16 ? d.x1h : nullptr, H, d.st1, M, H));
+        { Epi ep; ep.bias = cx.Pf(w.ca_b); CK(cx.lin_fwd(h16 ? cx.AT(d.x1h, H) : cx.A32(d.x1, H), cx.W(w.ca_w, H), cx.AT(d.q_c, H), (int)M, H, H, ep)); }
         if (!kv_batched) { Epi ep; ep.bias = cx.Pf(w.ca_b + H); CK(cx.lin_fwd(cx.A32(e->mem, H), cx.W(w.ca_w + (long)H * H, H), cx.AT(d.kv_c, 2 * H), (int)M, 2 * H, H, ep)); }
         { const char* kv = (const char*)d.kv_c;
           CK(dec_attn(cx, false, d.q_c, H, kv, kv + (size_t)H * es, 2 * H, d.ao_c, d.lse_c, c.window_size, nullptr, nullptr, nullptr, nullptr, 0, 0, cx.site(3, L, Ctx::K_CA))); }
         { Epi ep; ep.bias = cx.Pf(w.ca_ob); ep.residual = d.x1; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_CA_OUT); CK(cx.lin_fwd(cx.AT(d.ao_c, H), cx.W(w.ca_ow, H), cx.A32(d.s2, H), (int)M, H, H, ep)); }
-        CK(cx.ln_fwd(VC_F32, d.s2, H, w.n2w, w.n2b, d.x2, H, nullptr, 0, d.st2, M, H));
-        { Epi ep; ep.bias = cx.Pf(w.b1); ep.act = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT); CK(cx.lin_fwd(cx.A32(d.x2, H), cx.W(w.w1, H), cx.AT(d.f1, c.dim_feedforward), (int)M, c.dim_feedforward, H, ep)); }
+        CK(cx.ln_fwd(VC_F32, d.s2, H, w.n2w, w.n2b, d.x2, H, h16 ? d.x2h : nullptr, H, d.st2, M, H));
+        { Epi ep; ep.bias = cx.Pf(w.b1); ep.act = VC_ACT_RELU; ep.drop = cx.site(3, L, Ctx::K_FF_ACT); CK(cx.lin_fwd(h16 ? cx.AT(d.x2h, H) : cx.A32(d.x2, H), cx.W(w.w1, H), cx.AT(d.f1, c.dim_feedforward), (int)M, c.dim_feedforward, H, ep)); }
         { Epi ep; ep.bias = cx.Pf(w.b2); ep.residual = d.x2; ep.ldr = H; ep.drop = cx.site(3, L, Ctx::K_FF_OUT);
           CK(cx.lin_fwd(cx.AT(d.f1, c.dim_feedforward), cx.W(w.w2, c.dim_feedforward), cx.A32(d.s3, H), (int)M, H, c.dim_feedforward, ep)); }
-        CK(cx.ln_fwd(VC_F32, d.s3, H, w.n3w, w.n3b, d.x3, H, nullptr, 0, d.st3, M, H));
-        x = d.x3;
+        CK(cx.ln_fwd(VC_F32, d.s3, H, w.n3w, w.n3b, d.x3, H, h16 ? d.x3h : nullptr, H, d.st3, M, H));
+        x = d.x3; xh = d.x3h;
     }
     e->xfinal = (float*)x;
     const int n5 = c.num_classes, n6 = c.num_params * c.num_params_values;
-    { Epi ep; ep.bias = cx.Pf(e->o_h5_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(e->o_h5_w, H), cx.A32(cmds_out, n5), (int)M, n5, H, ep)); }
-    { Epi ep; ep.bias = cx.Pf(e->o_h6_b); CK(cx.lin_fwd(cx.A32(x, H), cx.W(e->o_h6_w, H), cx.A32(pars_out, n6), (int)M, n6, H, ep)); }
+    const Mat xf = h16 ? cx.AT(xh, H) : cx.A32(x, H);
+    { Epi ep; ep.bias = cx.Pf(e->o_h5_b); CK(cx.lin_fwd(xf, cx.W(e->o_h5_w, H), cx.A32(cmds_out, n5), (int)M, n5, H, ep)); }
+    { Epi ep; ep.bias = cx.Pf(e->o_h6_b); CK(cx.lin_fwd(xf, cx.W(e->o_h6_w, H), cx.A32(pars_out, n6), (int)M, n6, H, ep)); }
     return 0;
 }
 
@@ -982,13 +1026,15 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
     for (int L = 0; L < c.num_decoder_layers; ++L) {
         const DecW& w = e->wd[L]; const DecLayerActs& d = e->da[L];
         const float* xin = L == 0 ? tgt0 : e->da[L - 1].x3;
+        const void* xinh = L == 0 ? e->tgt0h : e->da[L - 1].x3h;
+        const bool h16 = e->dec_h16; const int gx = h16 ? 0 : 1;             // with the 16-bit copies every problem has the all-16-bit signature: one group
         add(0, cx.AT(d.g_du_ff, H), cx.AT(d.f1, ff), w.w2, ff, w.b2, H, ff);
-        add(1, cx.AT(d.g_df1, ff), cx.A32(d.x2, H), w.w1, H, w.b1, ff, H);
+        add(gx, cx.AT(d.g_df1, ff), h16 ? cx.AT(d.x2h, H) : cx.A32(d.x2, H), w.w1, H, w.b1, ff, H);
         add(0, cx.AT(d.g_du_ca, H), cx.AT(d.ao_c, H), w.ca_ow, H, w.ca_ob, H, H);
-        add(1, cx.AT(d.g_dq, H), cx.A32(d.x1, H), w.ca_w, H, w.ca_b, H, H);
-        add(1, cx.AT(d.g_dkv, 2 * H), cx.A32(e->mem, H), w.ca_w + (long)H * H, H, w.ca_b + H, 2 * H, H);
+        add(gx, cx.AT(d.g_dq, H), h16 ? cx.AT(d.x1h, H) : cx.A32(d.x1, H), w.ca_w, H, w.ca_b, H, H);
+        add(gx, cx.AT(d.g_dkv, 2 * H), h16 ? cx.AT(e->memh, H) : cx.A32(e->mem, H), w.ca_w + (long)H * H, H, w.ca_b + H, 2 * H, H);
         add(0, cx.AT(d.g_du_sa, H), cx.AT(d.ao_s, H), w.sa_ow, H, w.sa_ob, H, H);
-        add(1, cx.AT(d.g_dqkv, 3 * H), cx.A32(xin, H), w.sa_w, H, w.sa_b, 3 * H, H);
+        add(gx, cx.AT(d.g_dqkv, 3 * H), h16 ? cx.AT(xinh, H) : cx.A32(xin, H), w.sa_w, H, w.sa_b, 3 * H, H);
         // the three LayerNorm backwards' partial rows [blocks][dgamma | dbeta]: norm{1,2,3}.weight and .bias are adjacent in the flat buffer
         const long nw[3] = {w.n1w, w.n2w, w.n3w}, nb[3] = {w.n1b, w.n2b, w.n3b};
         for (int i = 0; i < 3; ++i) {
@@ -1000,6 +1046,7 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
     }
     for (int g = 0; g < 2; ++g) {
         const int n = (int)df.calls[g].size();
+        if (n == 0) { df.total_tiles[g] = 0; df.flops[g] = 0; continue; }       // (16-bit copies of the residual stream: every problem is in group 0)
         std::vector<GemmParams> probs(n); std::vector<int> tiles(n + 1);
         CK(vc_gemm_grouped_prepare(df.calls[g].data(), n, probs.data(), tiles.data()));
         df.total_tiles[g] = tiles[n]; df.flops[g] = 0;
@@ -1086,7 +1133,7 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
         vc_stream_t gs = s;
         if (e->bwd_side) { CK(vc_event_record(e->ev_fork2, s)); CK(vc_stream_wait_event(e->side, e->ev_fork2)); gs = e->side; }
         for (int g = 0; g < 2; ++g)
-            CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], gs));
+            if (!df.calls[g].empty()) CK(vc_gemm_grouped_launch(df.calls[g][0], df.d_probs[g], df.d_tiles[g], (int)df.calls[g].size(), df.total_tiles[g], df.flops[g], gs));
         CK(vc_colsum_grouped(df.d_cs, (int)df.cs.size(), df.cs_strips, df.cs_chunks, df.cs_partial, gs));
         CK(unscale_bucket(e, 0, gs));
         return 0;
@@ -1245,7 +1292,7 @@ int vcad_bind(vcad_engine* e, float* params, float* grads, float* m, float* v, v
     if (e->dt == VC_BF16 && !shadow) { vc_set_error("vcad_bind: bf16 engine needs a shadow buffer"); return VC_ERR_ARG; }
     e->P = params; e->G = grads; e->Mm = m; e->Vv = v; e->S = e->dt == VC_BF16 ? (vc_bf16*)shadow : nullptr;
     e->Spk = e->ct == VC_X3 ? (uint32_t*)shadow : nullptr;      // optional: without it the bf16x3 GEMMs split the fp32 weights while staging
-    e->wT_fresh = false; e->q8_fresh = false; e->def.ready = false; e->kvf.ready = false;
+    e->wT_fresh = false; e->pe_fresh[0] = e->pe_fresh[1] = false; e->q8_fresh = false; e->def.ready = false; e->kvf.ready = false;
     for (int v = 0; v < 2; ++v) for (int part = 0; part < 3; ++part) e->vcs[v][part].ready = false;
     for (int v = 0; v < 2; ++v) e->cls[v].bwd_ready = false;
     return 0;
@@ -1264,7 +1311,7 @@ int vcad_sync_shadow(vcad_engine* e, void* stream) {
     if (e->Spk) return vc_pack_x3(e->P, e->Spk, e->ptotal, (vc_stream_t)stream);
     if (e->dt != VC_BF16) return 0;
     if (!e->P || !e->S) { vc_set_error("vcad_sync_shadow: not bound"); return VC_ERR_ARG; }
-    e->wT_fresh = false; e->q8_fresh = false;
+    e->wT_fresh = false; e->pe_fresh[0] = e->pe_fresh[1] = false; e->q8_fresh = false;
     return vc_cast(VC_BF16, e->P, e->S, e->ptotal, (vc_stream_t)stream);
 }
 size_t vcad_workspace_bytes(const vcad_engine* e, int B, int T) {
@@ -1305,6 +1352,15 @@ int vcad_dropout_mask(const vcad_engine* e, int module, int layer, int kind, int
     Ctx cx{const_cast<vcad_engine*>(e), nullptr};
     const vc_drop d = cx.site(module, layer, kind);
     for (int64_t i = 0; i < n; ++i) host_out[i] = d.key ? vc_drop_mul(d, (uint32_t)i) : 1.0f;
+    return 0;
+}
+
+// ... elements first .. first + n - 1 of the site's index space (r06: the masks of a few clips of a benchmark-sized batch without materialising 50 M floats per site)
+int vcad_dropout_mask_range(const vcad_engine* e, int module, int layer, int kind, int64_t first, int64_t n, float* host_out) {
+    if (first < 0 || n < 0 || first + n > 4294967296LL) { vc_set_error("vcad_dropout_mask_range: [%lld, +%lld) outside the 32-bit index space", (long long)first, (long long)n); return VC_ERR_ARG; }
+    Ctx cx{const_cast<vcad_engine*>(e), nullptr};
+    const vc_drop d = cx.site(module, layer, kind);
+    for (int64_t i = 0; i < n; ++i) host_out[i] = d.key ? vc_drop_mul(d, (uint32_t)(first + i)) : 1.0f;
     return 0;
 }
 
@@ -1653,7 +1709,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
         CK(vc_adam(a, s));
         b0 = b1i + 1;
     }
-    e->wT_fresh = false;                  // the bf16 shadow just changed: its transposed copies are rebuilt before the next backward
+    e->wT_fresh = false; e->pe_fresh[0] = e->pe_fresh[1] = false;                  // the bf16 shadow just changed: its transposed copies are rebuilt before the next backward
     e->q8_fresh = false;                  // ... and the fp8 copies before the next forward
     if (norm_out) CK(vc_memcpy_d2d_async(norm_out, e->norm_out, 2 * 4, s));
     return 0;

@@ -155,10 +155,15 @@ VC_KERNEL __launch_bounds__(256) void ln_fwd_kernel(LnFwdParams p) {
     }
     float mean, rstd;
     row_stats<VPL>(v, p.eps, mean, rstd);
-    float g[VPL], b[VPL];
-    row_load<float, VPL>(p.gamma, g, lane); row_load<float, VPL>(p.beta, b, lane);
+    if (p.gamma) {
+        float g[VPL], b[VPL];
+        row_load<float, VPL>(p.gamma, g, lane); row_load<float, VPL>(p.beta, b, lane);
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * g[i] + b[i];
+        for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd * g[i] + b[i];
+    } else {                                            // no affine: the caller folded gamma / beta into the Linear behind this norm (pe_fold_kernel)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) v[i] = (v[i] - mean) * rstd;
+    }
     if constexpr (MODE == 2) {
         float q[VPL];
         row_load<float, VPL>(p.pos + (long)(row % (p.P + 1)) * C, q, lane);
@@ -188,6 +193,8 @@ struct LnBwdParams {
     int img, patch; int P; int u8;    // PATCH / EMBED mapping (EMBED: dy row = n*(P+1)+p+1 for x row n*P+p); u8 as in LnFwdParams
     int dsum;                         // also reduce the emitted gradient (dxt if written, else dx32) over rows: third partial row = the bias
                                       // gradient of the Linear that consumes it (saves that Linear's own column-sum pass over the tensor)
+    vc_drop drop32;                   // r06: dropout mask (row * C + c) applied to the dx32 OUTPUT only — the ViT's emb_dropout rides on the first layer's norm backward
+                                      // instead of a pass of its own over the fp32 gradient stream (not combined with dxt / dsum)
 };
 
 template <typename TD, typename TX, typename TY, int VPL, int MODE>
@@ -226,7 +233,13 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
 #pragma unroll
                 for (int i = 0; i < VPL; ++i) dx[i] += a[i];
             }
-            if (p.dx32) row_store<float, VPL>(p.dx32 + row * p.lddx32, dx, lane);
+            if (p.dx32) {
+                if (p.drop32.key) {
+#pragma unroll
+                    for (int q4 = 0; q4 < VPL / 4; ++q4) { float dm[4]; vc_drop_mul4(p.drop32, (uint32_t)(row * C + q4 * 256 + lane * 4), dm); for (int k = 0; k < 4; ++k) dx[q4 * 4 + k] *= dm[k]; }
+                }
+                row_store<float, VPL>(p.dx32 + row * p.lddx32, dx, lane);
+            }
             if (p.dxt) {
                 if (p.drop.key) {
 #pragma unroll
@@ -513,6 +526,53 @@ VC_KERNEL __launch_bounds__(256) void dact_bwd_bf16_rows_kernel(vc_bf16* dz, con
         for (int r = 0; r < rpb; ++r) t += red[r * cols + c];
         partial[(long)blockIdx.x * cols + c] = t;
     }
+}
+
+// ---- LayerNorm affine folded into the Linear behind it (r06: the patch embedding, Rearrange -> LayerNorm(1024) -> Linear(1024, 512); vit-pytorch
+// to_patch_embedding, ctor call reference model/trajectory_model.py:54-65).  With xh = (x - mean) rstd:  Linear(gamma xh + beta) = xh (W gamma)^T + (b + W beta),
+// so the engine stores xh (16-bit), multiplies by Wf = W . diag(gamma) and adds bf = b + W beta.  In the backward the weight gradient of the folded Linear,
+// dWf = dY^T xh, IS the sum the LayerNorm's parameter gradients need:  dgamma_k = sum_d dWf[d][k] W[d][k],  dbeta_k = sum_d S[d] W[d][k]  (S = colsum dY = db),
+// dW[d][k] = dWf[d][k] gamma_k + S[d] beta_k — exact, and the dgrad to the normalised patches (107 GFLOP, 200 us at the benchmark shape) and the LayerNorm
+// backward pass over them (119 us, 620 MB) that r01-r05 ran only to reduce those 2 048 numbers are not needed: the frames take no gradient.
+// W [D][K] fp32 master, gamma / beta [K]; Wf [D][K] 16-bit, bf [D] fp32.  One workgroup per output row d.
+VC_KERNEL __launch_bounds__(256) void pe_fold_kernel(const float* W, const float* b, const float* gamma, const float* beta, vc_bf16* Wf, float* bf, int K) {
+    VC_SHARED float red[4];
+    const int d = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = W[(long)d * K + k];
+        vc_st(Wf + (long)d * K + k, w * gamma[k]);
+        acc += w * beta[k];
+    }
+    acc = vc_wave_sum(acc);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    vc_sync();
+    if (tid == 0) bf[d] = b[d] + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+// dWf [D][K] fp32 (weight gradient of the folded Linear), S [D] (its bias gradient) -> dW [D][K] and, per chunk of rows, the partial sums of dgamma | dbeta:
+// partial[chunk][2 K] (the caller's column-sum pass adds the chunks in order: deterministic).  Thread = column k (coalesced along k), blockIdx.y = chunk of
+// D / gridDim.y rows, eight rows' loads in flight.  (A first version walked all D rows in one thread: 4 workgroups, 209 us of dependent round trips.)
+VC_KERNEL __launch_bounds__(256) void pe_fold_bwd_kernel(const float* __restrict__ dWf, const float* __restrict__ S, const float* __restrict__ W,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ dW, float* __restrict__ partial, int D, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int per = (D + gridDim.y - 1) / gridDim.y, d0 = blockIdx.y * per, d1 = d0 + per < D ? d0 + per : D;
+    const float g = gamma[k], be = beta[k];
+    float ag = 0.f, ab = 0.f;
+    int d = d0;
+    for (; d + 8 <= d1; d += 8) {
+        float dwf[8], w[8], sd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dwf[u] = dWf[(long)(d + u) * K + k]; w[u] = W[(long)(d + u) * K + k]; sd[u] = S[d + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dW[(long)(d + u) * K + k] = dwf[u] * g + sd[u] * be; ag += dwf[u] * w[u]; ab += sd[u] * w[u]; }
+    }
+    for (; d < d1; ++d) {
+        const float dwf = dWf[(long)d * K + k], w = W[(long)d * K + k], sd = S[d];
+        dW[(long)d * K + k] = dwf * g + sd * be; ag += dwf * w; ab += sd * w;
+    }
+    partial[(long)blockIdx.y * 2 * K + k] = ag; partial[(long)blockIdx.y * 2 * K + K + k] = ab;
 }
 
 // ---- dst[c][r] = src[r][c] (bf16): the transposed weight shadows of the frame ViT (engine.hip: wT); 32x32 tiles through LDS

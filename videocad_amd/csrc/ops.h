@@ -92,7 +92,11 @@ long vc_dact_bwd_blocks(long rows, int cols);
 bool vc_dact_bwd_fused_ok(int cols);           // the activation-derivative pass can reduce its output over rows (partial-row form): cols / 8 divides 256
 // grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);
-int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);     // dst[c][r] = src[r][c]
+int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);
+// LayerNorm affine folded into the Linear behind it (norm.h): Wf = 16-bit(W diag(gamma)), bf = b + W beta;  backward: dW, dgamma, dbeta from the folded Linear's dWf and db
+int vc_pe_fold(const float* W, const float* b, const float* gamma, const float* beta, void* Wf, float* bf, int D, int K, vc_stream_t s);
+int vc_pe_fold_bwd(const float* dWf, const float* S, const float* W, const float* gamma, const float* beta, float* dW, float* dgamma_dbeta, int D, int K,
+                   float* partial_ws /* >= 32 * 2 K floats */, float* colsum_ws, vc_stream_t s);       // dgamma | dbeta contiguous [2 K]     // dst[c][r] = src[r][c]
 
 // MXFP8 (gemm_mx8.h): quantise [rows, cols] (fp32 / bf16) to e4m3 + E8M0 block scales; C = epilogue(A8 B8^T)
 struct Mx8Params { GemmParams g; const uint8_t* sa; long ldsa; const uint8_t* sb; long ldsb; };     // fp8 operands + their E8M0 scale matrices [rows][K / 32]

@@ -162,7 +162,9 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         const long mt = (long)VC_CEIL_DIV(p.M, vc_gemm_mid_tile_m(c.trb)) * (p.N / vc_gemm_mid_tile_n(c.trb));
         // automatic for the k-contiguous-B (forward) layout only: in-model A/B at C2 (profiles/r02_gemm_mid_ab.txt) forward -0.35 ms per step,
         // but the row-contiguous-B variant (decoder dgrads through W, 64 x 128 tile) +0.26 ms against the register-staged kernel
-        if (g_mid_mode == 1 || (!c.trb && mt >= 96 && mt <= 1024 && p.K >= 256)) { *tag = VC_TAG_GEMM_MID; return vc_gemm_mid_launch(c, s); }
+        // (r06: up to two and a half rounds of the 256 one-workgroup-per-CU slots — the decoder's 3 072-wide in-projection is 768 tiles = three rounds here, 38 us, against 33 us on
+        // the register-staged 128 x 128 tile with two workgroups per CU; profiles/r06_mid_rounds_ab.txt)
+        if (g_mid_mode == 1 || (!c.trb && mt >= 96 && mt <= 640 && p.K >= 256)) { *tag = VC_TAG_GEMM_MID; return vc_gemm_mid_launch(c, s); }
     }
     *tag = VC_TAG_GEMM_REG;
     const int BK = (c.ct == VC_BF16) ? GemmCfg<vc_bf16>::BK : GemmCfg<float>::BK;

@@ -243,6 +243,22 @@ int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chun
     VC_LAUNCH(colsum_grouped_kernel, dim3((unsigned)strips, 1), dim3(256), 0, s, jobs, njobs, partial, 1);
     return VC_OK;
 }
+// LayerNorm affine folded into the Linear behind it (norm.h pe_fold_kernel / pe_fold_bwd_kernel)
+int vc_pe_fold(const float* W, const float* b, const float* gamma, const float* beta, void* Wf, float* bf, int D, int K, vc_stream_t s) {
+    ProfScope ps(VC_CAT_OTHER, 0, (double)D * K * 6, s);
+    VC_LAUNCH(pe_fold_kernel, dim3((unsigned)D), dim3(256), 0, s, W, b, gamma, beta, (vc_bf16*)Wf, bf, K);
+    return VC_OK;
+}
+// dgamma | dbeta [2 K] must be contiguous (norm weight / bias adjacent in the flat buffer); partial_ws >= PE_FOLD_CHUNKS * 2 K floats, colsum_ws as for vc_colsum
+enum { PE_FOLD_CHUNKS = 32 };
+int vc_pe_fold_bwd(const float* dWf, const float* S, const float* W, const float* gamma, const float* beta, float* dW, float* dgamma_dbeta, int D, int K,
+                   float* partial_ws, float* colsum_ws, vc_stream_t s) {
+    {
+        ProfScope ps(VC_CAT_OTHER, 0, (double)D * K * 12, s);
+        VC_LAUNCH(pe_fold_bwd_kernel, dim3((unsigned)VC_CEIL_DIV(K, 256), PE_FOLD_CHUNKS), dim3(256), 0, s, dWf, S, W, gamma, beta, dW, partial_ws, D, K);
+    }
+    return vc_colsum(VC_F32, partial_ws, 2L * K, PE_FOLD_CHUNKS, 2 * K, dgamma_dbeta, 0, 1, 0, 0, colsum_ws, s);
+}
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s) {
     VC_LAUNCH(transpose_bf16_kernel, dim3((unsigned)VC_CEIL_DIV(cols, 32), (unsigned)VC_CEIL_DIV(rows, 32)), dim3(256), 0, s, src, dst, rows, cols);
     return VC_OK;

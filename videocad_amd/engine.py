@@ -159,9 +159,13 @@ class NativeEngine:
         """p = 0 disables; call with a fresh seed before every training forward (masks = hash(seed, site, index))."""
         L.check(self.lib, self.lib.vcad_set_dropout(self.h, float(p), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF)), "set_dropout")
 
-    def dropout_mask(self, module: int, layer: int, kind: int, n: int) -> torch.Tensor:
+    def dropout_mask(self, module: int, layer: int, kind: int, n: int, first: int = 0) -> torch.Tensor:
+        """keep-multipliers of elements first .. first + n - 1 of one dropout site (tests: the oracle applies them as explicit multipliers)"""
         out = torch.empty(n, dtype=torch.float32)
-        L.check(self.lib, self.lib.vcad_dropout_mask(self.h, module, layer, kind, n, C.c_void_p(out.data_ptr())), "dropout_mask")
+        if first:
+            L.check(self.lib, self.lib.vcad_dropout_mask_range(self.h, module, layer, kind, first, n, C.c_void_p(out.data_ptr())), "dropout_mask_range")
+        else:
+            L.check(self.lib, self.lib.vcad_dropout_mask(self.h, module, layer, kind, n, C.c_void_p(out.data_ptr())), "dropout_mask")
         return out
 
     # kernel-selection flags (tests: small batches on the kernels the C2 shapes take; lib.GEMM_*) / launches per kernel family / side stream
