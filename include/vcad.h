@@ -231,6 +231,8 @@ int vcad_profile_kernel(int family, double out[4]);
 #define VCAD_GEMM_DYNAMIC (1u << 16)   /* the persistent kernel claims its items with tickets instead of static per-workgroup lists: robust when other kernels (RCCL) hold CUs.
                                          * The one flag the product sets: the data-parallel trainer turns it on for world > 1 (vcad_set_gemm_flags); vcad_op_gemm carves the
                                          * counters from its scratch buffer */
+#define VCAD_GEMM_RESERVE_CUS(n8) (((uint32_t)(n8) & 15u) << 17)   /* with VCAD_GEMM_DYNAMIC: the persistent kernel launches on 256 - 8 n8 CUs and leaves the rest to other streams'
+                                         * kernels (the data-parallel trainer: RCCL's) — a persistent workgroup waiting for a taken CU stalls the dispatch of every other stream */
 #define VCAD_GEMM_NGROUP(n) ((uint32_t)(n) << 12)    /* register-staged kernel: tile columns per sweep over all tile rows (0 automatic: only when B overflows an XCD's L2) */
 #define VCAD_GEMM_XCD_COLS(n) ((uint32_t)(n) << 8)   /* XCD column groups of the persistent kernel's forward launches: 0 automatic, 1 never, 2 / 4 / 8 forced */
 int vcad_set_gemm_flags(vcad_engine* e, uint32_t flags);

@@ -433,3 +433,29 @@ def test_f16_overflow_drill_in_the_trainer(tmp_path, monkeypatch):
         tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "drill"}, "cpu", mtype, rank=0)
         hist = U.f16_overflow_drill(tr, tb, inject_at=3, window=2, grow_after=6)
         assert hist[0][1] == 1024.0 and min(h[1] for h in hist) == 512.0 and hist[-1][1] == 1024.0
+
+
+def test_f16_persistent_overflow_halves_once_per_scale(tmp_path, monkeypatch):
+    """the host reads a window's overflow counter ONE WINDOW LATE.  With a persistent overflow, the window after the one that triggered a halving
+    also ran at the old scale and is non-finite too; read later, it must book its skipped updates (Adam's step counter) but not halve again — only a window that
+    ran AT the current scale and still overflowed may.  Host logic of the trainer's watcher + NativeEngine.note_overflows, driven with synthetic norms."""
+    monkeypatch.chdir(tmp_path)
+    shutil.copy(os.path.join(HERE, "golden", "class_weights.json"), "class_weights.json")
+    with U.emulated(), U.emulated("f16"):
+        cfg, ocfg = small(compute_dtype="f16")
+        model, mtype, shapes = make_model(cfg, ocfg)
+        nb, tb = tbatch(1, 2, 4)
+        pk = {"loader": [tb], "sampler": None}
+        tr = create_trainer(pk, pk, pk, model, {"lr": 1e-5, "use_mse": True, "experiment_name": "persist"}, "cpu", mtype, rank=0)
+        eng = tr.engine
+        tr.OVERFLOW_WINDOW = 2
+        eng.set_grad_scale(1024.0); eng.step_count = 100
+        bad, good = torch.tensor([float("inf"), 0.0]), torch.tensor([1.0, 1.0])
+        scales = []
+        for norm in [bad] * 6 + [good] * 4:                 # three windows of overflows (the first two at 1024, the third at 512), then clean ones
+            tr._watch_overflow(norm)
+            scales.append(eng.grad_scale)
+        # window 0 (1024, bad) is read at the end of window 1 -> 512; window 1 (ran at 1024) is read at the end of window 2: no halving; window 2 (ran at 512,
+        # bad) is read at the end of window 3 -> 256; windows 3, 4 are clean
+        assert scales == [1024.0, 1024.0, 1024.0, 512.0, 512.0, 512.0, 512.0, 256.0, 256.0, 256.0], scales
+        assert eng.skipped_steps == 6 and eng.step_count == 100 - 6

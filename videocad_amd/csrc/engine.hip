@@ -282,7 +282,8 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
             l.stat_f = b.take<float>(R * 2 * 4); l.h_f = b.take<void>(R * D * es); l.z = b.take<void>(R * c.vit_mlp * es);
             l.g = b.take<void>(R * c.vit_mlp * es); l.xo = b.take<float>(R * D * 4);
             l.part_fn = b.take<float>((size_t)vc_ln_bwd_blocks(R) * 3 * D * 4); l.part_an = b.take<float>((size_t)vc_ln_bwd_blocks(R) * 3 * D * 4);
-            l.part_b1 = b.take<float>((size_t)vc_dact_bwd_blocks(R, c.vit_mlp) * c.vit_mlp * 4);
+            // (the activation-derivative pass with the b1 reduction exists on 16-bit engines only — ADVICE r05: fp32 engines planned 2 048 x vit_mlp floats per layer for nothing)
+            l.part_b1 = e->dt == VC_BF16 ? b.take<float>((size_t)vc_dact_bwd_blocks(R, c.vit_mlp) * c.vit_mlp * 4) : nullptr;
         }
         for (int part = 0; part < 3; ++part) {
             vcad_engine::VitColsums& vc = e->vcs[v][part];

@@ -459,32 +459,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         } else {
             acc_init();
 #ifdef VCAD_AB
-            // experiment (debug bit 256, implies "no epilogue"): a tile's side-input loads and output stores spread over the k-tiles of the main loop
-            // (4 quads per wave on each of its first four turns; garbage values, right addresses) — does the epilogue's HBM stream overlap with the ring?
-            if constexpr (NJ == 2 && NW == 8) if (VC_ABL(256) && p.residual) {
-                vc_u32x4 pend[4] = {}; int npiece = 0; uint32_t dummy = 0;
-                for (int kt = 0; kt < cp.ntc - 1; ++kt) {
-                    ktile_begin();
-                    if (grp == turn && npiece < 4) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) dummy ^= pend[q].x ^ pend[q].y ^ pend[q].z ^ pend[q].w;
-                        const int i_ = npiece >> 1, jn_ = npiece & 1;
-                        int m_ = tm * GD_BM + wm * WR + i_ * 32 + (lane & 31); m_ = m_ < p.M ? m_ : p.M - 1;
-                        const int n_ = tn * BN + wn * HALF_N + jn_ * 32 + 4 * (lane >> 5);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { float v[4] = {acc[0][0][4 * q], acc[0][1][4 * q + 1], acc[1][0][4 * q + 2], acc[1][1][4 * q + 3]}; quad_st<TO>(((TO*)p.C) + (long)m_ * p.ldc + n_ + 8 * q, v); }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pend[q] = *reinterpret_cast<const vc_u32x4*>(p.residual + (long)m_ * p.ldr + n_ + 8 * q);
-                        ++npiece;
-                    }
-                    ktile_prefetch(); ktile_mfma();
-                }
-                ktile_begin(); ktile_prefetch(); ktile_mfma();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dummy ^= pend[q].x ^ pend[q].y ^ pend[q].z ^ pend[q].w;
-                if (acc[0][0][0] == 12345.678f || dummy == 0x12345u) ((float*)p.C)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7];
-                continue;
-            }
+#include "gemm_dma_ab.h"       // (A/B build only: the r04 spread-epilogue experiment; a fragment that uses this loop's locals)
 #endif
             for (int kt = 0; kt < cp.ntc - 1; ++kt) { ktile_begin(); ktile_prefetch(); ktile_mfma(); }
         }

@@ -34,7 +34,8 @@ const char* vc_get_error();
 enum { VC_GF_TILE64 = 1, VC_GF_TILE128 = 2, VC_GF_DMA_NEVER = 4, VC_GF_DMA_ALWAYS = 8, VC_GF_WIDE_NEVER = 16, VC_GF_WIDE_ALWAYS = 32,
        VC_GF_MID_NEVER = 64, VC_GF_MID_ALWAYS = 128, VC_GF_XCD_COLS_SHIFT = 8 /* bits 8-11, XCD column groups of the persistent kernel: 0 automatic, 1 never, 2 / 4 / 8 forced */,
        VC_GF_NGROUP_SHIFT = 12 /* bits 12-15, register-staged kernel: tile columns per sweep (gemm.h n_group): 0 automatic, 1-15 forced */,
-       VC_GF_DYNAMIC = 1 << 16 /* vcad_op_gemm: persistent kernel claims its items dynamically (counters carved from the scratch buffer) */ };
+       VC_GF_DYNAMIC = 1 << 16 /* vcad_op_gemm: persistent kernel claims its items dynamically (counters carved from the scratch buffer) */,
+       VC_GF_RESERVE_SHIFT = 17 /* bits 17-20: the persistent kernel launches on 256 - 8 n CUs (n = 0..15), leaving the rest to other streams' kernels (data-parallel runs) */ };
 struct GemmCall {
     int ct, sa, sb, to;         // compute / A-source / B-source / output dtypes
     int tra, trb;

@@ -17,7 +17,11 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     ProfScope ps(c.role ? c.role - 1 : (TRA ? VC_CAT_GEMM_WGRAD : (TRB ? VC_CAT_GEMM_DGRAD : VC_CAT_GEMM_FWD)), 2.0 * c.p.M * c.p.N * c.p.K,
                  (double)c.p.M * c.p.K * 2 + (double)c.p.N * c.p.K * 2 + (double)c.p.M * c.p.N * sizeof(TO), s, VC_TAG_GEMM_DMA);
     const int tiles_n = c.p.N / BN, tiles_mn = VC_CEIL_DIV(c.p.M, GD_BM) * tiles_n, total = tiles_mn * nsplit;
-    const int grid = total < 256 ? total : 256;                    // one workgroup per CU (147 KiB of LDS each)
+    // one workgroup per CU (147 KiB of LDS each).  VC_GF_RESERVE (r06, data-parallel runs): leave 8 x n CUs to the kernels of other streams — a persistent workgroup
+    // that finds its CU taken (RCCL's kernels during the exchange) waits in the dispatcher until another one exits, and while it waits NOTHING of the process's other
+    // streams is dispatched either: with 8 of 256 CUs pinned the whole train step ran +24 % (tickets) / +31 % (static lists), not +3 % (profiles/r06_step_hog_*.txt)
+    const int cus = 256 - 8 * (int)((c.flags >> VC_GF_RESERVE_SHIFT) & 15u);
+    const int grid = total < cus ? total : cus;
     {
     // XCD column groups (see the kernel): only for k-contiguous forward-layout GEMMs whose weight matrix would not stay in one XCD's L2
     int xn = 1;
@@ -26,7 +30,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
         const double b_bytes = (double)c.p.N * c.p.K * 2, a_bytes = (double)c.p.M * c.p.K * 2, slice = (double)BN * c.p.K * 2;
         const int tiles_m = tiles_mn / tiles_n;
         if (g_xn > 0) { xn = g_xn; if (tiles_n % xn || tiles_m < 8 / xn) xn = 1; }         // forced (tests, A/B): any grid
-        else if (grid == 256 && b_bytes >= 2.0e6) {
+        else if (grid == cus && b_bytes >= 2.0e6) {
             xn = 2; while (xn < 8 && b_bytes / xn > 1.6e6) xn *= 2;
             // worth it only if the extra A reads (xn XCD columns) stay well below the weight re-fetches they remove, and every XCD keeps rows to sweep
             if (tiles_n % xn || a_bytes * xn > 0.5 * (double)tiles_mn * slice || tiles_m < 8 * 8 / xn) xn = 1;

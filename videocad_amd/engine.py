@@ -113,7 +113,7 @@ class NativeEngine:
 
     GROW_AFTER = 2000                 # finite steps in a row before a lowered scale is doubled again (torch.amp.GradScaler's growth_interval)
 
-    def note_overflows(self, bad: int, steps: int) -> bool:
+    def note_overflows(self, bad: int, steps: int, ran_at_scale: Optional[float] = None) -> bool:
         """fp16 engines, host logic of the gradient scale (no kernels).  `bad` of the last `steps` optimizer steps came back with a non-finite
         gradient norm — the scaled backward overflowed fp16 and the library skipped those updates.  Then: the Adam step counter is taken back
         by `bad` (a skipped update must not advance the bias correction), the scale is halved once (explicit mode from here on) and the value
@@ -127,6 +127,10 @@ class NativeEngine:
             self._good_norms = 0
             self.step_count = max(0, self.step_count - int(bad))
             self.skipped_steps = getattr(self, "skipped_steps", 0) + int(bad)
+            #  the host reads a window's counter one window late: with a persistent overflow the window AFTER the one that triggered a halving also
+            # ran at the old scale and is non-finite too — its skipped updates are booked above, but it says nothing about the scale in force now: no second halving
+            if ran_at_scale is not None and ran_at_scale > self.grad_scale:
+                return False
             if getattr(self, "_scale_target", None) is None:
                 self._scale_target = self.grad_scale                 # (what the automatic rule chose for this batch shape)
             if self.grad_scale > 1.0:

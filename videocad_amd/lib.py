@@ -17,6 +17,12 @@ VCAD_F32, VCAD_BF16, VCAD_BF16X3, VCAD_F16 = 0, 1, 2, 3
 # kernel-selection flags (include/vcad.h VCAD_GEMM_*; tests only) and kernel families (vcad_kernel_launches / vcad_op_gemm kernel_out)
 GEMM_TILE64, GEMM_TILE128, GEMM_DMA_NEVER, GEMM_DMA_ALWAYS, GEMM_WIDE_NEVER, GEMM_WIDE_ALWAYS, GEMM_MID_NEVER, GEMM_MID_ALWAYS = 1, 2, 4, 8, 16, 32, 64, 128
 GEMM_DYNAMIC = 1 << 16
+
+
+def gemm_reserve_cus(n8):
+    """persistent GEMM on 256 - 8 * n8 CUs (n8 = 0..15): the rest stay free for other streams' kernels (RCCL during the gradient exchange)"""
+    return (int(n8) & 15) << 17
+
 KERNEL_GEMM_DMA, KERNEL_GEMM_REG, KERNEL_GEMM_MID, KERNEL_GEMM_GROUPED = 1, 2, 3, 4
 
 

@@ -275,7 +275,10 @@ class GradSync:
     r05 — two knobs for the first multi-GPU runs (training_config `grad_wire`, `grad_exchange`, `grad_rs_min_mb`; DESIGN.md §6 says which to try when):
       wire = "fp32" (default: the reference's numerics) | "half": the bucket travels in the engine's 16-bit storage format (bf16; fp16 with a
              power-of-two scale from the all-reduced max |g| for VCAD_F16 engines) — half the xGMI bytes, packed / unpacked by the library
-             (include/vcad.h: vcad_wire_*);
+             (include/vcad.h: vcad_wire_*).  Limitation of the fp16 wire: ONE max |g| — one power-of-two scale — covers a whole exchanged range
+             (up to ~90 M elements for the heads + decoder bucket), so with world = 8 elements below ~max|g| * 2^-27 flush to zero or go subnormal before the
+             sum; Adam normalises per element, so a tensor whose gradients are that small next to a large-gradient neighbour can lose its update signal.
+             The bf16 wire (bf16 engines) has fp32's range and no such floor; engines with a wide gradient range should take bf16 or stay on "fp32";
       exchange = "all_reduce" (default) | "rs_ag": reduce_scatter + all_gather of the same bucket — the two halves of a ring all-reduce as separate
              collectives, each a one-hop pattern on the fully connected xGMI mesh | "auto": rs_ag for buckets of at least `rs_min_mb` MB on the wire.
     `timing = True` records issue / completion events around every exchange; `comm_report()` turns the last step's into milliseconds
@@ -558,16 +561,17 @@ class BaseTrainer:
         eng = self.engine
         self._last_norm = norm
         if getattr(self, "_ovf_acc", None) is None:
-            self._ovf_acc = torch.zeros((), dtype=torch.int32, device=norm.device); self._ovf_n = 0; self._ovf_prev = None
+            self._ovf_acc = torch.zeros((), dtype=torch.int32, device=norm.device); self._ovf_n = 0; self._ovf_prev = None; self._ovf_scale = eng.grad_scale
         self._ovf_acc += (~torch.isfinite(norm[0])).to(torch.int32)
         self._ovf_n += 1
         if self._ovf_n >= self.OVERFLOW_WINDOW:
-            prev, self._ovf_prev = self._ovf_prev, (self._ovf_acc, self._ovf_n)
+            prev, self._ovf_prev = self._ovf_prev, (self._ovf_acc, self._ovf_n, self._ovf_scale)
             self._ovf_acc = torch.zeros((), dtype=torch.int32, device=norm.device); self._ovf_n = 0
             if prev is not None:
                 bad = int(prev[0].item())                          # (a window that ended OVERFLOW_WINDOW steps ago)
-                if eng.note_overflows(bad, prev[1]):
+                if eng.note_overflows(bad, prev[1], ran_at_scale=prev[2]):     # (a window that ran at a scale since lowered cannot lower it again)
                     self.log(f"fp16 gradient overflow: {bad} of {prev[1]} updates skipped, gradient scale now {eng.grad_scale:.0f}")
+            self._ovf_scale = eng.grad_scale                       # the scale the window that starts now runs at
 
     def _reset_overflow_watch(self):
         self._ovf_acc = None; self._ovf_prev = None; self._ovf_n = 0
