@@ -233,6 +233,9 @@ int vcad_profile_kernel(int family, double out[4]);
                                          * counters from its scratch buffer */
 #define VCAD_GEMM_RESERVE_CUS(n8) (((uint32_t)(n8) & 15u) << 17)   /* with VCAD_GEMM_DYNAMIC: the persistent kernel launches on 256 - 8 n8 CUs and leaves the rest to other streams'
                                          * kernels (the data-parallel trainer: RCCL's) — a persistent workgroup waiting for a taken CU stalls the dispatch of every other stream */
+#define VCAD_GEMM_MINI_NEVER (1u << 21)  /* persistent kernel: never cut the rows of a mostly empty last round into 64-row mini tiles (default: automatic — 800 tiles on 256 CUs run as
+                                         * 3 rounds + one mini per workgroup instead of 4 rounds) */
+#define VCAD_GEMM_MINI_ALWAYS (1u << 22) /* tests: mini tiles from the last full tile row on, whatever the grid */
 #define VCAD_GEMM_NGROUP(n) ((uint32_t)(n) << 12)    /* register-staged kernel: tile columns per sweep over all tile rows (0 automatic: only when B overflows an XCD's L2) */
 #define VCAD_GEMM_XCD_COLS(n) ((uint32_t)(n) << 8)   /* XCD column groups of the persistent kernel's forward launches: 0 automatic, 1 never, 2 / 4 / 8 forced */
 int vcad_set_gemm_flags(vcad_engine* e, uint32_t flags);
@@ -263,6 +266,7 @@ void vcad_debug_wgrad_bk32(int on);          /* 256-wide weight-gradient kernel:
 void vcad_debug_cls_path(int on);            /* 16-bit engines, last ViT layer: class-token attention on (q W_k, normalised tokens) (1, default: r06, csrc/attn_cls.h) or K / V projections of all tokens (0: r05) */
 void vcad_debug_dec_h16(int on);             /* 16-bit engines: decoder LayerNorms also emit 16-bit copies for the Linears / deferred weight gradients behind them (1, default: r06) or not (0: r05) */
 void vcad_debug_pe_fold(int on);             /* 16-bit engines: patch-embedding LayerNorm affine folded into its Linear (1, default: r06) or applied to the patches with a dgrad + LayerNorm backward for its gradients (0: r05) */
+void vcad_debug_attn_prefetch(int frames); /* ViT attention backward: 0 (default) or: every workgroup warms the L2 for the (frame + frames, head) pair of a later workgroup on its XCD — r06 experiment, measured slower (profiles/r06_attn_prefetch_ab.txt) */
 void vcad_debug_frame_first(int on);         /* whole backward with the side stream forked: frame tower's upper stage enqueued before the CAD tower's stage (1, default: r06) or after (0: r05) */
 #endif
 

@@ -130,6 +130,21 @@ def test_gemm_dma_kernel_dynamic_item_claiming(emu, gemm_tile, tra, trb, to, wid
         U.check_gemm(emu, "cpu", 2100, 512, 128, BF16, sa=BF16, sb=BF16, to=to, pad=8, bias=True, splitk=True, flags=fl | L.gemm_xcd_cols(2), kernel=L.KERNEL_GEMM_DMA)
 
 
+@pytest.mark.parametrize("dyn", [0, 1])
+@pytest.mark.parametrize("trb,to,wide", [(0, BF16, 1), (0, F32, 1), (0, BF16, 0), (0, F32, 0), (1, BF16, 0)])
+def test_gemm_dma_kernel_mini_tiles(emu, gemm_tile, trb, to, wide, dyn):
+    """r06: the rows of a mostly empty last round as 64-row mini tiles of the same tile program (gemm_dma.h GdMini) — forced here from the last full tile row on:
+    a ragged last piece (790 = 3 x 256 + 22: pieces of 64, 64, 64, 64, 22 rows behind two full tile rows), 1 / 3 / 10 k-tiles per item, plain and fused
+    (bias + residual, 128-wide tile) epilogues, static lists and ticket-drawn items, and a problem shorter than one tile (everything is minis)"""
+    if gemm_tile != 128:
+        pytest.skip("tile-size fixture does not apply to the DMA kernel")
+    fl = L.GEMM_DMA_ALWAYS | L.GEMM_MINI_ALWAYS | (L.GEMM_DYNAMIC if dyn else 0) | (L.GEMM_WIDE_ALWAYS if wide else L.GEMM_WIDE_NEVER)
+    for K in (64, 192, 640):
+        U.check_gemm(emu, "cpu", 790, 512, K, BF16, sa=BF16, sb=BF16, to=to, trb=trb, pad=8, bias=True, residual=(to == F32 and not wide), splitk=False,
+                     flags=fl, kernel=L.KERNEL_GEMM_DMA)
+    U.check_gemm(emu, "cpu", 200, 256, 128, BF16, sa=BF16, sb=BF16, to=to, trb=trb, pad=0, bias=True, splitk=False, flags=fl, kernel=L.KERNEL_GEMM_DMA)
+
+
 @pytest.mark.parametrize("trb,to", [(0, BF16), (0, F32), (1, BF16), (1, F32)])
 def test_gemm_mid_kernel(emu, gemm_tile, trb, to):
     """the six-stage DMA-ring kernel for mid-size problems (gemm_mid.h): ragged M tail, fewer k-tiles than stages / exactly / more,

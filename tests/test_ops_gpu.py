@@ -88,6 +88,24 @@ def test_gemm_dma_kernel(hip):
     U.check_gemm(hip, DEV, 20040, 512, 1024, BF16, to=F32, bias=True, residual=True, kernel=L.KERNEL_GEMM_DMA)   # automatic choice: DMA kernel
 
 
+def test_gemm_dma_kernel_mini_tiles(hip):
+    """r06: mini tiles for the rows of a mostly empty last round (gemm_dma.h GdMini).  Automatic at the benchmark shapes (102 400 rows x 512 / 1 024 columns:
+    800 / 1 600 tiles on 256 CUs), forced on a ragged small problem; static lists and ticket-drawn items; three times each (a mis-counted vmcnt or a
+    surplus wave reading a stage shows up as sporadic wrong tiles).  The same calls with VCAD_GEMM_MINI_NEVER must give bit-identical results
+    (same tile program, same k order) — check_gemm compares against the fp32 reference within the 16-bit tolerance either way."""
+    dma = dict(kernel=L.KERNEL_GEMM_DMA)
+    for rep in range(3):
+        for fl in (L.GEMM_DMA_ALWAYS, L.GEMM_DMA_ALWAYS | L.GEMM_DYNAMIC, L.GEMM_DMA_ALWAYS | L.GEMM_MINI_NEVER):
+            U.check_gemm(hip, DEV, 102400, 512, 512, BF16, to=BF16, bias=True, seed=rep, flags=fl, **dma)
+            U.check_gemm(hip, DEV, 102400, 512, 1024, BF16, to=BF16, bias=True, seed=rep, flags=fl, **dma)
+        U.check_gemm(hip, DEV, 102400, 1024, 512, BF16, to=BF16, seed=rep, flags=L.GEMM_DMA_ALWAYS, **dma)
+        U.check_gemm(hip, DEV, 102400, 512, 3072, BF16, to=BF16, seed=rep, flags=L.GEMM_DMA_ALWAYS, **dma)
+        for fl in (0, L.GEMM_DYNAMIC):
+            U.check_gemm(hip, DEV, 790, 512, 192, BF16, to=F32, bias=True, residual=True, pad=8, seed=rep, flags=L.GEMM_DMA_ALWAYS | L.GEMM_MINI_ALWAYS | L.GEMM_WIDE_NEVER | fl, **dma)
+            U.check_gemm(hip, DEV, 790, 512, 640, BF16, to=BF16, bias=True, pad=8, seed=rep, flags=L.GEMM_DMA_ALWAYS | L.GEMM_MINI_ALWAYS | L.GEMM_WIDE_ALWAYS | fl, **dma)
+            U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, trb=1, seed=rep, flags=L.GEMM_DMA_ALWAYS | L.GEMM_MINI_ALWAYS | fl, **dma)
+
+
 def test_gemm_mid_kernel(hip):
     """six-stage DMA-ring kernel (gemm_mid.h) at the decoder's shapes: forward (k-contiguous W) and dgrad (row-contiguous W) layouts, fused
     epilogues, ragged M (B=16, T=186 -> 2976 rows), three times each (a mis-counted vmcnt shows up as sporadic wrong tiles); and the

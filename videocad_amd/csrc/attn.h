@@ -36,6 +36,8 @@ struct AttnParams {
     // fp32 tensors of the bf16x3 compute mode: 1 = the kernels that have an x3 form (attn_x3.h) run on the bf16 matrix cores with hi / lo split operands;
     // 2 = additionally q / k / v / dout / o / dq / dk / dv are pre-split hi | lo words (gemm.h vc_pk) — only shapes with an x3 kernel
     int x3;
+    // ViT attention backward (attn_mfma.h, r06): L2 warm-up distance in frames, set by the launcher (0 = off)
+    int pf_frames;
 };
 
 // sum_d row[d] * bc[d]; bc: LDS, same address for all lanes (broadcast).  The row is walked in 16-byte chunks, four

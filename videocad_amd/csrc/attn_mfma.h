@@ -490,6 +490,9 @@ VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
     VC_SHARED __attribute__((aligned(16))) vc_bf16 tiles[4][AM_T * AM_S];     // Q, K, V, dO
     VC_SHARED float lse_s[AM_T];
     VC_SHARED float del_s[AM_T];
+#if defined(VCAD_AB) && !defined(VC_EMU)
+    VC_SHARED uint32_t pf_sink[2 * 64];                                        // landing place of the L2 warm-up DMAs (never read)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
     int h; long n; am_block_to_frame_head((int)blockIdx.x, p.B, p.H, n, h);
     const int T = p.Tq;
@@ -506,6 +509,22 @@ VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
     if (wave < 2) {    // ---------------- lane = query of tile t:  D_i, dQ
         uint32_t keep = 0;
         if (DROP) keep = am_keep_bits1<true>(p.drop, dbase0, T, t, lane);
+#if defined(VCAD_AB) && !defined(VC_EMU)
+        // r06 experiment, A/B build only (vcad_debug_attn_prefetch; profiles/r06_attn_prefetch_ab.txt: SLOWER, +0.2 % / +0.6 % / +0.5 % on the step at 16 / 64 / 128 frames ahead).
+        // Hypothesis: a workgroup is one dependent chain — tiles in (a memory round trip), ~5 us of matrix / VALU work, gradients out — and a CU holds four of them, so on
+        // average little more than one workgroup per CU has loads in flight (~30 KB against the ~54 KB that 5.5 TB/s x the loaded latency asks of a CU); the two query
+        // waves therefore warm the L2 for the (frame + pf_frames, head) pair a later workgroup of the SAME XCD will stage (am_block_to_frame_head: XCD x owns frames
+        // 8 j + x): 200 lines, one 4-byte DMA per line (wave 0: Q and K rows, wave 1: V and dO rows), issued where the next vmcnt wait of these waves is ~500
+        // instructions away (vmcnt retires in order).  The kernel is not waiting for bytes in flight.
+        if (p.pf_frames > 0 && n + p.pf_frames < p.B) {
+            const int row = lane < T ? lane : T - 1;
+            const long r2 = (n + p.pf_frames) * T + row;
+            const vc_bf16* s0 = wave == 0 ? (const vc_bf16*)p.q + r2 * p.ldq : (const vc_bf16*)p.v + r2 * p.ldv;
+            const vc_bf16* s1 = wave == 0 ? (const vc_bf16*)p.k + r2 * p.ldk : (const vc_bf16*)p.dout + r2 * p.lddo;
+            vc_prefetch_line(s0 + h * AM_D, pf_sink + wave * 64);
+            vc_prefetch_line(s1 + h * AM_D, pf_sink + wave * 64);
+        }
+#endif
         vc_f32x16 st[2], dpt[2];
         am_zero1(st); am_zero1(dpt);
         am_mm_nt1(st, Ks, Qs, t, lane);      // S^T[key][query]
@@ -533,6 +552,9 @@ VC_DEV void attn_vit_bwd4_body(const AttnParams& p) {
         vc_f32x16 dq[2];
         am_zero1(dq);
         am_mm_tok1<false>(dq, st, Ks, lane, 0u, 1.0f);          // dQ[query][d] = sum_key dS[query][key] K[key][d]
+#if defined(VCAD_AB) && !defined(VC_EMU)
+        vc_wait_vmcnt<0>();                  // (the warm-up DMAs: no LDS write of this wave may be pending when the workgroup's LDS is handed on)
+#endif
         am_store_rows(tiles[2] + t * 32 * AM_S, (vc_bf16*)p.dq + rowq * p.lddq + h * AM_D, p.lddq, dq, t, T, lane, p.scale);   // (V is dead after the barrier)
     } else {           // ---------------- lane = key of tile t:  dV, dK
         uint32_t keep = 0;

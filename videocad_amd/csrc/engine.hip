@@ -410,7 +410,11 @@ struct Ctx {
     Mat WT(long offT, long ld) const { return Mat{(const void*)(e->wT + offT), VC_BF16, ld}; }
     int refresh_wT() const {
         if (!e->wT || e->wT_fresh) return 0;
-        for (const auto& j : e->wT_jobs) { int rc = vc_transpose_bf16(e->S + j.src_off, e->wT + j.dst_off, j.rows, j.cols, s); if (rc) return rc; }
+        {   // one grid for all of them (r06: 24 launches of 5-45 us sat between the stem's backward and the ViT's)
+            std::vector<long> so, d_o; std::vector<int> rw, cl;
+            for (const auto& j : e->wT_jobs) { so.push_back(j.src_off); d_o.push_back(j.dst_off); rw.push_back(j.rows); cl.push_back(j.cols); }
+            int rc = vc_transpose_bf16_batched(e->S, e->wT, so.data(), d_o.data(), rw.data(), cl.data(), (int)so.size(), s); if (rc) return rc;
+        }
         e->wT_fresh = true;
         return 0;
     }

@@ -141,7 +141,15 @@ template <int NM, int ND> VC_DEV void gd_interleave() {
 #endif
 }
 
-struct GdCursor { int item, kt, ntc, seq, z, tm, tn; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile row, tile column)
+struct GdCursor { int item, kt, ntc, seq, z, tn, row0, mend, li; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile column, first row, row bound), index in the workgroup's static list
+// Mini tiles (r06).  800 tiles on 256 CUs are 3.125 rounds: 32 workgroups walk a fourth tile while 224 idle (the N = 512 Linears of the ViT at the benchmark
+// shape: a fifth of 30 launches per step).  With h > 0 the rows from tile row tm0 on are cut into pieces of h (64 / 128) rows instead: the same tile program on a
+// tile of which only the first h rows exist — the A rows beyond are clamped re-reads of the piece's last row (one cache line per DMA piece), the waves that
+// own them skip their fragment reads, MFMAs and stores but keep issuing their share of the ring and meeting the barriers.  A mini costs about a third of a full
+// tile (its B tile and eight k-tiles of two to four waves), so the launch ends after 3 rounds + one mini per workgroup instead of 4 rounds.
+// Item ids: [0, nfull) = full tiles (k-slice, tile row, tile column), [nfull, nfull + nmini) = minis (piece, tile column); every XCD's list is its chunk of the full
+// tiles followed by its chunk of the minis.  h = 0: no minis (nfull = total).
+struct GdMini { int tm0, h, nfull, nmini; };
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
 template <int PW, int NS>
@@ -193,7 +201,7 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
 // per 8 (128 KiB of reads per k-tile), and a wave hides its own fragment latency behind 16 back-to-back MFMAs.  All four waves issue
 // their quarter of every stage (no second wave on the SIMD to take turns with).
 template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8, int BK = 64>
-VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn, int* claim) {
+VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn, int* claim, GdMini mn) {
     using TL = GdTile<BN, BK>;
     static_assert(NW == 8 || (NW == 4 && BN == 256 && BK == 64), "four-wave form: 256-wide tile, 64-deep stages only");
     static_assert(BK == 64 || (TRA && TRB), "32-deep stages: the row-contiguous (tr-read) layouts only");
@@ -225,19 +233,28 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     const int G = gridDim.x, b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int nbx = (G + 7 - xcd) >> 3;
     int tm0 = 0, tn0 = 0, tnc = tiles_n, tmn = tiles_mn, first, last;
+    // chunk of XCD x out of n items dealt as evenly as possible (the first n % 8 XCDs take one more)
+    auto xcd_chunk = [](int n, int x, int& cs, int& cn) { const int q8 = n >> 3, r8 = n & 7; cs = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; cn = x < r8 ? q8 + 1 : q8; };
+    int csf = 0, cnf = 0, csm = 0, cnm = 0;                      // this XCD's chunks of the full tiles and of the minis (static lists, xn == 1)
     if (xn > 1) {
         const int xm = 8 / xn, gx = xcd % xn, gy = xcd / xn, tiles_m = tiles_mn / tiles_n;
         tnc = tiles_n / xn; tn0 = gx * tnc;
         const int qm = tiles_m / xm, rm = tiles_m % xm;
         tm0 = gy < rm ? gy * (qm + 1) : rm * (qm + 1) + (gy - rm) * qm;
         tmn = (gy < rm ? qm + 1 : qm) * tnc;                       // tiles of this XCD per k-slice
-        first = j; last = tmn * nsplit;
+        first = j; last = tmn * nsplit;                          // (XCD-local ids; never with minis)
     } else {
-        const int q8 = total >> 3, r8 = total & 7;
-        const int cs = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-        const int cn = xcd < r8 ? q8 + 1 : q8;
-        first = cs + j; last = cs + cn;                          // items first, first + nbx, ... < last
+        xcd_chunk(mn.nfull, xcd, csf, cnf); xcd_chunk(mn.nmini, xcd, csm, cnm);
+        last = total;                                            // item ids are global; `last` = "no more items"
     }
+    // static lists: list position li = j, j + nbx, ... -> item id
+    auto resolve = [&](int li) -> int {
+        if (xn > 1) return li < last ? li : last;
+        if (li < cnf) return csf + li;
+        if (li < cnf + cnm) return mn.nfull + csm + (li - cnf);
+        return last;
+    };
+    first = resolve(j);
     // Dynamic item claiming (r03; `claim` = 9 zeroed ints: one ticket counter per XCD + a finish counter): the static lists above assume all
     // gridDim.x workgroups run at once — one per CU.  When other kernels hold CUs (RCCL's all-reduce under the backward), the workgroups that
     // could not start run as a second round after the others and the launch takes up to 2x.  With tickets, workgroup order does not matter:
@@ -247,17 +264,13 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     // ring anyway, one item ahead of the prefetch cursor; the last workgroup to finish re-zeroes the counters for the next launch.
     const bool dyn = claim != nullptr;
     int steal_x = xcd;                                            // XCD whose counter wave 0 draws from (moves on when that one is exhausted)
-    auto xcd_range = [&](int x, int& base, int& cnt) {
-        if (xn > 1) { base = 0; cnt = tmn * nsplit; return; }
-        const int q8 = total >> 3, r8 = total & 7;
-        base = x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8; cnt = x < r8 ? q8 + 1 : q8;
-    };
-    if (dyn) last = xn > 1 ? tmn * nsplit : total;               // item ids are global (or XCD-local with column groups); `last` = "no more items"
     auto claim_item = [&]() -> int {                              // wave 0 only
-        for (int tries = 0; tries < (xn > 1 ? 1 : 8); ++tries) {
-            int base, cnt; xcd_range(steal_x, base, cnt);
-            const int t = vc_wave_ticket(claim + steal_x);
-            if (t < cnt) return base + t;
+        if (xn > 1) { const int t = vc_wave_ticket(claim + steal_x); return t < last ? t : last; }
+        for (int tries = 0; tries < 8; ++tries) {
+            int f0, fn, m0, mc; xcd_chunk(mn.nfull, steal_x, f0, fn); xcd_chunk(mn.nmini, steal_x, m0, mc);
+            const int t = vc_wave_ticket(claim + steal_x);       // ticket t = position in that XCD's list (its full tiles, then its minis)
+            if (t < fn) return f0 + t;
+            if (t < fn + mc) return mn.nfull + m0 + (t - fn);
             steal_x = (steal_x + 1) & 7;
         }
         return last;
@@ -284,22 +297,28 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     const long kstepA = TRA ? (long)BK * p.lda * 2 : (long)BK * 2, kstepB = TRB ? (long)BK * p.ldb * 2 : (long)BK * 2;
 
     auto locate = [&](GdCursor& c) {            // integer divisions: once per item, never per k-tile
+        if (c.item >= mn.nfull) {               // mini: (piece, tile column), mn.h rows from row mn.tm0 * GD_BM + piece * mn.h (single k-slice launches only)
+            const int m_ = c.item - mn.nfull, pc = m_ / tnc;
+            c.z = 0; c.tn = m_ - pc * tnc; c.row0 = mn.tm0 * GD_BM + pc * mn.h; c.mend = c.row0 + mn.h < p.M ? c.row0 + mn.h : p.M;
+            c.ntc = ktiles < nt ? ktiles : nt;
+            return;
+        }
         c.z = c.item / tmn; const int rem = c.item - c.z * tmn;
         const int rm_ = rem / tnc;
-        c.tm = tm0 + rm_; c.tn = tn0 + rem - rm_ * tnc;
+        c.row0 = (tm0 + rm_) * GD_BM; c.mend = p.M; c.tn = tn0 + rem - rm_ * tnc;
         const int rest = ktiles - c.z * nt; c.ntc = rest < nt ? rest : nt;
     };
     auto advance = [&](GdCursor& c) -> bool {   // true when the cursor moved on to a new item
         if (++c.kt < c.ntc) return false;
         c.kt = 0; ++c.seq;
         if (dyn) c.item = tk[c.seq & 7];                                  // (claimed ahead; visible since the last barrier)
-        else c.item += nbx;
+        else { c.li += nbx; c.item = resolve(c.li); }
         if (c.item < last) locate(c);
         return true;
     };
     uint32_t offA[NPA], offB[NPB];
     auto retarget = [&](const GdCursor& c) {
-        gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.tm * GD_BM, p.M, wq * NPA, lane);
+        gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.row0, c.mend, wq * NPA, lane);
         gd_offsets<TRB, BN, NPB, COL ? NJ : 0>(offB, p.ldb, c.tn * BN, p.N, wq * NPB, lane);
     };
     auto issue = [&](const GdCursor& c, int slot) {
@@ -312,7 +331,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS_K, wq * NPB);
     };
 
-    GdCursor pf{first, 0, 1, 0, 0, 0, 0};
+    GdCursor pf{first, 0, 1, 0, 0, 0, 0, 0, j};
     if (first < last) { locate(pf); retarget(pf); }
     GdCursor cp = pf;
     int turn = 0;                                                // parity of the stage being consumed == the group that issued it
@@ -326,6 +345,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     // VMEM operations this wave issued in the last k-tile iterations (lower bounds): e1 / e2 / e3 = epilogue stores of iterations t-1 / t-2 / t-3, d1 / d2 = DMA
     // pieces of iterations t-1 / t-2; d_now = pieces issued in the current iteration (recorded by ktile_prefetch)
     int slot = 0, e1 = 0, e2 = 0, e3 = 0, d1 = 0, d2 = 0, young_cur = 0, d_now = 0;
+    bool wave_active = true;                                     // this wave owns rows of the item being consumed (false: a mini tile's surplus waves)
 
     // One k-tile: retire stage `slot`, re-arm the slot freed by the previous k-tile, feed the matrix cores.
     // Every instruction here is paid 300+ times per launch by every wave (a wave issues one instruction per ~4 cycles, a
@@ -389,6 +409,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             }
     };
     auto ktile_mfma = [&]() {
+        if (!wave_active) { slot = slot == STAGES - 1 ? 0 : slot + 1; return; }
         const vc_bf16* a_tile = lds + slot * STAGE_ELEMS;
         const vc_bf16* b_tile = a_tile + GD_A_ELEMS_K;
         vc_s16x8 af[2][MI], bf[2][NJ];
@@ -414,9 +435,10 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     constexpr bool FOLD = BN == 256;
     const bool fold_bias = FOLD && use_bias && plain;
 
-    for (; cp.item < last; ++cp.seq, cp.item = dyn ? tk[cp.seq & 7] : cp.item + nbx) {
+    for (; cp.item < last; ++cp.seq, cp.item = dyn ? tk[cp.seq & 7] : resolve(cp.li += nbx)) {
         if (cp.seq) locate(cp);
-        const int z = cp.z, tm = cp.tm, tn = cp.tn;
+        const int z = cp.z, tn = cp.tn, row0 = cp.row0, mend = cp.mend;        // (row0 / mend: the item's first row and row bound — a mini tile covers fewer than GD_BM rows)
+        wave_active = wm * WR < mend - row0;
         // accumulators start at the tile's bias when the epilogue is plain (then the epilogue is convert + store: no per-element add); the bias row
         // was DMA'd ahead of the item's first stage, so it is readable once that stage's wait + barrier (ktile_begin) are through
         auto acc_init = [&]() {
@@ -471,7 +493,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         if constexpr (COL) {
             const int cl = lane & 31;
             const int nb = tn * BN + wn * HALF_N + NJ * cl;                        // first of this lane's NJ adjacent columns
-            const int mb = tm * GD_BM + wm * WR + 4 * (lane >> 5);                 // row of (i = 0, r = 0); row(i, r) = mb + 32 i + (r & 3) + 8 (r >> 2)
+            const int mb = row0 + wm * WR + 4 * (lane >> 5);                 // row of (i = 0, r = 0); row(i, r) = mb + 32 i + (r & 3) + 8 (r >> 2)
             vc_u32x2 sd[MI][16];                                                    // side input of (i, r): NJ = 2 columns (fp32 pair / packed bf16 pair in .x)
             if constexpr (NJ == 2) if (use_side) {
                 if (p.residual) {
@@ -479,7 +501,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
+                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < mend ? m : mend - 1;
                             sd[i][r] = *reinterpret_cast<const vc_u32x2*>(p.residual + (long)m * p.ldr + nb);
                         }
                 } else if constexpr (sizeof(TO) == 2) {
@@ -487,7 +509,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
+                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < mend ? m : mend - 1;
                             sd[i][r].x = *reinterpret_cast<const uint32_t*>(((const TO*)p.dact_src) + (long)m * p.lddact + nb);
                         }
                 } else {
@@ -495,7 +517,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < p.M ? m : p.M - 1;
+                            int m = mb + i * 32 + (r & 3) + 8 * (r >> 2); m = m < mend ? m : mend - 1;
                             sd[i][r] = *reinterpret_cast<const vc_u32x2*>(((const TO*)p.dact_src) + (long)m * p.lddact + nb);
                         }
                 }
@@ -512,7 +534,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             // a quarter of the QKV forward's time (profiles/r03_gemm_epilogue_fastpath_ab.txt).  Here: the mode and "interior tile" are
             // decided once (wave-uniform), row offsets are compile-time multiples of the (scalar) leading dimension.
             if (p.partial || plain) {
-                const bool interior = (tm + 1) * GD_BM <= p.M;
+                const bool interior = row0 + GD_BM <= mend;
                 auto rows = [&](auto INTERIOR, auto PART) {
                     using T = typename std::conditional<decltype(PART)::value, float, TO>::type;
                     const long ld = decltype(PART)::value ? (long)p.N : p.ldc;
@@ -522,7 +544,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
-                            if (decltype(INTERIOR)::value || mb + ro < p.M) {
+                            if (decltype(INTERIOR)::value || mb + ro < mend) {
                                 float v[NJ];
 #pragma unroll
                                 for (int jn = 0; jn < NJ; ++jn) v[jn] = FOLD ? acc[i][jn][r] : acc[i][jn][r] + bv[jn];      // (256-wide: the bias is already in, acc_init; slabs: bv = 0)
@@ -540,7 +562,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m < p.M) {
+                    if (m < mend) {
                         float v[NJ];
 #pragma unroll
                         for (int jn = 0; jn < NJ; ++jn) v[jn] = acc[i][jn][r];
@@ -582,7 +604,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                         }
                     }
                 }
-            if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
+            if (row0 + GD_BM <= mend && !VC_ABL(32)) young_cur = NS_ITEM;
             continue;
         }
         // ---------------------------------------------------------------- row-per-lane form (tr-read B layouts), as in r01
@@ -592,7 +614,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             // drain around every load)
             int mrow[MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) { const int m = tm * GD_BM + wm * WR + i * 32 + (lane & 31); mrow[i] = m < p.M ? m : p.M - 1; }
+            for (int i = 0; i < MI; ++i) { const int m = row0 + wm * WR + i * 32 + (lane & 31); mrow[i] = m < mend ? m : mend - 1; }
             const int ncol = tn * BN + wn * HALF_N + 4 * (lane >> 5);
             if (p.residual) {
 #pragma unroll
@@ -632,11 +654,11 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
             auto quads = [&](auto PART) {
                 using T = typename std::conditional<decltype(PART)::value, float, TO>::type;
                 const long ld = decltype(PART)::value ? (long)p.N : p.ldc;
-                const int m0 = tm * GD_BM + wm * WR + (lane & 31), n0 = tn * BN + wn * HALF_N + 4 * (lane >> 5);
+                const int m0 = row0 + wm * WR + (lane & 31), n0 = tn * BN + wn * HALF_N + 4 * (lane >> 5);
                 T* q0 = (decltype(PART)::value ? (T*)(p.partial + (long)z * p.M * p.N) : (T*)p.C) + (long)m0 * ld + n0;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    if (m0 + i * 32 < p.M) {
+                    if (m0 + i * 32 < mend) {
 #pragma unroll
                         for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
@@ -653,13 +675,13 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                 }
             };
             if (p.partial) quads(gemm_true{}); else quads(gemm_false{});
-            if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
+            if (row0 + GD_BM <= mend && !VC_ABL(32)) young_cur = NS_ITEM;
             continue;
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int m = tm * GD_BM + wm * WR + i * 32 + (lane & 31);
-            if (m < p.M) {
+            const int m = row0 + wm * WR + i * 32 + (lane & 31);
+            if (m < mend) {
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
@@ -672,7 +694,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
                     }
             }
         }
-        if ((tm + 1) * GD_BM <= p.M && !VC_ABL(32)) young_cur = NS_ITEM;
+        if (row0 + GD_BM <= mend && !VC_ABL(32)) young_cur = NS_ITEM;
     }
     vc_wait_vmcnt<0>();            // no DMA may still be writing this workgroup's LDS when it is handed to the next one
     if (dyn && wave == 0) {        // the last workgroup through re-zeroes the counters (every other one has drawn its last ticket by then)

@@ -1,6 +1,6 @@
 // gemm_dma_ab.h — A/B-build-only fragment of gemm_dma_kernel (textually included INSIDE the kernel's item loop under -DVCAD_AB, `make ab`): the r04
 // "spread epilogue" experiment (profiles/r04_spread_epilogue_ab.txt).  Kept out of gemm_dma.h so that the product kernel's source reads as what runs
-// (VERDICT r05 item 9).  Uses the kernel's locals (ktile_begin / ktile_prefetch / ktile_mfma, acc, cp, grp, turn, tm, tn, wm, wn, lane, p).
+// (VERDICT r05 item 9).  Uses the kernel's locals (ktile_begin / ktile_prefetch / ktile_mfma, acc, cp, grp, turn, row0, mend, tn, wm, wn, lane, p).
             // experiment (debug bit 256, implies "no epilogue"): a tile's side-input loads and output stores spread over the k-tiles of the main loop
             // (4 quads per wave on each of its first four turns; garbage values, right addresses) — does the epilogue's HBM stream overlap with the ring?
             if constexpr (NJ == 2 && NW == 8) if (VC_ABL(256) && p.residual) {
@@ -11,7 +11,7 @@
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dummy ^= pend[q].x ^ pend[q].y ^ pend[q].z ^ pend[q].w;
                         const int i_ = npiece >> 1, jn_ = npiece & 1;
-                        int m_ = tm * GD_BM + wm * WR + i_ * 32 + (lane & 31); m_ = m_ < p.M ? m_ : p.M - 1;
+                        int m_ = row0 + wm * WR + i_ * 32 + (lane & 31); m_ = m_ < mend ? m_ : mend - 1;
                         const int n_ = tn * BN + wn * HALF_N + jn_ * 32 + 4 * (lane >> 5);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { float v[4] = {acc[0][0][4 * q], acc[0][1][4 * q + 1], acc[1][0][4 * q + 2], acc[1][1][4 * q + 3]}; quad_st<TO>(((TO*)p.C) + (long)m_ * p.ldc + n_ + 8 * q, v); }

@@ -591,6 +591,28 @@ VC_KERNEL __launch_bounds__(256) void transpose_bf16_kernel(const vc_bf16* src, 
     }
 }
 
+// ---- the same for up to 32 matrices in ONE grid (r06): the frame ViT's 24 transposed weight shadows were 24 launches of 5-45 us on the critical path between the stem's
+// backward and the ViT's (0.19 ms per step for 126 MB of traffic).  Jobs travel by value in the kernel arguments; 64 x 64 tiles, whole 128-byte row pieces both ways.
+struct TransposeBatch { int n; int tile_start[33]; long src_off[32], dst_off[32]; int rows[32], cols[32]; };
+VC_KERNEL __launch_bounds__(256) void transpose_bf16_batched_kernel(const vc_bf16* S, vc_bf16* D, TransposeBatch tb) {
+    VC_SHARED uint16_t tile[64 * 65];
+    int j = 0;
+    while (j + 1 < tb.n && tb.tile_start[j + 1] <= (int)blockIdx.x) ++j;
+    const int rows = tb.rows[j], cols = tb.cols[j], t = (int)blockIdx.x - tb.tile_start[j], tcx = (cols + 63) / 64;
+    const int r0 = (t / tcx) * 64, c0 = (t % tcx) * 64;
+    const vc_bf16* src = S + tb.src_off[j]; vc_bf16* dst = D + tb.dst_off[j];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i * 65 + tx] = (r < rows && c < cols) ? src[(long)r * cols + c].bits : (uint16_t)0;
+    }
+    vc_sync();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[(long)c * rows + r].bits = tile[tx * 65 + i];
+    }
+}
+
 // ---- grouped column sums (the decoder's deferred bias gradients): one grid over the 256-column strips of many jobs.
 // pass 0: partial[job.part_off + chunk * cols + c] = sum of rows [128 chunk, 128 chunk + 128);  pass 1: out[c] = sum over chunks
 // (fixed order: deterministic).  Jobs live in device memory; strip_start[j] = first strip of job j.

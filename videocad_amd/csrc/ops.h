@@ -35,7 +35,8 @@ enum { VC_GF_TILE64 = 1, VC_GF_TILE128 = 2, VC_GF_DMA_NEVER = 4, VC_GF_DMA_ALWAY
        VC_GF_MID_NEVER = 64, VC_GF_MID_ALWAYS = 128, VC_GF_XCD_COLS_SHIFT = 8 /* bits 8-11, XCD column groups of the persistent kernel: 0 automatic, 1 never, 2 / 4 / 8 forced */,
        VC_GF_NGROUP_SHIFT = 12 /* bits 12-15, register-staged kernel: tile columns per sweep (gemm.h n_group): 0 automatic, 1-15 forced */,
        VC_GF_DYNAMIC = 1 << 16 /* vcad_op_gemm: persistent kernel claims its items dynamically (counters carved from the scratch buffer) */,
-       VC_GF_RESERVE_SHIFT = 17 /* bits 17-20: the persistent kernel launches on 256 - 8 n CUs (n = 0..15), leaving the rest to other streams' kernels (data-parallel runs) */ };
+       VC_GF_RESERVE_SHIFT = 17 /* bits 17-20: the persistent kernel launches on 256 - 8 n CUs (n = 0..15), leaving the rest to other streams' kernels (data-parallel runs) */,
+       VC_GF_MINI_NEVER = 1 << 21, VC_GF_MINI_ALWAYS = 1 << 22 /* persistent kernel: mini tiles for the rows of a mostly empty last round (gemm_dma.h GdMini): automatic / never / forced (tests) */ };
 struct GemmCall {
     int ct, sa, sb, to;         // compute / A-source / B-source / output dtypes
     int tra, trb;
@@ -94,6 +95,8 @@ bool vc_dact_bwd_fused_ok(int cols);           // the activation-derivative pass
 // grouped column sums: jobs / partial are device pointers; max_chunks = ceil(max rows / 128), strips = total 256-column strips
 int vc_colsum_grouped(const ColsumJob* jobs, int njobs, int strips, int max_chunks, float* partial, vc_stream_t s);
 int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_stream_t s);
+// n matrices of one source / destination buffer in one grid (element offsets; 32 jobs per launch)
+int vc_transpose_bf16_batched(const vc_bf16* S, vc_bf16* D, const long* src_off, const long* dst_off, const int* rows, const int* cols, int n, vc_stream_t s);
 // LayerNorm affine folded into the Linear behind it (norm.h): Wf = 16-bit(W diag(gamma)), bf = b + W beta;  backward: dW, dgamma, dbeta from the folded Linear's dWf and db
 int vc_pe_fold(const float* W, const float* b, const float* gamma, const float* beta, void* Wf, float* bf, int D, int K, vc_stream_t s);
 int vc_pe_fold_bwd(const float* dWf, const float* S, const float* W, const float* gamma, const float* beta, float* dW, float* dgamma_dbeta, int D, int K,

@@ -220,6 +220,7 @@ int vc_attn_bwd(int t, int D, AttnParams p, vc_stream_t s) {
     }
     if (p.x3 == 2) { vc_set_error("attention backward: pre-split tensors (x3 = 2) have no kernel for this shape (D=%d Tq=%d Tk=%d causal=%d)", D, p.Tq, p.Tk, p.causal); return VC_ERR_UNSUPPORTED; }
     if (mfma_ok(t, D, p, true) && g_vit_bwd_variant == 0) {       // four waves per (frame, head)
+        p.pf_frames = p.B >= 512 ? VC_AB(attn_pf, 0) : 0;           // (A/B build only: L2 warm-up experiment of r06, attn_mfma.h — measured slower)
         if (p.drop.key) VC_LAUNCH(attn_vit_bwd4_kernel_drop, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);
         else VC_LAUNCH(attn_vit_bwd4_kernel_eval, dim3((unsigned)((long)p.B * p.H)), dim3(256), 0, s, p);
         return VC_OK;

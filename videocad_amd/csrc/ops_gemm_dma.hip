@@ -36,7 +36,26 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
             if (tiles_n % xn || a_bytes * xn > 0.5 * (double)tiles_mn * slice || tiles_m < 8 * 8 / xn) xn = 1;
         }
     }
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW, BK>), dim3(grid), dim3(NW * 64), (GdTile<BN, BK>::LDS_BYTES), s, c.p, tiles_n, tiles_mn, nsplit, total, xn, c.claim);
+    // Mini tiles (gemm_dma.h GdMini): when the item count leaves a mostly empty last round — 800 tiles on 256 CUs: 32 workgroups walk a fourth tile while 224 idle —
+    // the rows of that round are cut into 64-row pieces of the same tile program instead, one per workgroup at about a third of a full tile's time.  Single k-slice,
+    // row-major A (forward / dgrad layouts), no XCD column groups.  VC_GF_MINI_ALWAYS (tests): the last full tile row and everything behind it, whatever the grid.
+    GdMini mn = {0, 0, total, 0};
+    const int mini_mode = (c.flags & VC_GF_MINI_NEVER) ? 0 : ((c.flags & VC_GF_MINI_ALWAYS) ? 1 : -1);
+    if (!TRA && nsplit == 1 && xn == 1 && mini_mode != 0) {
+        const int tiles_m = tiles_mn / tiles_n, MH = 64;
+        int tm0 = -1;
+        if (mini_mode == 1) tm0 = c.p.M / GD_BM > 0 ? c.p.M / GD_BM - 1 : 0;
+        else if (grid == cus && tiles_mn > cus) {
+            const int full_rounds = tiles_mn / cus, cand = (int)((long)full_rounds * cus / tiles_n);       // tile rows that fill whole rounds
+            const int nm = VC_CEIL_DIV(c.p.M - cand * GD_BM, MH) * tiles_n;
+            // cost in rounds: a mini ~ 0.35 of a full tile (its B tile, the k-loop of one wave pair)
+            const double plain = (double)VC_CEIL_DIV(tiles_mn, cus), with = (double)(cand * tiles_n) / cus + 0.35 * VC_CEIL_DIV(nm, cus);
+            if (cand >= 1 && cand < tiles_m && with < plain - 0.3) tm0 = cand;
+        }
+        if (tm0 >= 0 && tm0 < tiles_m) { mn.tm0 = tm0; mn.h = MH; mn.nfull = tm0 * tiles_n; mn.nmini = VC_CEIL_DIV(c.p.M - tm0 * GD_BM, MH) * tiles_n; }
+    }
+    const int total_items = mn.nfull + mn.nmini;
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW, BK>), dim3(total_items < cus ? total_items : cus), dim3(NW * 64), (GdTile<BN, BK>::LDS_BYTES), s, c.p, tiles_n, tiles_mn, nsplit, total_items, xn, c.claim, mn);
     }
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;

@@ -264,6 +264,21 @@ int vc_transpose_bf16(const vc_bf16* src, vc_bf16* dst, int rows, int cols, vc_s
     return VC_OK;
 }
 
+int vc_transpose_bf16_batched(const vc_bf16* S, vc_bf16* D, const long* src_off, const long* dst_off, const int* rows, const int* cols, int n, vc_stream_t s) {
+    for (int j0 = 0; j0 < n; j0 += 32) {
+        TransposeBatch tb = TransposeBatch();
+        tb.n = n - j0 < 32 ? n - j0 : 32;
+        int tiles = 0;
+        for (int j = 0; j < tb.n; ++j) {
+            tb.tile_start[j] = tiles; tb.src_off[j] = src_off[j0 + j]; tb.dst_off[j] = dst_off[j0 + j]; tb.rows[j] = rows[j0 + j]; tb.cols[j] = cols[j0 + j];
+            tiles += VC_CEIL_DIV(rows[j0 + j], 64) * VC_CEIL_DIV(cols[j0 + j], 64);
+        }
+        tb.tile_start[tb.n] = tiles;
+        if (tiles) VC_LAUNCH(transpose_bf16_batched_kernel, dim3((unsigned)tiles), dim3(256), 0, s, S, D, tb);
+    }
+    return VC_OK;
+}
+
 int vc_loss_fwd(LossParams p, vc_stream_t s) {
     ProfScope ps(VC_CAT_LOSS, 0, (double)p.M * (VC_NPARAM * VC_NVAL + VC_NCMD) * 4, s);
     VC_LAUNCH(loss_rows_kernel, dim3((unsigned)VC_CEIL_DIV(p.M * VC_NPARAM, 4)), dim3(256), 0, s, p);

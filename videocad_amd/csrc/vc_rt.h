@@ -94,6 +94,14 @@ VC_DEV vc_s16x4 vc_ds_read_tr16(const void* lds_ptr) {
 VC_DEV void vc_dma16(const void* gsrc, void* lds_piece) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
 }
+// L2 warm-up of one cache line per lane (r06, attn_mfma.h): a 4-byte direct-to-LDS DMA into a 256-byte wave-private sink nobody reads — no destination
+// register, so nothing ever waits for it except a vmcnt(0); written as asm so that hipcc does not order later LDS reads behind it (it only makes the
+// compiler's own counted waits conservative: the untracked operation is older than anything they count).  Respects the exec mask.
+VC_DEV void vc_prefetch_line(const void* gsrc, void* lds_sink) {
+    unsigned keep;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)lds_sink);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
 VC_DEV float vc_expf_fast(float x) { return __expf(x); }
 // a product that is rounded on its own: hipcc contracts `a * b - c` (and __fmul_rn, which is a plain multiply in the IR) into one FMA
 VC_DEV float vc_mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

@@ -17,6 +17,7 @@ VCAD_F32, VCAD_BF16, VCAD_BF16X3, VCAD_F16 = 0, 1, 2, 3
 # kernel-selection flags (include/vcad.h VCAD_GEMM_*; tests only) and kernel families (vcad_kernel_launches / vcad_op_gemm kernel_out)
 GEMM_TILE64, GEMM_TILE128, GEMM_DMA_NEVER, GEMM_DMA_ALWAYS, GEMM_WIDE_NEVER, GEMM_WIDE_ALWAYS, GEMM_MID_NEVER, GEMM_MID_ALWAYS = 1, 2, 4, 8, 16, 32, 64, 128
 GEMM_DYNAMIC = 1 << 16
+GEMM_MINI_NEVER, GEMM_MINI_ALWAYS = 1 << 21, 1 << 22      # persistent kernel: mini tiles for the rows of a mostly empty last round (automatic otherwise)
 
 
 def gemm_reserve_cus(n8):
@@ -118,7 +119,7 @@ PROTOTYPES = {
 AB_PROTOTYPES = {name: (None, [_i]) for name in (
     "vcad_debug_force_gemm_tile", "vcad_debug_gemm_dma", "vcad_debug_gemm_wide", "vcad_debug_gemm_mid", "vcad_debug_gemm_xcd_cols",
     "vcad_debug_attn_variant", "vcad_debug_gemm_waves", "vcad_debug_split_gelu", "vcad_debug_no_side_stream", "vcad_debug_gemm_policy",
-    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip", "vcad_debug_res_in_ln", "vcad_debug_wgrad_bk32", "vcad_debug_cls_path", "vcad_debug_frame_first", "vcad_debug_pe_fold", "vcad_debug_dec_h16")}
+    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip", "vcad_debug_res_in_ln", "vcad_debug_wgrad_bk32", "vcad_debug_cls_path", "vcad_debug_frame_first", "vcad_debug_pe_fold", "vcad_debug_dec_h16", "vcad_debug_attn_prefetch")}
 AB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_bin", "libvcad_ab.so")
 
 
