@@ -92,6 +92,12 @@ int vcad_set_workspace(vcad_engine* e, void* workspace, size_t bytes);
  * Re-plans the workspace: call before the next forward.  vcad_grad_scale: the value in force (after a plan in automatic mode: that plan's). */
 int vcad_set_grad_scale(vcad_engine* e, float scale);
 float vcad_grad_scale(const vcad_engine* e);
+/* r06, the native train step (forward, vcad_loss, vcad_backward*, vcad_optimizer_step* with nothing reading gradients or dlogits in between): with on = 1 the gradient
+ * buckets stay multiplied by the gradient scale until the optimiser — its norm pass and Adam divide, exactly, and Adam writes the true gradient back, so the buffer
+ * holds true gradients again once the step is through — instead of five passes over the gradient buffer, and vcad_loss writes scale x dlogits straight into the
+ * backward's private copy (the tensors at vcad_dlogits_offsets are then NOT written).  Bucket callbacks and data-parallel exchanges would see scaled gradients in
+ * this mode; the default (0) keeps true gradients in the buffer after every stage. */
+int vcad_set_defer_unscale(vcad_engine* e, int on);
 
 /* VCAD_FP8 forward mode (bf16 engines): the four Linear layers of every full ViT layer run on the block-scaled fp8 matrix cores
  * (MXFP8: e4m3 elements, one E8M0 scale per 32 k-values, fp32 accumulate); weights are re-quantised from the fp32 master after every

@@ -80,6 +80,35 @@ def test_f16_gradients_are_true_gradients_at_any_scale(golden_dir):
     assert max(err.values()) < 1.5e-2, err
 
 
+def test_f16_deferred_unscale_is_bit_identical():
+    """r06 (vcad_set_defer_unscale, what the single-rank trainer turns on around its step): the buckets stay scaled until the optimiser, the loss writes the scaled
+    dlogits itself — seven passes fewer, and the SAME update bit for bit: weights, moments, the 16-bit shadow and the gradient norm of two consecutive steps."""
+    batch = synth.make_batch_torch(2, 8, 3, DEV)
+
+    def run(defer):
+        eng = build(); eng.set_dropout(0.1, 7)
+        out = []
+        for step in range(2):
+            if defer:
+                eng.set_defer_unscale(True)
+            cmds, pars = eng.forward(batch["frames"][:, :-1], O.normalize_actions(batch["actions"][:, :-1]), batch["cad_image"])
+            loss, _ = eng.loss(cmds, pars, batch["actions"][:, 1:], U.LABEL_W)
+            eng.backward()
+            if defer:
+                assert eng.grad_scale > 1.0                                                    # (the buffer holds scale x gradient here)
+            norm = eng.optimizer_step(lr=1e-3)
+            if defer:
+                eng.set_defer_unscale(False)
+            out.append((loss.clone(), norm.clone(), eng.params.clone(), eng.m.clone(), eng.shadow.clone(), eng.grads.clone()))
+        return out
+    a, b = run(False), run(True)
+    for (la, na, pa, ma, sa, ga), (lb, nb, pb, mb, sb, gb) in zip(a, b):
+        assert torch.equal(la, lb) and torch.equal(na[:2], nb[:2]), (na, nb)
+        assert torch.equal(pa, pb) and torch.equal(sa, sb)
+        assert torch.equal(ma, mb)
+        assert torch.equal(ga, gb)              # Adam wrote the true gradients back: the buffer reads the same after the step
+
+
 def test_f16_overflow_skips_the_update():
     eng = build()
     batch = synth.make_batch_torch(2, 8, 3, DEV)

@@ -26,9 +26,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=4); ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--flags", nargs="*", default=["mini_never", "0"])
     ap.add_argument("--knob", default=None, help="A/B build: name of a vcad_debug_* setter; the legs are --values instead of --flags")
+    ap.add_argument("--attr", default=None, help="trainer attribute set to each of --values in turn (e.g. defer_unscale)")
     ap.add_argument("--values", type=int, nargs="*", default=[0, 1])
     a = ap.parse_args()
-    if a.knob:
+    if a.knob or a.attr:
         a.flags = [str(v) for v in a.values]
     dev = "cuda:0"
     model, tr = BI.build_trainer(a.dtype, 0.1, dev, 0)
@@ -40,7 +41,9 @@ def main():
     res = {f: [] for f in a.flags}
     for r in range(a.rounds):
         for f in a.flags:
-            if a.knob:
+            if a.attr:
+                setattr(tr, a.attr, int(f))
+            elif a.knob:
                 getattr(L.load_ab(), a.knob)(int(f))
             else:
                 eng.set_gemm_flags(NAMES[f])

@@ -106,6 +106,11 @@ struct vcad_engine {
     // divided again — exactly — by the launch that finalises it), so that activation gradients of 1e-6..1e-8 stay inside fp16's normal range.  1 = off.
     float grad_scale = 1.0f; float *dls_cmds = nullptr, *dls_pars = nullptr;
     bool grad_scale_auto = false;      // fp16 engines until vcad_set_grad_scale names a value: the scale follows the planned batch (plan())
+    // vcad_set_defer_unscale (r06, the native train step): the buckets stay scaled until the optimiser — the gradient-norm pass and Adam multiply by 1 / scale, and Adam
+    // writes g / scale back (one more store stream in a pass that reads g anyway) instead of five read-modify-write passes over the gradient buffer — and vcad_loss
+    // writes the scaled dlogits itself (two more passes).
+    // Exact either way (a power of two).  grads_scaled_by: scale of the backward whose gradients sit in G still scaled (0 = G holds true gradients).
+    bool defer_unscale = false; float grads_scaled_by = 0.0f; bool dls_valid = false;
     const float* bwd_dcmds = nullptr; const float* bwd_dpars = nullptr;
     // dropout (train mode): probability and the seed of the CURRENT forward (the backward regenerates the same masks)
     float drop_p = 0.f; uint64_t drop_seed = 0;
@@ -1070,6 +1075,7 @@ int build_deferred(const Ctx& cx, const float* tgt0) {
 // fp16 build: bucket b is complete on `on` — divide the gradient scale out again (exact: a power of two)
 int unscale_bucket(vcad_engine* e, int b, vc_stream_t on) {
     if (e->grad_scale == 1.0f) return 0;
+    if (e->defer_unscale) { e->grads_scaled_by = e->grad_scale; return 0; }       // (the optimiser divides: vcad_optimizer_step_groups)
     const long lo = e->buckets[b].first, hi = e->buckets[b].second;
     return vc_scale(e->G + lo, e->G + lo, hi - lo, 1.0f / e->grad_scale, on);
 }
@@ -1085,7 +1091,8 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     const float* tgt0 = pa ? e->act : (ps ? e->ui : e->mem);
     const int sa_window = pa ? T : c.window_size;
     if (e->grad_scale != 1.0f) {
-        CK(vc_scale(dcmds, e->dls_cmds, M * n5, e->grad_scale, s)); CK(vc_scale(dpars, e->dls_pars, M * n6, e->grad_scale, s));
+        // (deferred mode: vcad_loss of this forward already wrote scale x dlogits there)
+        if (!(e->dls_valid && dcmds == e->dl_cmds && dpars == e->dl_pars)) { CK(vc_scale(dcmds, e->dls_cmds, M * n5, e->grad_scale, s)); CK(vc_scale(dpars, e->dls_pars, M * n6, e->grad_scale, s)); }
         dcmds = e->dls_cmds; dpars = e->dls_pars;
     }
     CK(cx.lin_wgrad(cx.A32(dcmds, n5), cx.A32(xf, H), cx.Gf(e->o_h5_w), H, cx.Gf(e->o_h5_b), (int)M, n5, H));
@@ -1231,6 +1238,11 @@ int vcad_set_grad_scale(vcad_engine* e, float scale) {
     return 0;
 }
 float vcad_grad_scale(const vcad_engine* e) { return e->grad_scale; }
+int vcad_set_defer_unscale(vcad_engine* e, int on) {
+    if (e->grads_scaled_by != 0.0f && !on) { vc_set_error("vcad_set_defer_unscale: the gradient buffer still holds scaled gradients (run the optimiser step first)"); return VC_ERR_ARG; }
+    e->defer_unscale = on != 0; e->dls_valid = false;
+    return 0;
+}
 
 int vcad_engine_create(const vcad_config* cfg, vcad_engine** out) {
     if (!cfg || !out) { vc_set_error("null argument"); return VC_ERR_ARG; }
@@ -1402,7 +1414,7 @@ static int forward_any(vcad_engine* e, const void* frames, int64_t fbstride, con
         e->planned_ws = e->ws; e->infer_T = 0;
     }
     e->B = B; e->T = T; e->in_frames = frames; e->in_fbstride = fbstride; e->in_actions = actions; e->in_cad = cad; e->in_u8 = u8;
-    e->fwd_valid = false;
+    e->fwd_valid = false; e->dls_valid = false;
     int rc = engine_forward(e, cmds_out, pars_out, (vc_stream_t)stream);
     if (rc) return rc;
     if (vc_last_launch_error()) { vc_set_error("vcad_forward: kernel launch failed"); return VC_ERR_LAUNCH; }
@@ -1424,7 +1436,11 @@ static void fill_loss_params(vcad_engine* e, LossParams& p, const float* cmds, c
     p.class_w = class_w;
     p.row_num = e->loss_rows; p.row_den = e->loss_rows + M * 7; p.row_lse = e->loss_rows + 2 * M * 7; p.row_arg = e->loss_arg;
     p.loss_out = e->loss_small; p.scales = e->loss_small + 16; p.metrics = e->loss_metrics;
-    p.dcmds = e->dl_cmds; p.lddc = c.num_classes; p.dpars = e->dl_pars; p.lddp = p.ldp;
+    p.dcmds = e->dl_cmds; p.lddc = c.num_classes; p.dpars = e->dl_pars; p.lddp = p.ldp; p.gmul = 1.0f;
+    e->dls_valid = false;
+    if (e->defer_unscale && e->grad_scale != 1.0f && e->dls_cmds) {      // the dlogits pass writes scale x dlogits where the backward looks for them (dl_* stay stale: native train step only)
+        p.dcmds = e->dls_cmds; p.dpars = e->dls_pars; p.gmul = e->grad_scale; e->dls_valid = true;
+    }
 }
 
 int vcad_loss(vcad_engine* e, const float* cmds, const float* pars, const float* targets, int B, int T, int use_mse,
@@ -1700,6 +1716,9 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
     CK(need_device(e, "vcad_optimizer_step"));
     if (e->B == 0) plan(e, 1, 1, e->ws);
     vc_stream_t s = (vc_stream_t)stream;
+    // (deferred unscale, fp16 engines: the last backward left scale x gradient in G — exact division by a power of two, here instead of in five passes over G)
+    const float unscale = e->grads_scaled_by != 0.0f ? 1.0f / e->grads_scaled_by : 0.0f;     // (Adam writes g / scale back: the buffer holds true gradients again after the step)
+    if (unscale != 0.0f) { gscale *= unscale; e->grads_scaled_by = 0.0f; }
     // the norm the reference clips against is that of the (already averaged) gradients
     CK(vc_grad_norm(e->G, e->ptotal, max_norm, gscale, e->norm_part, e->norm_out, s));
     // one launch per run of buckets that share a learning rate (the reference's `frozen` mode, trainer.py:237-251, gives the CAD ViT,
@@ -1711,6 +1730,7 @@ int vcad_optimizer_step_groups(vcad_engine* e, const float* lr_bucket, float b1,
         a.p = e->P + lo; a.g = e->G + lo; a.m = e->Mm + lo; a.v = e->Vv + lo; a.n = hi - lo; a.lr = lr_bucket[b0]; a.beta1 = b1; a.beta2 = b2; a.eps = eps;
         a.bc1 = 1.0f - powf(b1, (float)step); a.bc2 = 1.0f - powf(b2, (float)step);
         a.clip = max_norm > 0.f ? e->norm_out + 1 : nullptr; a.finite = e->c.dtype == VCAD_F16 ? e->norm_out + 2 : nullptr; a.gscale = gscale; a.shadow = e->S ? e->S + lo : nullptr; a.shadow_pk = e->Spk ? e->Spk + lo : nullptr;
+        if (unscale != 0.0f) { a.gw = e->G + lo; a.gw_mul = unscale; }
         CK(vc_adam(a, s));
         b0 = b1i + 1;
     }

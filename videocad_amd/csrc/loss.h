@@ -35,6 +35,7 @@ struct LossParams {
     float* scales;                      // [7]: per-head dlogit scale (params 0..5, cmd)
     int* metrics;                       // [VC_NMETRIC]
     float* dcmds; long lddc; float* dpars; long lddp;
+    float gmul;                         // dlogits are written times this (fp16 engines in deferred-unscale mode: the gradient scale, a power of two; else 1)
 };
 
 VC_KERNEL __launch_bounds__(256) void loss_rows_kernel(LossParams p) {
@@ -150,7 +151,7 @@ VC_KERNEL __launch_bounds__(256) void loss_dlogits_kernel(LossParams p) {
     const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= p.M * 7) return;
     const long m = wid / 7; const int h = (int)(wid % 7);
-    const float den = p.row_den[m * 7 + h], lse = p.row_lse[m * 7 + h], sc = p.scales[h];
+    const float den = p.row_den[m * 7 + h], lse = p.row_lse[m * 7 + h], sc = p.scales[h] * p.gmul;
     if (h == 6) {
         const int t = (int)p.targets[m * 7];
         if (lane < VC_NCMD) {

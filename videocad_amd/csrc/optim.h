@@ -52,13 +52,18 @@ struct AdamParams {
     const float* finite;                        // device scalar (norm_out + 2): 0 = the gradient norm is inf / NaN -> leave p, m, v alone
     vc_bf16* shadow;                            // optional bf16 copy of p (same flat offsets)
     uint32_t* shadow_pk;                        // optional pre-split (hi | lo bf16) copy of p for the bf16x3 GEMMs (gemm.h vc_pk)
+    float* gw; float gw_mul;                    // optional (fp16 engines, deferred unscale): g[i] is written back as g[i] * gw_mul — the buffer holds true gradients again after the step
 };
 VC_KERNEL __launch_bounds__(256) void adam_kernel(AdamParams a) {
-    if (a.finite && a.finite[0] == 0.0f) return;
+    if (a.finite && a.finite[0] == 0.0f) {       // skipped update: only the write-back (the values are those of an overflowed backward either way)
+        if (a.gw) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) a.gw[i] = a.g[i] * a.gw_mul;
+        return;
+    }
     const float c = (a.clip ? a.clip[0] : 1.0f) * a.gscale;
     const float step = a.lr / a.bc1, rs2 = 1.0f / sqrtf(a.bc2);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long)gridDim.x * 256) {
-        const float g = a.g[i] * c;
+        const float g0 = a.g[i], g = g0 * c;
+        if (a.gw) a.gw[i] = g0 * a.gw_mul;
         const float m = a.beta1 * a.m[i] + (1.0f - a.beta1) * g;
         const float v = a.beta2 * a.v[i] + (1.0f - a.beta2) * g * g;
         const float p = a.p[i] - step * (m / (sqrtf(v) * rs2 + a.eps));

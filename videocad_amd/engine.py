@@ -111,6 +111,11 @@ class NativeEngine:
         gradient buffer holds true ones.  Re-plans the workspace on the next forward."""
         L.check(self.lib, self.lib.vcad_set_grad_scale(self.h, float(scale)), "set_grad_scale")
 
+    def set_defer_unscale(self, on: bool):
+        """fp16 engines, the native train step only (include/vcad.h: vcad_set_defer_unscale): gradients stay multiplied by the gradient scale until the optimiser divides
+        (exactly) in its norm pass and in Adam; the loss writes scaled dlogits straight into the backward's copy.  Nothing may read gradients or dlogits in between."""
+        L.check(self.lib, self.lib.vcad_set_defer_unscale(self.h, 1 if on else 0), "set_defer_unscale")
+
     GROW_AFTER = 2000                 # finite steps in a row before a lowered scale is doubled again (torch.amp.GradScaler's growth_interval)
 
     def note_overflows(self, bad: int, steps: int, ran_at_scale: Optional[float] = None) -> bool:

@@ -57,6 +57,7 @@ PROTOTYPES = {
     "vcad_storage_format": (C.c_char_p, []),
     "vcad_set_grad_scale": (_i, [_vp, _f]),
     "vcad_grad_scale": (_f, [_vp]),
+    "vcad_set_defer_unscale": (_i, [_vp, _i]),
     "vcad_engine_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
     "vcad_engine_destroy": (None, [_vp]),
     "vcad_param_total": (_i64, [_vp]),

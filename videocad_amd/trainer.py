@@ -456,6 +456,7 @@ class BaseTrainer:
         # The reference "reloads" best_model_state at the end of train() (:370-380), but that state dict aliases the live parameters, so the
         # model it returns holds the LAST weights.  Default = that behaviour; restore_best_weights=True copies the best epoch's weights back.
         self.restore_best_weights = cfg("restore_best_weights", False)
+        self.defer_unscale = cfg("defer_unscale", True)          # fp16 engines, single rank: the optimiser divides the gradient scale out (train_step)
         self.stage_inputs = cfg("stage_inputs", True)             # double-buffered H2D staging of the train loader (data.DeviceStager)
         self.native._drop_rank = rank                             # every rank draws its own dropout masks
         self.gradsync = GradSync(self.engine, on_params_changed=self._params_changed, force_staged=cfg("force_bucketed_exchange", False),
@@ -541,11 +542,18 @@ class BaseTrainer:
         if not self.native._shadow_fresh:
             eng.sync_shadow()
         self.native._arm_dropout()                               # model.train() -> dropout active, like the reference's train loop
+        # fp16 engines, single rank: nothing reads gradients or dlogits between the loss and the optimiser here, so the gradient scale is divided out by the optimiser's
+        # own passes instead of seven extra ones (include/vcad.h: vcad_set_defer_unscale; bit-identical updates).  Data-parallel runs keep true gradients in the buckets.
+        defer = eng.cfg.dtype == L.VCAD_F16 and not self.gradsync.staged and self.defer_unscale
+        if defer:
+            eng.set_defer_unscale(True)
         cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"], inputs.get("multiview_images") if self.native.num_views > 0 else None)
         out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
         self.gradsync.backward()
         norm = eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
                                   grad_scale=1.0 / self.gradsync.world)
+        if defer:
+            eng.set_defer_unscale(False)
         self.native.mark_shadow_fresh()
         if eng.cfg.dtype == L.VCAD_F16:
             self._watch_overflow(norm)
