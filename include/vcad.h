@@ -272,6 +272,7 @@ void vcad_debug_wgrad_bk32(int on);          /* 256-wide weight-gradient kernel:
 void vcad_debug_cls_path(int on);            /* 16-bit engines, last ViT layer: class-token attention on (q W_k, normalised tokens) (1, default: r06, csrc/attn_cls.h) or K / V projections of all tokens (0: r05) */
 void vcad_debug_dec_h16(int on);             /* 16-bit engines: decoder LayerNorms also emit 16-bit copies for the Linears / deferred weight gradients behind them (1, default: r06) or not (0: r05) */
 void vcad_debug_pe_fold(int on);             /* 16-bit engines: patch-embedding LayerNorm affine folded into its Linear (1, default: r06) or applied to the patches with a dgrad + LayerNorm backward for its gradients (0: r05) */
+void vcad_debug_splitk_r06(int on);       /* register-staged GEMM, k-slice rule: 0 (default: r04's) or 1 (r06 experiment: a k-tile priced at the 1.4 / 3 us it lasts in the model, up to 512 tiles — measured slower, profiles/r06_splitk_rule_ab.txt) */
 void vcad_debug_attn_prefetch(int frames); /* ViT attention backward: 0 (default) or: every workgroup warms the L2 for the (frame + frames, head) pair of a later workgroup on its XCD — r06 experiment, measured slower (profiles/r06_attn_prefetch_ab.txt) */
 void vcad_debug_frame_first(int on);         /* whole backward with the side stream forked: frame tower's upper stage enqueued before the CAD tower's stage (1, default: r06) or after (0: r05) */
 #endif

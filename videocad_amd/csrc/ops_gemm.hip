@@ -180,7 +180,7 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
     const int BT = small ? 64 : 128;
     long tiles = (long)VC_CEIL_DIV(p.M, BT) * VC_CEIL_DIV(p.N, BT);
     int nsplit = 1;
-    if (scratch && tiles < 256 && p.K >= 8 * BK) {
+    if (scratch && tiles < (VC_AB(splitk_r06, 0) ? 512 : 256) && p.K >= 8 * BK) {
         // k-slices: two workgroups are co-resident per CU (512 slots).  r01-r03 took ceil(512 / tiles) slices — for 96 tiles (the ViT's QKV weight
         // gradient in the fp32 / bf16x3 modes) that is 6 slices = 576 workgroups: a full round plus a 64-workgroup tail, i.e. two rounds of K / 6 each
         // (1 373 us per call in the bf16x3 mode, profiles/r04_x3_kernel_shapes.txt).  Now: the slice count that minimises rounds x slice length.
@@ -190,7 +190,12 @@ int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s) {
         if ((size_t)maxs * per > scratch_bytes) maxs = (int)(scratch_bytes / per);
         // cost in units of "one workgroup walking the whole K": rounds(ns) / ns for the k-loop + ns slab round trips (write + read of the fp32 tile
         // grid at ~5 TB/s against ~0.3 us per k-tile of a workgroup)
-        const double t_full = (double)(p.K / BK) * 0.3, slab = (double)p.M * p.N * 8.0 / 5.0e6 / (t_full > 1e-9 ? t_full : 1e-9);
+        // r06 experiment (A/B build: vcad_debug_splitk_r06): in the model a k-tile of this kernel lasts ~1.4 us with 16-bit operands and ~3 us with an fp32 source (decoder
+        // dgrads: 16 k-tiles in 22 us; the stem's fp32-source weight gradients: 32 k-tiles in 105 us), not 0.3 us — so price it that way and let problems of up to 512
+        // tiles split?  Measured SLOWER: +0.66 % on the C2 step, +0.12 % at T = 186 (profiles/r06_splitk_rule_ab.txt): the extra slab round trips and reduce launches sit
+        // on the critical path, the long k-loops they shorten mostly do not (the stem's weight gradients overlap the side stream's work).  r04's rule stays.
+        const double kt_us = VC_AB(splitk_r06, 0) ? ((c.sa == VC_F32 || c.sb == VC_F32) ? 3.0 : 1.4) : 0.3;
+        const double t_full = (double)(p.K / BK) * kt_us, slab = (double)p.M * p.N * 8.0 / 5.0e6 / (t_full > 1e-9 ? t_full : 1e-9);
         double best = 1e30;
         for (int ns = 1; ns <= maxs; ++ns) {
             const double cost = (double)VC_CEIL_DIV(tiles * ns, 512) / ns + slab * ns;
