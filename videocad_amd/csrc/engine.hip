@@ -1090,6 +1090,7 @@ int backward_stage0(vcad_engine* e, const float* dcmds, const float* dpars, vc_s
     const bool pa = c.enable_past_actions, ps = c.enable_past_states, tsE = c.enable_timestep_embedding;
     const float* tgt0 = pa ? e->act : (ps ? e->ui : e->mem);
     const int sa_window = pa ? T : c.window_size;
+    e->grads_scaled_by = 0.0f;                 // (this backward rewrites every bucket)
     if (e->grad_scale != 1.0f) {
         // (deferred mode: vcad_loss of this forward already wrote scale x dlogits there)
         if (!(e->dls_valid && dcmds == e->dl_cmds && dpars == e->dl_pars)) { CK(vc_scale(dcmds, e->dls_cmds, M * n5, e->grad_scale, s)); CK(vc_scale(dpars, e->dls_pars, M * n6, e->grad_scale, s)); }
@@ -1239,7 +1240,8 @@ int vcad_set_grad_scale(vcad_engine* e, float scale) {
 }
 float vcad_grad_scale(const vcad_engine* e) { return e->grad_scale; }
 int vcad_set_defer_unscale(vcad_engine* e, int on) {
-    if (e->grads_scaled_by != 0.0f && !on) { vc_set_error("vcad_set_defer_unscale: the gradient buffer still holds scaled gradients (run the optimiser step first)"); return VC_ERR_ARG; }
+    // (turned off while the buffer still holds scaled gradients — a train step that raised between its backward and its optimiser step: the next optimiser step still
+    // divides, the next backward rewrites the buffer with true gradients)
     e->defer_unscale = on != 0; e->dls_valid = false;
     return 0;
 }

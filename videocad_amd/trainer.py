@@ -547,13 +547,15 @@ class BaseTrainer:
         defer = eng.cfg.dtype == L.VCAD_F16 and not self.gradsync.staged and self.defer_unscale
         if defer:
             eng.set_defer_unscale(True)
-        cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"], inputs.get("multiview_images") if self.native.num_views > 0 else None)
-        out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
-        self.gradsync.backward()
-        norm = eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
-                                  grad_scale=1.0 / self.gradsync.world)
-        if defer:
-            eng.set_defer_unscale(False)
+        try:
+            cmds, pars = eng.forward(inputs["frames"], inputs["actions"], inputs["cad_image"], inputs.get("multiview_images") if self.native.num_views > 0 else None)
+            out, met = eng.loss(cmds, pars, bd["actions"][:, 1:], self._label_w(), use_mse=self.use_mse, class_weights=self._class_w())
+            self.gradsync.backward()
+            norm = eng.optimizer_step(lr=self.optimizer.lr, betas=self.optimizer.betas, eps=self.optimizer.eps, max_norm=1.0,
+                                      grad_scale=1.0 / self.gradsync.world)
+        finally:
+            if defer:
+                eng.set_defer_unscale(False)                     # (also when the step raised: everything outside train_step sees true gradients and dlogits)
         self.native.mark_shadow_fresh()
         if eng.cfg.dtype == L.VCAD_F16:
             self._watch_overflow(norm)
