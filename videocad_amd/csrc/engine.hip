@@ -518,8 +518,8 @@ struct Ctx {
     int ln_bwd(int td, const void* dy, long lddy, const float* x, long ldx, const float* stats, long wo, long bo,
                const float* add_in, long ldadd, float* dx32, long lddx, long rows, int C,
                vc_drop d = vc_drop{0u, 0u, 1.0f}, Mat* du = nullptr, void* du_dst = nullptr, float* du_colsum = nullptr, float* defer_partial = nullptr,
-               bool du_pk = false, vc_drop d32 = vc_drop{0u, 0u, 1.0f}) const {
-        LnBwdParams p; memset(&p, 0, sizeof(p)); p.drop32 = d32;
+               bool du_pk = false, vc_drop d32 = vc_drop{0u, 0u, 1.0f}, int add_period = 0) const {
+        LnBwdParams p; memset(&p, 0, sizeof(p)); p.drop32 = d32; p.add_period = add_period;
         p.dy = dy; p.lddy = lddy; p.x = x; p.ldx = ldx; p.stats = stats; p.gamma = Pf(wo);
         p.add_in = add_in; p.ldadd = ldadd; p.dx32 = dx32; p.lddx32 = lddx; p.rows = rows;
         if (du) {
@@ -762,8 +762,11 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
     // r06: emb_dropout's backward mask applied by layer 0's norm backward — when THIS call both walks layer 0 and runs the embedding's backward
     const bool emb_in_ln = e->dt == VC_BF16 && e->ct == VC_BF16 && part != 1 && Llo == 0 && Lhi >= 0;
     if (defer_cs && !e->vcs[v][part].ready) CK(build_vit_colsums(cx, v, part));
+    // The class-token-only last layer leaves the stream gradient on class rows only.  r01-r05 cleared all of dx first and the layer's attention-norm backward read
+    // the zeros back; 16-bit engines with more than one layer now tell that pass which rows exist (LnBwdParams::add_period): no 210 MB memset, no 210 MB of zeros read.
+    const bool sparse_dx = e->dt == VC_BF16 && e->ct == VC_BF16 && c.vit_depth > 1 && part != 2;
     if (part != 2) {
-        CK(vc_memset_async(dx, 0, (size_t)R * D * 4, cx.s));
+        if (!sparse_dx) CK(vc_memset_async(dx, 0, (size_t)R * D * 4, cx.s));
         const float* xl = a.L[c.vit_depth - 1].xo;
         CK(cx.ln_bwd(VC_F32, de, D, xl, (long)(P + 1) * D, a.statn, w.normw, w.normb, nullptr, 0, dx, (long)(P + 1) * D, N, D));
     }
@@ -840,7 +843,8 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         }
         // (the layer below is never the cls-only one: the du it receives is pre-split whenever the mode stores pre-split tensors)
         if (L > Llo || (part == 1 && L > 0)) {
-            CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), defer_cs ? l.part_an : nullptr, cx.pk_acts())); have_du = true;
+            CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, xin, D, l.stat_a, wl.anw, wl.anb, dx, D, dx, D, R, D, cx.site(v + 1, L - 1, Ctx::K_MLP_OUT), &du, nullptr, cx.Gf(w.l[L - 1].b4), defer_cs ? l.part_an : nullptr, cx.pk_acts(),
+                         vc_drop{0u, 0u, 1.0f}, sparse_dx && cls_only ? P + 1 : 0)); have_du = true;
             if (L == Llo && v == 0) { e->du_carry = true; e->du_carry_mat = du; }        // stage boundary: the lower stage (vit_backward part 2, next call) starts from this du
         }
         // bottom layer: the embedding dropout (everything below sees dx * mask) rides on this pass's fp32 output (16-bit engines; norm.h LnBwdParams::drop32)

@@ -185,6 +185,8 @@ struct LnBwdParams {
     const float* stats;               // [rows][2]
     const float* gamma;
     const float* add_in; long ldadd;  // optional fp32 tensor added to dx (the residual-path gradient)
+    int add_period;                   // r06: > 1 = add_in is defined on rows that are multiples of it only and ZERO elsewhere (the class-token-only last ViT layer: the stream gradient
+                                      // exists on class rows; r05 cleared the other 49 of 50 rows with a 210 MB memset that this pass then read back)
     float* dx32; long lddx32;         // optional fp32 dx output (may alias add_in)
     void* dxt; long lddxt;            // optional T dx output; with drop.key != 0 it is dx * dropout-mask(row * C + c): the masked
     vc_drop drop;                     //   gradient the next (dropped) Linear's wgrad / dgrad consume, fused here instead of a separate pass
@@ -227,7 +229,7 @@ VC_KERNEL __launch_bounds__(256) void ln_bwd_kernel(LnBwdParams p) {
             float dx[VPL];
 #pragma unroll
             for (int i = 0; i < VPL; ++i) dx[i] = rstd * (dy[i] - c1 - x[i] * c2);
-            if (p.add_in) {
+            if (p.add_in && (p.add_period <= 1 || row % p.add_period == 0)) {
                 float a[VPL];
                 row_load<float, VPL>(p.add_in + row * p.ldadd, a, lane);
 #pragma unroll
