@@ -273,6 +273,7 @@ void vcad_debug_cls_path(int on);            /* 16-bit engines, last ViT layer: 
 void vcad_debug_dec_h16(int on);             /* 16-bit engines: decoder LayerNorms also emit 16-bit copies for the Linears / deferred weight gradients behind them (1, default: r06) or not (0: r05) */
 void vcad_debug_pe_fold(int on);             /* 16-bit engines: patch-embedding LayerNorm affine folded into its Linear (1, default: r06) or applied to the patches with a dgrad + LayerNorm backward for its gradients (0: r05) */
 void vcad_debug_splitk_r06(int on);       /* register-staged GEMM, k-slice rule: 0 (default: r04's) or 1 (r06 experiment: a k-tile priced at the 1.4 / 3 us it lasts in the model, up to 512 tiles — measured slower, profiles/r06_splitk_rule_ab.txt) */
+void vcad_debug_batch_wgrad(int on);      /* 16-bit engines, train mode, full ViT layers: net.4 / net.0 / to_out weight gradients in ONE launch of the persistent kernel (1, default: r06) or three (0: r05) */
 void vcad_debug_attn_prefetch(int frames); /* ViT attention backward: 0 (default) or: every workgroup warms the L2 for the (frame + frames, head) pair of a later workgroup on its XCD — r06 experiment, measured slower (profiles/r06_attn_prefetch_ab.txt) */
 void vcad_debug_frame_first(int on);         /* whole backward with the side stream forked: frame tower's upper stage enqueued before the CAD tower's stage (1, default: r06) or after (0: r05) */
 #endif
@@ -282,6 +283,10 @@ int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A
                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const float* bias, int act,
                  const float* residual, int64_t ldr, float alpha, float* scratch, size_t scratch_bytes, uint32_t flags /* VCAD_GEMM_* */,
                  int* kernel_out /* optional: kernel family that ran */, void* stream);
+/* r06: n (<= 4) weight gradients dW_i[N_i, K_i] (fp32) = dY_i[tok, N_i]^T X_i[tok, K_i] (16-bit, compact rows) over the SAME tok rows in one launch of the persistent kernel —
+ * what the engine does with a full ViT layer's net.4 / net.0 / to_out weight gradients.  N_i % 8 == 0, K_i % 256 == 0, tok % 64 == 0. */
+int vcad_op_wgrad_batched(int n, const void* const* dY, const void* const* X, float* const* dW, const int* N, const int* K, int tok,
+                          float* scratch, size_t scratch_bytes, uint32_t flags, void* stream);
 /* y[i] = (RNE bf16(x[i]) << 16) | RNE bf16(x[i] - hi): the pre-split operand word of the bf16x3 GEMMs (storage type 3 as vcad_op_gemm's `sb`,
  * forward / dgrad layouts; bit-identical results to splitting inside the kernel, which is what an fp32 `sb` does) */
 int vcad_op_pack_x3(const float* x, void* y, int64_t n, void* stream);

@@ -171,6 +171,27 @@ def check_gemm(lib, device, M, N, K, ct, sa=None, to=None, sb=None, tra=0, trb=0
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm
+def check_wgrad_batched(lib, device, tok, shapes, seed=0, flags=0, dt=torch.bfloat16):
+    """vcad_op_wgrad_batched: dW_i = dY_i^T X_i for every (N_i, K_i) of `shapes` over the same `tok` rows, one launch — against fp32 matmuls of the rounded operands"""
+    import ctypes as C_
+    n = len(shapes)
+    dYs = [rnd((tok, N), device, seed=seed + 11 * i).to(dt) for i, (N, K) in enumerate(shapes)]
+    Xs = [rnd((tok, K), device, seed=seed + 11 * i + 5).to(dt) for i, (N, K) in enumerate(shapes)]
+    dWs = [torch.full((N, K), float("nan"), device=device) for (N, K) in shapes]
+    scratch = torch.zeros(64 + 64 * sum(N * K for N, K in shapes), dtype=torch.float32, device=device)
+    arr = lambda ts: (C_.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ints = lambda xs: (C_.c_int * n)(*xs)
+    rc = lib.vcad_op_wgrad_batched(n, arr(dYs), arr(Xs), arr(dWs), ints([s[0] for s in shapes]), ints([s[1] for s in shapes]), tok,
+                                   ptr(scratch), scratch.numel() * 4, flags, stream_of(device))
+    assert rc == 0, lib.vcad_last_error()
+    if device != "cpu":
+        torch.cuda.synchronize()
+    for dY, X, dW in zip(dYs, Xs, dWs):
+        ref = dY.float().t() @ X.float()
+        err = relerr(dW, ref)
+        assert err < 2e-5, err
+
+
 def check_layernorm(lib, device, rows, C_, dt, seed=0):
     x = rnd((rows, C_), device, seed=seed, scale=2.0) + 0.5
     g = rnd((C_,), device, seed=seed + 1, scale=0.2) + 1.0

@@ -145,6 +145,19 @@ def test_gemm_dma_kernel_mini_tiles(emu, gemm_tile, trb, to, wide, dyn):
     U.check_gemm(emu, "cpu", 200, 256, 128, BF16, sa=BF16, sb=BF16, to=to, trb=trb, pad=0, bias=True, splitk=False, flags=fl, kernel=L.KERNEL_GEMM_DMA)
 
 
+@pytest.mark.parametrize("dyn", [0, 1])
+def test_gemm_dma_kernel_batched_weight_gradients(emu, gemm_tile, dyn):
+    """r06: several weight gradients over the same token rows in ONE launch of the persistent kernel (gemm_dma.h GdBatch): a ViT layer's shapes at a small token count
+    (512 x 512, 512 x 512, 512 x 1024: 16 tiles), a ragged output height (264 rows: two tile rows, the second with 8 valid rows), a single problem, one / several k-slices"""
+    if gemm_tile != 128:
+        pytest.skip("tile-size fixture does not apply to the DMA kernel")
+    fl = L.GEMM_DYNAMIC if dyn else 0
+    U.check_wgrad_batched(emu, "cpu", 1024, [(512, 512), (512, 512), (512, 1024)], flags=fl)      # 16 tiles x 2 k-slices
+    U.check_wgrad_batched(emu, "cpu", 576, [(264, 256), (512, 512)], seed=3, flags=fl)             # ragged M; 9 k-tiles -> one slice
+    U.check_wgrad_batched(emu, "cpu", 4096, [(256, 256)], seed=5, flags=fl)                        # one problem, 8 k-slices
+    U.check_wgrad_batched(emu, "cpu", 2048, [(512, 256), (256, 512), (264, 256), (512, 512)], seed=7, flags=fl)
+
+
 @pytest.mark.parametrize("trb,to", [(0, BF16), (0, F32), (1, BF16), (1, F32)])
 def test_gemm_mid_kernel(emu, gemm_tile, trb, to):
     """the six-stage DMA-ring kernel for mid-size problems (gemm_mid.h): ragged M tail, fewer k-tiles than stages / exactly / more,

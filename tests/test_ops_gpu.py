@@ -106,6 +106,15 @@ def test_gemm_dma_kernel_mini_tiles(hip):
             U.check_gemm(hip, DEV, 20040, 512, 3072, BF16, to=BF16, trb=1, seed=rep, flags=L.GEMM_DMA_ALWAYS | L.GEMM_MINI_ALWAYS | fl, **dma)
 
 
+def test_gemm_dma_kernel_batched_weight_gradients(hip):
+    """r06: a full ViT layer's three small weight gradients (512 x 512, 512 x 512, 512 x 1024 over 102 400 token rows) in ONE launch of the persistent kernel
+    (gemm_dma.h GdBatch: 16 tiles x 16 k-slices), static lists and ticket-drawn items, three times each; a ragged / four-problem case"""
+    for rep in range(3):
+        for fl in (0, L.GEMM_DYNAMIC):
+            U.check_wgrad_batched(hip, DEV, 102400, [(512, 512), (512, 512), (512, 1024)], seed=rep, flags=fl)
+        U.check_wgrad_batched(hip, DEV, 20032, [(512, 256), (256, 512), (264, 256), (512, 512)], seed=rep + 7)
+
+
 def test_gemm_mid_kernel(hip):
     """six-stage DMA-ring kernel (gemm_mid.h) at the decoder's shapes: forward (k-contiguous W) and dgrad (row-contiguous W) layouts, fused
     epilogues, ragged M (B=16, T=186 -> 2976 rows), three times each (a mis-counted vmcnt shows up as sporadic wrong tiles); and the

@@ -24,6 +24,7 @@ struct VcAb {
     int pe_fold;       // 16-bit engines: 1 = patch-embedding LayerNorm affine folded into its Linear (r06), 0 = applied to the patches, dgrad + LayerNorm backward for its gradients (r05)
     int dec_h16;       // 16-bit engines: 1 = decoder LayerNorms also emit 16-bit copies for the Linears / deferred weight gradients behind them (r06), 0 = those read the fp32 stream (r05)
     int splitk_r06;    // register-staged kernel: 1 = r06 experiment (k-tile priced at 1.4 / 3 us, up to 512 tiles: slower), 0 = r04's rule (default)
+    int batch_wg;      // full ViT layers: 1 = net.4 / net.0 / to_out weight gradients in one launch of the persistent kernel (r06), 0 = three launches (r05)
     int attn_pf;       // ViT attention backward: L2 warm-up distance in frames (r06 experiment, slower; 0 = off, default)
     unsigned gemm_flags;   // OR-ed into every GemmCall::flags
 };

@@ -1,7 +1,7 @@
 // ab.hip — state and setters of the A/B build (see ab.h); compiled with -DVCAD_AB only, never into libvcad_hip.so.
 #include "ops.h"
 #ifdef VCAD_AB
-VcAb g_ab = {0, 0, 0, -1, 0, 8, 0, 1, 0, 0, 1, 1, 1, 1, 1, 0, 0, 0u};
+VcAb g_ab = {0, 0, 0, -1, 0, 8, 0, 1, 0, 0, 1, 1, 1, 1, 1, 0, 1, 0, 0u};
 static void setf(unsigned clear, unsigned set) { g_ab.gemm_flags = (g_ab.gemm_flags & ~clear) | set; }
 extern "C" {
 void vcad_debug_gemm_policy(int bits) { g_ab.policy = bits; }
@@ -20,6 +20,7 @@ void vcad_debug_frame_first(int on) { g_ab.frame_first = on ? 1 : 0; }
 void vcad_debug_pe_fold(int on) { g_ab.pe_fold = on ? 1 : 0; }
 void vcad_debug_dec_h16(int on) { g_ab.dec_h16 = on ? 1 : 0; }
 void vcad_debug_splitk_r06(int on) { g_ab.splitk_r06 = on ? 1 : 0; }
+void vcad_debug_batch_wgrad(int on) { g_ab.batch_wg = on ? 1 : 0; }
 void vcad_debug_attn_prefetch(int frames) { g_ab.attn_pf = frames > 0 ? frames : 0; }
 void vcad_debug_force_gemm_tile(int tile) { setf(VC_GF_TILE64 | VC_GF_TILE128, tile == 64 ? VC_GF_TILE64 : (tile == 128 ? VC_GF_TILE128 : 0u)); }
 void vcad_debug_gemm_dma(int mode) { setf(VC_GF_DMA_NEVER | VC_GF_DMA_ALWAYS, mode == 0 ? VC_GF_DMA_NEVER : (mode == 1 ? VC_GF_DMA_ALWAYS : 0u)); }

@@ -24,6 +24,26 @@ int vcad_op_gemm(int ct, int sa, int sb, int to, int tra, int trb, const void* A
     return rc;
 }
 
+// n (<= 4) weight gradients dW_i[N_i, K_i] = dY_i[tok, N_i]^T X_i[tok, K_i] over the same tok rows in ONE launch of the persistent kernel (16-bit operands, compact rows)
+int vcad_op_wgrad_batched(int n, const void* const* dY, const void* const* X, float* const* dW, const int* N, const int* K, int tok,
+                          float* scratch, size_t scratch_bytes, uint32_t flags, void* stream) {
+    if (n < 1 || n > 4) { vc_set_error("vcad_op_wgrad_batched: 1..4 problems"); return VC_ERR_ARG; }
+    GemmCall calls[4];
+    int* claim = nullptr;
+    if ((flags & VC_GF_DYNAMIC) && scratch && scratch_bytes >= 256) {
+        if (int rc = vc_memset_async(scratch, 0, 64, (vc_stream_t)stream)) return rc;
+        claim = (int*)scratch; scratch += 64; scratch_bytes -= 256;
+    }
+    for (int i = 0; i < n; ++i) {
+        GemmCall& c = calls[i]; memset(&c, 0, sizeof(c));
+        c.flags = flags; c.claim = claim; c.ct = VC_BF16; c.sa = VC_BF16; c.sb = VC_BF16; c.to = VC_F32; c.tra = 1; c.trb = 1;
+        c.p.A = dY[i]; c.p.B = X[i]; c.p.C = dW[i]; c.p.M = N[i]; c.p.N = K[i]; c.p.K = tok; c.p.lda = N[i]; c.p.ldb = K[i]; c.p.ldc = K[i]; c.p.alpha = 1.0f; c.p.rowadd_div = 1;
+    }
+    int rc = vc_gemm_dma_wgrad_batched(calls, n, scratch, scratch_bytes, (vc_stream_t)stream);
+    if (!rc && vc_last_launch_error()) { vc_set_error("vcad_op_wgrad_batched: launch failed"); return VC_ERR_LAUNCH; }
+    return rc;
+}
+
 // fp32 -> pre-split bf16x3 operand words (VCAD_PK storage: what bf16x3 engines keep as their weight shadow)
 int vcad_op_pack_x3(const float* x, void* y, int64_t n, void* stream) {
     int rc = vc_pack_x3(x, (uint32_t*)y, n, (vc_stream_t)stream);

@@ -398,6 +398,7 @@ size_t plan(vcad_engine* e, int B, int T, char* base) {
 // the ViT MLP's GELU / GELU' as their own passes behind plain GEMMs (bf16 mode): 1 = yes, 0 = fused into the GEMM epilogues (r01; A/B build only)
 #define g_split_gelu VC_AB(split_gelu, 1)
 #define g_no_side VC_AB(no_side, 0)
+#define g_batch_wg VC_AB(batch_wg, 1)         // A/B: 0 = a full ViT layer's net.4 / net.0 / to_out weight gradients as three launches (r05)
 #define g_res_in_ln VC_AB(res_in_ln, 1)       // A/B: 0 = r04's residual adds in the to_out / net.4 GEMM epilogues
 #define CK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 #define CK_(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -785,7 +786,13 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
         if (!have_du) CK(cx.masked(dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_MLP_OUT), &du, nullptr, pk));     // else: emitted by the layer above's LayerNorm backward
         const bool have_db4 = have_du;
         have_du = false;
-        CK(cx.lin_wgrad(du, cx.VT(l.g, c.vit_mlp, pk), cx.Gf(wl.w4), c.vit_mlp, have_db4 ? nullptr : cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));   // (b4's gradient: from the LayerNorm backward that emitted du)
+        // r06: a full layer's three small weight gradients (net.4, net.0, to_out: token reductions over the same R rows) run as ONE launch of the persistent kernel once
+        // the third one's masked gradient exists (ops_gemm_dma.hip vc_gemm_dma_wgrad_batched) — train mode only: every dY is then a private 16-bit copy that lives that long
+        // (the attention norm's backward emits its du into a forward-only temporary instead of over the MLP's)
+        const bool batch3 = g_batch_wg && e->dt == VC_BF16 && e->ct == VC_BF16 && !e->fp8 && !cls_only && !pk && e->drop_p > 0.f && Rm % 64 == 0 && (R >= 8192 || (e->gemm_flags & VC_GF_DMA_ALWAYS)) && du.dt == e->dt;      // (small towers stay on the small-problem kernels; tests force the persistent kernel)
+        const Mat du_mlp = du;
+        if (!batch3) CK(cx.lin_wgrad(du, cx.VT(l.g, c.vit_mlp, pk), cx.Gf(wl.w4), c.vit_mlp, have_db4 ? nullptr : cx.Gf(wl.b4), (int)Rm, D, c.vit_mlp));   // (b4's gradient: from the LayerNorm backward that emitted du)
+        else if (!have_db4) CK(cx.colsum(du, Rm, D, cx.Gf(wl.b4), 0));
         bool have_db1 = false;
         { Epi ep; ep.dact = l.z; ep.lddact = c.vit_mlp; ep.dkind = VC_ACT_GELU; ep.drop = cx.site(v + 1, L, Ctx::K_MLP_ACT);
           const bool split = e->dt == VC_BF16 && g_split_gelu && !cls_only;      // bf16: plain dgrad, then the activation-derivative pass
@@ -796,12 +803,31 @@ int vit_backward(const Ctx& cx, int v, const float* de, int part /*0 = whole, 1 
           if (split && defer_cs) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), l.part_b1, (size_t)vc_dact_bwd_blocks(Rm, c.vit_mlp) * c.vit_mlp * 4, nullptr, true));
           else if (split) CK(vc_dact_bwd_bf16(cx.L().t_dz, l.z, Rm, c.vit_mlp, VC_ACT_GELU, ep.drop, cx.s, cx.Gf(wl.b1), cx.L().scr_lnpart, cx.L().scr_lnpart_bytes, cx.L().scr_colsum));
           have_db1 = split; }
-        CK(cx.lin_wgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.VT(l.h_f, D, pk), cx.Gf(wl.w1), D, have_db1 ? nullptr : cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
+        if (!batch3) CK(cx.lin_wgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.VT(l.h_f, D, pk), cx.Gf(wl.w1), D, have_db1 ? nullptr : cx.Gf(wl.b1), (int)Rm, c.vit_mlp, D));
+        else if (!have_db1) CK(cx.colsum(cx.AT(cx.L().t_dz, c.vit_mlp), Rm, c.vit_mlp, cx.Gf(wl.b1), 0));
         if (cx.hasT(wl.w1T)) CK(cx.lin_dgrad_T(cx.AT(cx.L().t_dz, c.vit_mlp), cx.WT(wl.w1T, c.vit_mlp), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         else CK(cx.lin_dgrad(cx.VT(cx.L().t_dz, c.vit_mlp, pk), cx.W(wl.w1, D), cx.AT(cx.L().t_dh, D), (int)Rm, c.vit_mlp, D, Epi()));
         // attention block (xm = x + drop(Wo ao + bo)): the LayerNorm backward also emits du = dx * mask_out
-        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, nullptr, cx.Gf(wl.ob), defer_cs ? l.part_fn : nullptr, pk));
-        CK(cx.lin_wgrad(du, cx.VT(l.ao, ldao, pk), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
+        CK(cx.ln_bwd(e->dt, cx.L().t_dh, D, l.xm, ldx, l.stat_f, wl.fnw, wl.fnb, dx, ldx, dx, ldx, Rm, D, cx.site(v + 1, L, Ctx::K_OUT), &du, batch3 ? cx.L().t_y[0] : nullptr, cx.Gf(wl.ob), defer_cs ? l.part_fn : nullptr, pk));
+        if (batch3 && du.dt == e->dt) {
+            GemmCall gc[3];
+            auto fill = [&](GemmCall& g, Mat dY, Mat X, long w_off, int N_, int K_) {
+                memset(&g, 0, sizeof(g));
+                g.ct = e->ct; g.sa = dY.dt; g.sb = X.dt; g.to = VC_F32; g.tra = 1; g.trb = 1; g.flags = e->gemm_flags; g.claim = (e->gemm_flags & VC_GF_DYNAMIC) ? cx.L().claim : nullptr;
+                g.p.A = dY.p; g.p.B = X.p; g.p.C = (void*)cx.Gf(w_off); g.p.M = N_; g.p.N = K_; g.p.K = (int)Rm; g.p.lda = dY.ld; g.p.ldb = X.ld; g.p.ldc = K_; g.p.alpha = 1.0f; g.p.rowadd_div = 1;
+            };
+            fill(gc[0], du_mlp, cx.AT(l.g, c.vit_mlp), wl.w4, D, c.vit_mlp);
+            fill(gc[1], cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), wl.w1, c.vit_mlp, D);
+            fill(gc[2], du, cx.AT(l.ao, ldao), wl.ow, D, inner);
+            CK(vc_gemm_dma_wgrad_batched(gc, 3, cx.L().scr_splitk, cx.L().scr_splitk_bytes, cx.s));
+            ++e->kernel_launches[VC_TAG_GEMM_DMA];
+        } else {
+            if (batch3) {      // (cannot happen in train mode: the norm backward emitted no private copy) the two deferred gradients on their own
+                CK(cx.lin_wgrad(du_mlp, cx.AT(l.g, c.vit_mlp), cx.Gf(wl.w4), c.vit_mlp, nullptr, (int)Rm, D, c.vit_mlp));
+                CK(cx.lin_wgrad(cx.AT(cx.L().t_dz, c.vit_mlp), cx.AT(l.h_f, D), cx.Gf(wl.w1), D, nullptr, (int)Rm, c.vit_mlp, D));
+            }
+            CK(cx.lin_wgrad(du, cx.VT(l.ao, ldao, pk), cx.Gf(wl.ow), inner, nullptr, (int)Rm, D, inner));       // (ob's gradient: reduced by the LayerNorm backward above)
+        }
         if (cx.hasT(wl.owT)) CK(cx.lin_dgrad_T(du, cx.WT(wl.owT, D), cx.AT(cx.L().t_dao, inner), (int)Rm, D, inner, Epi()));
         else CK(cx.lin_dgrad(du, cx.W(wl.ow, inner), cx.VT(cx.L().t_dao, inner, pk), (int)Rm, D, inner, Epi()));
         if (cls_only && e->cls[v].on) {      // r06 (attn_cls.h): dc = dout W_v -> kernel (dg, dh of every token) -> dq = dg W_k^T; weight gradients of the three slices

@@ -141,7 +141,7 @@ template <int NM, int ND> VC_DEV void gd_interleave() {
 #endif
 }
 
-struct GdCursor { int item, kt, ntc, seq, z, tn, row0, mend, li; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile column, first row, row bound), index in the workgroup's static list
+struct GdCursor { int item, kt, ntc, seq, z, tn, row0, mend, li, pb; };   // item, k-tile within it, its k-tile count, items started, (k-slice, tile column, first row, row bound), index in the workgroup's static list, problem (GdBatch)
 // Mini tiles (r06).  800 tiles on 256 CUs are 3.125 rounds: 32 workgroups walk a fourth tile while 224 idle (the N = 512 Linears of the ViT at the benchmark
 // shape: a fifth of 30 launches per step).  With h > 0 the rows from tile row tm0 on are cut into pieces of h (64 / 128) rows instead: the same tile program on a
 // tile of which only the first h rows exist — the A rows beyond are clamped re-reads of the piece's last row (one cache line per DMA piece), the waves that
@@ -150,6 +150,16 @@ struct GdCursor { int item, kt, ntc, seq, z, tn, row0, mend, li; };   // item, k
 // Item ids: [0, nfull) = full tiles (k-slice, tile row, tile column), [nfull, nfull + nmini) = minis (piece, tile column); every XCD's list is its chunk of the full
 // tiles followed by its chunk of the minis.  h = 0: no minis (nfull = total).
 struct GdMini { int tm0, h, nfull, nmini; };
+// Several weight-gradient problems in ONE launch (r06; tr-read layouts, k-slice slabs only).  A ViT layer's three small weight gradients — net.4 and net.0 (512 x 512)
+// and to_out (512 x 1 024), all token reductions over the same 102 400 rows — ran as three launches of 256 items with 25-50 k-tiles each: at ~98 us apiece for 50 us of
+// k-tiles, mostly ramp-up, a 256 KiB slab per item and tail.  Batched they are 16 tiles x 16 k-slices = 256 items of 100 k-tiles: one ramp, a quarter of the slab
+// traffic.  Item ids run k-slice major over ALL problems' tiles (an XCD's chunk still shares one k-slice's operands); problem i's operands, extents and slab base
+// replace GemmParams' per item.  n <= 1: the single problem of GemmParams.
+constexpr int GD_MAXB = 4;
+struct GdBatch { int n, tiles_all; const void* A[GD_MAXB]; const void* B[GD_MAXB]; float* part[GD_MAXB]; int M[GD_MAXB], N[GD_MAXB]; long lda[GD_MAXB], ldb[GD_MAXB];
+                 int t0[GD_MAXB] /* first tile of problem i within a k-slice (unused: INT_MAX) */, tn[GD_MAXB] /* its tile columns */; };
+// (wave-uniform index into a by-value kernel argument: a select chain — a dynamic index would make hipcc copy the struct to scratch)
+template <typename T> VC_DEV T gd_sel(const T (&a)[GD_MAXB], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
 template <int PW, int NS>
@@ -201,7 +211,7 @@ VC_DEV void gd_epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], c
 // per 8 (128 KiB of reads per k-tile), and a wave hides its own fragment latency behind 16 back-to-back MFMAs.  All four waves issue
 // their quarter of every stage (no second wave on the SIMD to take turns with).
 template <typename TO, bool TRA, bool TRB, int BN, bool COLW, int NW = 8, int BK = 64>
-VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn, int* claim, GdMini mn) {
+VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int tiles_n, int tiles_mn, int nsplit, int total, int xn, int* claim, GdMini mn, GdBatch bt) {
     using TL = GdTile<BN, BK>;
     static_assert(NW == 8 || (NW == 4 && BN == 256 && BK == 64), "four-wave form: 256-wide tile, 64-deep stages only");
     static_assert(BK == 64 || (TRA && TRB), "32-deep stages: the row-contiguous (tr-read) layouts only");
@@ -220,8 +230,9 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     int* const tk = reinterpret_cast<int*>(bias_lds + NBIAS * BN);        // dynamic claiming: item of sequence number s at tk[s & 7]
     const int tid = threadIdx.x, lane = tid & 63, wave = vc_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const unsigned char* Ag = (const unsigned char*)p.A;
+    const unsigned char* Ag = (const unsigned char*)p.A;      // operand bases / k-steps of the item the PREFETCH cursor is on (retarget moves them in a batched launch)
     const unsigned char* Bg = (const unsigned char*)p.B;
+    const bool batched = bt.n > 1;
 
     // this workgroup's items: XCD x (= block id & 7, the hardware's round-robin) owns one contiguous chunk of the item list
     // (items ordered k-slice major, then tile_m, tile_n fastest), and its workgroups sweep that chunk interleaved — at any
@@ -294,13 +305,21 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     const int grp = NW == 8 ? wave >> 2 : 0, wq = wave & 3;
     auto my_turn = [&](int tn) { return NW == 4 || grp == tn; };
     // bytes one k-tile advances the (wave-uniform) operand base
-    const long kstepA = TRA ? (long)BK * p.lda * 2 : (long)BK * 2, kstepB = TRB ? (long)BK * p.ldb * 2 : (long)BK * 2;
+    long kstepA = TRA ? (long)BK * p.lda * 2 : (long)BK * 2, kstepB = TRB ? (long)BK * p.ldb * 2 : (long)BK * 2;
 
     auto locate = [&](GdCursor& c) {            // integer divisions: once per item, never per k-tile
         if (c.item >= mn.nfull) {               // mini: (piece, tile column), mn.h rows from row mn.tm0 * GD_BM + piece * mn.h (single k-slice launches only)
             const int m_ = c.item - mn.nfull, pc = m_ / tnc;
             c.z = 0; c.tn = m_ - pc * tnc; c.row0 = mn.tm0 * GD_BM + pc * mn.h; c.mend = c.row0 + mn.h < p.M ? c.row0 + mn.h : p.M;
             c.ntc = ktiles < nt ? ktiles : nt;
+            return;
+        }
+        if (batched) {                          // (k-slice, problem, tile row, tile column)
+            c.z = c.item / bt.tiles_all; const int rem = c.item - c.z * bt.tiles_all;
+            c.pb = (rem >= bt.t0[1]) + (rem >= bt.t0[2]) + (rem >= bt.t0[3]);
+            const int r2 = rem - gd_sel(bt.t0, c.pb), tnp = gd_sel(bt.tn, c.pb), rm_ = r2 / tnp;
+            c.row0 = rm_ * GD_BM; c.mend = gd_sel(bt.M, c.pb); c.tn = r2 - rm_ * tnp;
+            const int rest = ktiles - c.z * nt; c.ntc = rest < nt ? rest : nt;
             return;
         }
         c.z = c.item / tmn; const int rem = c.item - c.z * tmn;
@@ -318,6 +337,14 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
     };
     uint32_t offA[NPA], offB[NPB];
     auto retarget = [&](const GdCursor& c) {
+        if (batched) {
+            const long lda = gd_sel(bt.lda, c.pb), ldb = gd_sel(bt.ldb, c.pb);
+            Ag = (const unsigned char*)gd_sel(bt.A, c.pb); Bg = (const unsigned char*)gd_sel(bt.B, c.pb);
+            kstepA = TRA ? (long)BK * lda * 2 : (long)BK * 2; kstepB = TRB ? (long)BK * ldb * 2 : (long)BK * 2;
+            gd_offsets<TRA, GD_BM, NPA>(offA, lda, c.row0, c.mend, wq * NPA, lane);
+            gd_offsets<TRB, BN, NPB, COL ? NJ : 0>(offB, ldb, c.tn * BN, gd_sel(bt.N, c.pb), wq * NPB, lane);
+            return;
+        }
         gd_offsets<TRA, GD_BM, NPA>(offA, p.lda, c.row0, c.mend, wq * NPA, lane);
         gd_offsets<TRB, BN, NPB, COL ? NJ : 0>(offB, p.ldb, c.tn * BN, p.N, wq * NPB, lane);
     };
@@ -331,7 +358,7 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         gd_issue<NPB>(Bg + kt_abs * kstepB, offB, st + GD_A_ELEMS_K, wq * NPB);
     };
 
-    GdCursor pf{first, 0, 1, 0, 0, 0, 0, 0, j};
+    GdCursor pf{first, 0, 1, 0, 0, 0, 0, 0, j, 0};
     if (first < last) { locate(pf); retarget(pf); }
     GdCursor cp = pf;
     int turn = 0;                                                // parity of the stage being consumed == the group that issued it
@@ -653,9 +680,11 @@ VC_KERNEL __launch_bounds__(NW * 64, 1) void gemm_dma_kernel(GemmParams p, int t
         if (p.partial || plain) {      // straight-line plain / slab stores (see the column-per-lane form above)
             auto quads = [&](auto PART) {
                 using T = typename std::conditional<decltype(PART)::value, float, TO>::type;
-                const long ld = decltype(PART)::value ? (long)p.N : p.ldc;
+                const int Mz = batched ? gd_sel(bt.M, cp.pb) : p.M, Nz = batched ? gd_sel(bt.N, cp.pb) : p.N;      // (batched launches: the problem's own extents and slab base)
+                float* const slab = batched ? gd_sel(bt.part, cp.pb) : p.partial;
+                const long ld = decltype(PART)::value ? (long)Nz : p.ldc;
                 const int m0 = row0 + wm * WR + (lane & 31), n0 = tn * BN + wn * HALF_N + 4 * (lane >> 5);
-                T* q0 = (decltype(PART)::value ? (T*)(p.partial + (long)z * p.M * p.N) : (T*)p.C) + (long)m0 * ld + n0;
+                T* q0 = (decltype(PART)::value ? (T*)(slab + (long)z * Mz * Nz) : (T*)p.C) + (long)m0 * ld + n0;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     if (m0 + i * 32 < mend) {

@@ -52,6 +52,7 @@ bool vc_profile_on();       // the HIP-event profiler is recording: per-kernel t
 int vc_gemm(GemmCall c, float* scratch, size_t scratch_bytes, vc_stream_t s);
 int vc_gemm_prepare(GemmCall& c);                                   // validation + per-problem legality flags (ops_gemm.hip)
 int vc_gemm_dma_launch(GemmCall c, int nsplit, int BN, vc_stream_t s);   // persistent DMA-fed kernel (ops_gemm_dma.hip), tile 256 x BN; c already prepared
+int vc_gemm_dma_wgrad_batched(GemmCall* calls, int n, float* scratch, size_t scratch_bytes, vc_stream_t s);   // (ops_gemm_dma.hip) up to 4 plain 16-bit weight gradients over the same token rows in one persistent launch
 int vc_gemm_mid_launch(GemmCall c, vc_stream_t s);          // gemm_mid.h (ops_gemm_mid.hip)
 int vc_gemm_mid_tile_m(int trb); int vc_gemm_mid_tile_n(int trb);
 int vc_gemm_mid_batched(GemmCall c, int batch, long bsa, long bsb, long bsc, vc_stream_t s);   // (ops_gemm_mid.hip) batch problems of one shape in one grid

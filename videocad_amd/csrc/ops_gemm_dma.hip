@@ -55,7 +55,7 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
         if (tm0 >= 0 && tm0 < tiles_m) { mn.tm0 = tm0; mn.h = MH; mn.nfull = tm0 * tiles_n; mn.nmini = VC_CEIL_DIV(c.p.M - tm0 * GD_BM, MH) * tiles_n; }
     }
     const int total_items = mn.nfull + mn.nmini;
-    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW, BK>), dim3(total_items < cus ? total_items : cus), dim3(NW * 64), (GdTile<BN, BK>::LDS_BYTES), s, c.p, tiles_n, tiles_mn, nsplit, total_items, xn, c.claim, mn);
+    VC_LAUNCH((gemm_dma_kernel<TO, TRA, TRB, BN, COLW, NW, BK>), dim3(total_items < cus ? total_items : cus), dim3(NW * 64), (GdTile<BN, BK>::LDS_BYTES), s, c.p, tiles_n, tiles_mn, nsplit, total_items, xn, c.claim, mn, GdBatch());
     }
     if (nsplit > 1) {
         long tot = (long)c.p.M * c.p.N;
@@ -65,6 +65,58 @@ static int gemm_launch_dma(GemmCall c, int nsplit, vc_stream_t s) {
     return VC_OK;
 }
 
+
+// Several weight gradients dW_i[N_i, K_i] = dY_i[tok, N_i]^T X_i[tok, K_i] over the SAME tok rows in one launch of the persistent kernel (gemm_dma.h GdBatch) + one slab sum
+// per problem.  calls[i]: tra = trb = 1, 16-bit operands, fp32 output; p.M = N_i (multiple of 8), p.N = K_i (multiple of 256), p.K = tok (multiple of 64, equal for all).
+int vc_gemm_dma_wgrad_batched(GemmCall* calls, int n, float* scratch, size_t scratch_bytes, vc_stream_t s) {
+    if (n < 1 || n > GD_MAXB) { vc_set_error("vc_gemm_dma_wgrad_batched: %d problems (1..%d)", n, GD_MAXB); return VC_ERR_ARG; }
+    GdBatch bt = GdBatch();
+    long tiles = 0, slab_floats = 0; double flops = 0, bytes = 0;
+    for (int i = 0; i < GD_MAXB; ++i) bt.t0[i] = 0x7fffffff;
+    for (int i = 0; i < n; ++i) {
+        GemmCall& c = calls[i];
+        { int rc = vc_gemm_prepare(c); if (rc) return rc; }
+        const GemmParams& p = c.p;
+        if (!(c.ct == VC_BF16 && c.sa == VC_BF16 && c.sb == VC_BF16 && c.to == VC_F32 && c.tra && c.trb && p.vecA && p.vecB && p.vecC && p.N % 256 == 0 && p.M % 8 == 0 &&
+              p.K % GD_BK == 0 && p.K == calls[0].p.K && !p.bias && !p.act && !p.aux && !p.residual && !p.dact_src && !p.drop.key && !p.rowadd && p.alpha == 1.0f)) {
+            vc_set_error("vc_gemm_dma_wgrad_batched: problem %d is not a plain 16-bit weight gradient of the common token count", i); return VC_ERR_UNSUPPORTED;
+        }
+        bt.A[i] = p.A; bt.B[i] = p.B; bt.M[i] = p.M; bt.N[i] = p.N; bt.lda[i] = p.lda; bt.ldb[i] = p.ldb; bt.t0[i] = (int)tiles; bt.tn[i] = p.N / 256;
+        tiles += (long)VC_CEIL_DIV(p.M, GD_BM) * (p.N / 256); slab_floats += (long)p.M * p.N;
+        flops += 2.0 * p.M * p.N * p.K; bytes += ((double)p.M + p.N) * p.K * 2 + (double)p.M * p.N * 4;
+    }
+    bt.n = n; bt.tiles_all = (int)tiles;
+    // k-slices: one round of the 256 one-workgroup-per-CU slots, at least 8 k-tiles per item
+    const int ktiles = calls[0].p.K / GD_BK;
+    int ns = (int)(256 / tiles); if (ns < 1) ns = 1; if (ns > ktiles / 8) ns = ktiles / 8 > 0 ? ktiles / 8 : 1; if (ns > 64) ns = 64;
+    while (ns > 1 && (size_t)ns * slab_floats * 4 > scratch_bytes) --ns;
+    const int nt = VC_CEIL_DIV(ktiles, ns); ns = VC_CEIL_DIV(ktiles, nt);
+    if (!scratch || (size_t)ns * slab_floats * 4 > scratch_bytes) { vc_set_error("vc_gemm_dma_wgrad_batched: slab scratch too small"); return VC_ERR_WORKSPACE; }
+    { float* q = scratch; for (int i = 0; i < n; ++i) { bt.part[i] = q; q += (size_t)ns * calls[i].p.M * calls[i].p.N; } }
+    GemmCall c = calls[0];
+    c.p.k_per_split = nt * GD_BK; c.p.partial = scratch;
+    using K = GdTile<256, 64>;
+#ifndef VC_EMU
+    static unsigned attr_set = 0;
+    if (!(attr_set & vc_device_bit())) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_dma_kernel<float, true, true, 256, false, 8, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS_BYTES);
+        if (e != hipSuccess) { vc_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return VC_ERR_LAUNCH; }
+        attr_set |= vc_device_bit();
+    }
+#endif
+    {
+    ProfScope ps(VC_CAT_GEMM_WGRAD, flops, bytes, s, VC_TAG_GEMM_DMA);
+    const int total = (int)tiles * ns, cus = 256 - 8 * (int)((c.flags >> VC_GF_RESERVE_SHIFT) & 15u);
+    GdMini mn = {0, 0, total, 0};
+    VC_LAUNCH((gemm_dma_kernel<float, true, true, 256, false, 8, 64>), dim3(total < cus ? total : cus), dim3(512), (K::LDS_BYTES), s, c.p, 1, (int)tiles, ns, total, 1, c.claim, mn, bt);
+    for (int i = 0; i < n; ++i) {
+        GemmParams r = calls[i].p; r.partial = bt.part[i]; r.k_per_split = nt * GD_BK;
+        const long tot = (long)r.M * r.N;
+        VC_LAUNCH((gemm_splitk_reduce4_kernel<float>), dim3((unsigned)VC_CEIL_DIV(tot / 4, 256)), dim3(256), 0, s, r, ns);       // (ns = 1: the copy out of the slab)
+    }
+    }
+    return VC_OK;
+}
 
 // column-per-lane epilogue?  Interleaved A/B on the C2 shapes (profiles/r02_gemm_epilogue_ab.txt): with the 256-wide tile a lane owns 4
 // adjacent columns (8-byte bf16 / 16-byte fp32 stores, full lines) and the plain epilogues gain 5-23 % (QKV forward 459 -> 370 us, dh

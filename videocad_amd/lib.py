@@ -101,6 +101,7 @@ PROTOTYPES = {
     "vcad_kernel_launches": (_i64, [_vp, _i]),
     "vcad_set_side_stream": (_i, [_vp, _i]),
     "vcad_op_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp, _i, _vp, _i64, _f, _vp, _sz, C.c_uint32, C.POINTER(_i), _vp]),
+    "vcad_op_wgrad_batched": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _vp, _sz, C.c_uint32, _vp]),
     "vcad_op_pack_x3": (_i, [_vp, _vp, _i64, _vp]),
     "vcad_op_quant_mx8": (_i, [_i, _vp, _i64, _vp, _vp, _i64, _i, _vp]),
     "vcad_op_gemm_mx8": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _i, _vp, _i64, _vp]),
@@ -120,7 +121,7 @@ PROTOTYPES = {
 AB_PROTOTYPES = {name: (None, [_i]) for name in (
     "vcad_debug_force_gemm_tile", "vcad_debug_gemm_dma", "vcad_debug_gemm_wide", "vcad_debug_gemm_mid", "vcad_debug_gemm_xcd_cols",
     "vcad_debug_attn_variant", "vcad_debug_gemm_waves", "vcad_debug_split_gelu", "vcad_debug_no_side_stream", "vcad_debug_gemm_policy",
-    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip", "vcad_debug_res_in_ln", "vcad_debug_wgrad_bk32", "vcad_debug_cls_path", "vcad_debug_frame_first", "vcad_debug_pe_fold", "vcad_debug_dec_h16", "vcad_debug_attn_prefetch", "vcad_debug_splitk_r06")}
+    "vcad_debug_gemm_epilogue", "vcad_debug_gemm_variant", "vcad_debug_gemm_stagger", "vcad_debug_gemm_skip", "vcad_debug_res_in_ln", "vcad_debug_wgrad_bk32", "vcad_debug_cls_path", "vcad_debug_frame_first", "vcad_debug_pe_fold", "vcad_debug_dec_h16", "vcad_debug_attn_prefetch", "vcad_debug_splitk_r06", "vcad_debug_batch_wgrad")}
 AB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_bin", "libvcad_ab.so")
 
 
