@@ -158,8 +158,28 @@ struct GdMini { int tm0, h, nfull, nmini; };
 constexpr int GD_MAXB = 4;
 struct GdBatch { int n, tiles_all; const void* A[GD_MAXB]; const void* B[GD_MAXB]; float* part[GD_MAXB]; int M[GD_MAXB], N[GD_MAXB]; long lda[GD_MAXB], ldb[GD_MAXB];
                  int t0[GD_MAXB] /* first tile of problem i within a k-slice (unused: INT_MAX) */, tn[GD_MAXB] /* its tile columns */; };
+// slab sums of a batched launch in one grid: problem i owns quads [q0[i], q0[i + 1]) of the flat quad index; plain fp32 output (C[m][n], ld = ldc)
+struct GdBatchReduce { int n; long q0[GD_MAXB + 1]; const float* part[GD_MAXB]; float* C[GD_MAXB]; int N[GD_MAXB]; long MN[GD_MAXB], ldc[GD_MAXB]; };
 // (wave-uniform index into a by-value kernel argument: a select chain — a dynamic index would make hipcc copy the struct to scratch)
 template <typename T> VC_DEV T gd_sel(const T (&a)[GD_MAXB], int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+VC_KERNEL __launch_bounds__(256) void gemm_splitk_reduce4_batched_kernel(GdBatchReduce r, int nsplit) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= r.q0[r.n]) return;
+    const int pb = (q >= r.q0[1]) + (r.n > 2 && q >= r.q0[2]) + (r.n > 3 && q >= r.q0[3]);       // (per lane: a block may straddle two problems)
+    const long idx = (q - (pb == 0 ? r.q0[0] : (pb == 1 ? r.q0[1] : (pb == 2 ? r.q0[2] : r.q0[3])))) * 4;
+    const float* part = pb == 0 ? r.part[0] : (pb == 1 ? r.part[1] : (pb == 2 ? r.part[2] : r.part[3]));
+    float* C = pb == 0 ? r.C[0] : (pb == 1 ? r.C[1] : (pb == 2 ? r.C[2] : r.C[3]));
+    const long MN = pb == 0 ? r.MN[0] : (pb == 1 ? r.MN[1] : (pb == 2 ? r.MN[2] : r.MN[3])), ldc = pb == 0 ? r.ldc[0] : (pb == 1 ? r.ldc[1] : (pb == 2 ? r.ldc[2] : r.ldc[3]));
+    const int N = pb == 0 ? r.N[0] : (pb == 1 ? r.N[1] : (pb == 2 ? r.N[2] : r.N[3]));
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nsplit; ++z) {           // fixed order: deterministic (the order of gemm_splitk_reduce4_kernel)
+        float v[4]; quad_ld_f32(part + (long)z * MN + idx, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += v[k];
+    }
+    const long m = idx / N; const int n = (int)(idx - m * N);
+    quad_st<float>(C + m * ldc + n, s);
+}
 
 // wait until at most n VMEM operations of this wave are outstanding (n wave-uniform; rounded DOWN to an encodable immediate)
 template <int PW, int NS>

@@ -109,11 +109,12 @@ int vc_gemm_dma_wgrad_batched(GemmCall* calls, int n, float* scratch, size_t scr
     const int total = (int)tiles * ns, cus = 256 - 8 * (int)((c.flags >> VC_GF_RESERVE_SHIFT) & 15u);
     GdMini mn = {0, 0, total, 0};
     VC_LAUNCH((gemm_dma_kernel<float, true, true, 256, false, 8, 64>), dim3(total < cus ? total : cus), dim3(512), (K::LDS_BYTES), s, c.p, 1, (int)tiles, ns, total, 1, c.claim, mn, bt);
-    for (int i = 0; i < n; ++i) {
-        GemmParams r = calls[i].p; r.partial = bt.part[i]; r.k_per_split = nt * GD_BK;
-        const long tot = (long)r.M * r.N;
-        VC_LAUNCH((gemm_splitk_reduce4_kernel<float>), dim3((unsigned)VC_CEIL_DIV(tot / 4, 256)), dim3(256), 0, s, r, ns);       // (ns = 1: the copy out of the slab)
-    }
+    GdBatchReduce rd = GdBatchReduce(); rd.n = n;                   // one slab-sum grid for all problems (ns = 1: the copy out of the slab)
+    long q = 0;
+    for (int i = 0; i < GD_MAXB + 1; ++i) rd.q0[i] = 0;
+    for (int i = 0; i < n; ++i) { rd.q0[i] = q; rd.part[i] = bt.part[i]; rd.C[i] = (float*)calls[i].p.C; rd.N[i] = calls[i].p.N; rd.MN[i] = (long)calls[i].p.M * calls[i].p.N; rd.ldc[i] = calls[i].p.ldc; q += rd.MN[i] / 4; }
+    for (int i = n; i < GD_MAXB + 1; ++i) rd.q0[i] = q;
+    VC_LAUNCH(gemm_splitk_reduce4_batched_kernel, dim3((unsigned)VC_CEIL_DIV(q, 256)), dim3(256), 0, s, rd, ns);
     }
     return VC_OK;
 }
